@@ -1,0 +1,112 @@
+"""Two-pass fit -> full ViennaRNA-layout tables -> params/turner2004_fitted.json
+
+pass 1: L1 fit with rule priors.  From its int22 values an additive
+pair-frame mismatch model is least-squares fitted and, rounded to 10 dcal,
+becomes the prior of the *unseen* 2x2 entries; the GC-CG measured 1x2 block is
+propagated to the GU-CG / GC-UG / GU-UG blocks (pattern visible in the fit).
+pass 2: L1 fit again with the improved priors.  Every entry records whether a
+KAT triple exercises it (`pinned`) or whether it is a rule/prior value.
+"""
+import json, sys, os, itertools
+import numpy as np
+from . import kats, model, fit, prior as P
+
+OUT = os.path.join(os.path.dirname(__file__), "..", "..", "params", "turner2004_fitted.json")
+
+
+def additive_int22(th, cnt):
+    idx = {}
+    def fi(t, x, y):
+        return idx.setdefault((t, x, y), len(idx))
+    items = [(k, v) for k, v in th.items() if k[0] == "int22"]
+    rows = [(fi(k[1], k[3], k[6]), fi(k[2], k[5], k[4])) for k, _ in items]
+    A = np.zeros((len(rows), len(idx) + 1))
+    for i, (p, q) in enumerate(rows):
+        A[i, p] += 1; A[i, q] += 1; A[i, -1] = 1
+    y = np.array([v for _, v in items], float)
+    W = np.sqrt(np.array([min(cnt[k], 5) for k, _ in items], float))
+    sol, *_ = np.linalg.lstsq(A * W[:, None], y * W, rcond=None)
+    mean_f = {}
+    for t in range(1, 7):
+        vals = [sol[j] for (tt, x, yy), j in idx.items() if tt == t]
+        mean_f[t] = float(np.mean(vals)) if vals else 0.0
+    def pred(t1, t2, a, b, c, d):
+        f1 = sol[idx[(t1, a, d)]] if (t1, a, d) in idx else mean_f[t1]
+        f2 = sol[idx[(t2, c, b)]] if (t2, c, b) in idx else mean_f[t2]
+        return int(round((f1 + f2 + sol[-1]) / 10.0)) * 10
+    return pred
+
+
+def _pur(t, x, y):
+    if (x, y) in ((3, 1), (3, 3)):
+        return True
+    return (x, y) == (1, 3) and t in (1, 4, 6)
+
+
+def int21_rule(t1, t2, a, b, c):
+    n = (t1 > 2) + (t2 > 2)
+    base = 230 + 70 * n
+    if _pur(t1, a, c) or _pur(t2, b, a):
+        return base - (120 if n == 0 else 110)
+    if a == 4 and (b == 4 or c == 4):
+        return base - (80 if n < 2 else 70)
+    return base
+
+
+def main():
+    ks = kats.load_fixture()
+    P.int21_prior = int21_rule
+    th1, cnt1 = fit.fitted_theta(ks)
+    pred22 = additive_int22(th1, cnt1)
+    P.int22_prior = pred22
+
+    def int21_p2(t1, t2, a, b, c):
+        if (t1, t2) in ((3, 1), (2, 4), (3, 4)):
+            k = ("int21", 2, 1, a, b, c)
+            if k in th1 and cnt1[k] >= 2:
+                return th1[k]
+        return int21_rule(t1, t2, a, b, c)
+    P.int21_prior = int21_p2
+    th, cnt = fit.fitted_theta(ks)
+    # verify
+    bad = sum(1 for s, st, d in ks if model.energy(s, st, th) != d)
+    print("KAT mismatches after fit:", bad, "of", len(ks), file=sys.stderr)
+    assert bad == 0
+
+    def val(key):
+        return th[key] if key in th else model.prior_value(key)
+
+    out = {"pinned": sorted(["|".join(map(str, k)) for k in th]), "tables": {}}
+    T = out["tables"]
+    T["stack"] = [[val(model.canon_stack(a, b)) for b in range(1, 7)] for a in range(1, 7)]
+    T["hairpin"] = [P.INF if P.HAIRPIN[i] >= P.INF else val(("hp", i)) for i in range(31)]
+    T["bulge"] = [P.INF if P.BULGE[i] >= P.INF else val(("bulge", i)) for i in range(31)]
+    T["interior"] = [P.INF if P.INTERIOR[i] >= P.INF else val(("int", i)) for i in range(31)]
+    for name, key in (("mismatch_hairpin", "mmH"), ("mismatch_interior", "mmI"),
+                      ("mismatch_interior_1n", "mm1n"), ("mismatch_interior_23", "mm23"),
+                      ("mismatch_multi", "mmM"), ("mismatch_exterior", "mmE")):
+        T[name] = [[[val((key, t, a, b)) for b in range(1, 5)] for a in range(1, 5)] for t in range(1, 7)]
+    T["dangle5"] = [[val(("d5", t, a)) for a in range(1, 5)] for t in range(1, 7)]
+    T["dangle3"] = [[val(("d3", t, a)) for a in range(1, 5)] for t in range(1, 7)]
+    T["int11"] = [[[[val(model.canon_int11(t1, t2, a, b)) for b in range(1, 5)] for a in range(1, 5)]
+                   for t2 in range(1, 7)] for t1 in range(1, 7)]
+    T["int21"] = [[[[[val(("int21", t1, t2, a, b, c)) for c in range(1, 5)] for b in range(1, 5)]
+                    for a in range(1, 5)] for t2 in range(1, 7)] for t1 in range(1, 7)]
+    T["int22"] = [[[[[[val(model.canon_int22(t1, t2, a, b, c, d)) for d in range(1, 5)] for c in range(1, 5)]
+                     for b in range(1, 5)] for a in range(1, 5)] for t2 in range(1, 7)] for t1 in range(1, 7)]
+    T["ml_base"] = val(("MLbase",)); T["ml_closing"] = val(("MLclosing",)); T["ml_intern"] = val(("MLintern",))
+    T["ninio"] = P.NINIO; T["max_ninio"] = P.MAX_NINIO; T["terminal_au"] = val(("termAU",)); T["lxc"] = P.LXC
+    T["triloops"] = {k: val(("tri", k)) for k in P.TRILOOPS}
+    T["tetraloops"] = {k: val(("tetra", k)) for k in P.TETRALOOPS}
+    T["hexaloops"] = {k: val(("hexa", k)) for k in P.HEXALOOPS}
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    json.dump(out, open(OUT, "w"), indent=0, separators=(",", ":"))
+    # stats
+    import collections
+    tot = {"int11": 6 * 6 * 16, "int21": 6 * 6 * 64, "int22": 6 * 6 * 256}
+    seen = collections.Counter(k[0] for k in th)
+    print({k: (seen[k], tot.get(k)) for k in seen}, file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()
