@@ -1,0 +1,133 @@
+/*
+ * rafft_hip.h - C-ABI of libraffthip.so, the MI355X (gfx950) RAFFT folding engine.
+ *
+ * The reference (lemerleau/RAFFT) is pure Python and has no FFI; its seam for the
+ * fold hot path is the Python API + CLI + fast-folding-graph text format
+ * (SURVEY.md section 8b).  This header is what a maintainer of the reference binds
+ * with ctypes to make `rafft.fold()` / `bin/rafft` run on the
+ * GPU.  Plain C types only; no exceptions cross the boundary; the library allocates
+ * results and the caller frees them with rafft_free_result().
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the
+ * reference tree).
+ */
+#ifndef RAFFT_HIP_H
+#define RAFFT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes (per call and per sequence) */
+enum {
+    RAFFT_OK = 0,
+    RAFFT_ERR_BAD_CHAR = 1,      /* reference: KeyError from prep_sequence, rafft/utils.py:73-80 */
+    RAFFT_ERR_EMPTY = 2,         /* reference: numpy AxisError from flip(), rafft/utils.py:83 */
+    RAFFT_ERR_TOO_LONG = 3,      /* L > RAFFT_MAX_LEN (one node's FFT must fit one workgroup's LDS) */
+    RAFFT_ERR_TEMP = 4,          /* only 37 C tables exist (no ViennaRNA to rescale with) */
+    RAFFT_ERR_CAPACITY = 5,      /* an HBM arena overflowed even after regrowth */
+    RAFFT_ERR_PARAM = 6,         /* unsupported parameter combination (e.g. max_branch+2*max_stack too large) */
+    RAFFT_ERR_HIP = 7,           /* HIP runtime error; see rafft_last_error() */
+    RAFFT_ERR_STRUCT = 8,        /* malformed dot-bracket / non-canonical pair in rafft_eval_structure */
+    RAFFT_ERR_NO_DEVICE = 9
+};
+
+#define RAFFT_MAX_LEN 4096
+
+/* Mirrors the argument list of rafft.fold(), rafft/rafft.py:219-221 (and
+ * Glob_parms, rafft/utils.py:9-21). */
+typedef struct {
+    int32_t nb_mode;     /* -n  : number of positional lags searched per unpaired region */
+    int32_t max_stack;   /* -ms : beam width */
+    int32_t max_branch;  /* --max_branch */
+    int32_t min_hp;      /* -mh */
+    double min_nrj;      /* -mn */
+    int32_t traj;        /* 0: final beam only; 1: beam of every folding step */
+    int32_t _pad;
+    double temp;         /* must be 37.0 */
+    double gc_wei, au_wei, gu_wei;
+} rafft_params;
+
+/* Per-sequence result: the fast-folding graph (bin/rafft:73-79) as arrays.
+ * n_steps == 1 when params.traj == 0 (the final beam). */
+typedef struct {
+    int32_t status;
+    int32_t length;
+    int32_t n_steps;
+    int32_t n_structs;        /* total rows over all steps */
+    const int32_t *step_size; /* [n_steps] */
+    const int32_t *step_off;  /* [n_steps] first row of each step */
+    const char *db;           /* n_structs rows of (length+1) bytes, NUL terminated dot-brackets */
+    const int32_t *dcal;      /* [n_structs] free energy in dcal/mol; kcal/mol = (float)dcal/100 as
+                                 ViennaRNA's eval_structure returns it (rafft/utils.py:135-138) */
+} rafft_seq_result;
+
+typedef struct {
+    int32_t n_seq;
+    int32_t _pad;
+    rafft_seq_result *seq;    /* [n_seq] in input order */
+    void *_owner;             /* private */
+} rafft_result;
+
+/* Kernel timing / traffic counters of the last rafft_fold_batch() on this thread's
+ * device (HIP events on the library's own stream). */
+typedef struct {
+    double ms_total;          /* wall time of the call, host side */
+    double ms_expand;         /* sum of expand-kernel durations (HIP events) */
+    double ms_beam;           /* sum of beam-step kernel durations */
+    double ms_materialize;    /* sum of materialize kernel durations */
+    double ms_output;         /* output formatting kernel */
+    int64_t n_expand_launches;
+    int64_t n_steps;          /* folding steps executed (max over sequences) */
+    int64_t n_node_expansions;/* unique (structure,node) pairs expanded */
+    int64_t sum_node_len;     /* sum of n over expansions */
+    int64_t sum_lags;         /* sum of min(nb_mode, 2n-1) over expansions */
+    int64_t n_structs;        /* structures materialized (beam survivors) */
+    int64_t n_children;       /* children accepted by the combine step */
+    int64_t sum_struct_len;   /* sum of L over materialized structures */
+    int64_t alg_bytes;        /* algorithmic HBM bytes, SURVEY.md section 8d formula */
+    int64_t alg_bytes_expand; /* the part attributed to the expand kernel */
+} rafft_stats;
+
+/* Select the GPU (HIP ordinal) and upload the energy tables.  Optional: every other
+ * entry point initialises lazily on device 0. */
+int rafft_init(int device);
+
+/* Replaces: one rafft.fold() call per sequence (rafft/rafft.py:219-239), i.e. the
+ * body of benchmark_results/bench_fft.py:8-22 for a whole batch.  `device` < 0 keeps
+ * the current device.  Sequences are independent; results come back in input order. */
+int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs,
+                     const int *lens, int device, rafft_result **out);
+
+void rafft_free_result(rafft_result *r);
+
+/* Thread-local message of the last failing call. */
+const char *rafft_last_error(void);
+
+/* Replaces: RNA.fold_compound(seq, md).eval_structure(db), the ViennaRNA call of
+ * rafft/utils.py:135-138 (also benchmark_results/scoring.py:125).  Evaluated on the
+ * GPU with the same device functions the fold kernels use. */
+int rafft_eval_structure(const char *seq, const char *db, int *dcal_out);
+int rafft_eval_structures(int n, const char *const *seqs, const char *const *dbs, int *dcal_out,
+                          int *status_out);
+
+/* Kernel-level seam for parity tests; replaces create_childs' search part:
+ * auto_cor (rafft/utils.py:125-132) + ranking (rafft/rafft.py:117-118,92) +
+ * window_slide (rafft/rafft.py:36-83) + the energy filter/sort of
+ * find_best_consecutives (rafft/rafft.py:86-109) for ONE unpaired region `pos[0..n)`
+ * of the structure `db`.  Output arrays must hold min(nb_mode, 2n-1) entries. */
+int rafft_expand_node(const rafft_params *p, const char *seq, const char *db, const int *pos, int n,
+                      int *n_ranked, int *lag, double *corval, int *nb, int *mi, int *mj,
+                      double *score, int *ddcal, int *n_kept, int *kept);
+
+int rafft_get_stats(rafft_stats *out);
+
+/* library / build information: "gfx950 ..." */
+const char *rafft_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,693 @@
+// rafft_api.hip - host side of libraffthip.so: the C-ABI of include/rafft_hip.h.
+//
+// One process drives one GPU.  All kernels run on the library's own HIP stream; the
+// host loop is the reference's bfs_pairs recursion (rafft/rafft.py:156-216) turned
+// into an iteration over folding steps that advances every sequence of the batch at
+// once:   expand (new unpaired regions) -> beam step (per sequence) -> materialize
+// (new beam members) -> ... until every sequence reached its fixed point.
+#include "../../include/rafft_hip.h"
+#include "rafft_kernels.h"
+#include "turner2004_tables.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+// kernels (rafft_kernels.hip is compiled into the same translation unit so the
+// templates and the Dev struct are shared without a device-link step)
+#include "rafft_kernels.hip"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(x)                                                                                      \
+    do {                                                                                               \
+        hipError_t e_ = (x);                                                                           \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(RAFFT_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_));                 \
+    } while (0)
+
+struct Buf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct Ctx {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    EnergyTables *T = nullptr;
+    float2 *tw = nullptr;
+    size_t hbm_total = 0;
+    std::vector<Buf *> bufs;
+    // named workspace buffers (grow-only)
+    Buf codes, seq_off, seq_len, beam, beam_n, done, nsteps, ch_parent, ch_combo, ch_dcal, ch_h, seen, seen_off,
+        seen_cap, seen_cnt, st_seq, st_dcal, st_node0, st_nnodes, st_parent, st_h, st_pt, st_cursor, st_combo, nd_sid,
+        nd_n, nd_ci, nd_cj, nd_ncand, nd_pos, nd_cand, pos, pt, cand, trec, tsid, work0, work1, work2, mat, counters,
+        row_sid, row_off, out_db, out_dcal, dbg;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    rafft_stats stats{};
+    std::mutex mu;
+};
+Ctx g;
+
+int ensure(Buf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return 0;
+    if (b.p) { hipError_t e = hipFree(b.p); (void)e; b.p = nullptr; b.cap = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(RAFFT_ERR_HIP, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
+    }
+    b.cap = want;
+    return 0;
+}
+
+uint32_t key_of(const char *s, int m)
+{
+    uint32_t k = 0;
+    for (int t = 0; t < m; t++) {
+        int c = s[t] == 'A' ? 1 : s[t] == 'C' ? 2 : s[t] == 'G' ? 3 : s[t] == 'U' ? 4 : 0;
+        k |= (uint32_t)c << (3 * t);
+    }
+    return k;
+}
+
+int init_ctx(int device)
+{
+    if (g.ready && (device < 0 || device == g.device)) return 0;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(RAFFT_ERR_NO_DEVICE, "no HIP device: libraffthip.so has no CPU fallback");
+    if (device < 0) device = 0;
+    if (device >= ndev) return fail(RAFFT_ERR_NO_DEVICE, "device ordinal out of range");
+    if (g.ready) return fail(RAFFT_ERR_PARAM, "library already initialised on another device in this process");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    g.hbm_total = prop.totalGlobalMem;
+    HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    // energy tables
+    EnergyTables *h = new EnergyTables();
+    memset(h, 0, sizeof *h);
+    memcpy(h->stack, t04_stack, sizeof h->stack);
+    memcpy(h->mmH, t04_mismatch_hairpin, sizeof h->mmH);
+    memcpy(h->mmI, t04_mismatch_interior, sizeof h->mmI);
+    memcpy(h->mm1n, t04_mismatch_interior_1n, sizeof h->mm1n);
+    memcpy(h->mm23, t04_mismatch_interior_23, sizeof h->mm23);
+    memcpy(h->mmM, t04_mismatch_multi, sizeof h->mmM);
+    memcpy(h->mmE, t04_mismatch_exterior, sizeof h->mmE);
+    memcpy(h->d5, t04_dangle5, sizeof h->d5);
+    memcpy(h->d3, t04_dangle3, sizeof h->d3);
+    memcpy(h->int11, t04_int11, sizeof h->int11);
+    memcpy(h->int21, t04_int21, sizeof h->int21);
+    memcpy(h->int22, t04_int22, sizeof h->int22);
+    memcpy(h->hairpin, t04_hairpin, sizeof h->hairpin);
+    memcpy(h->bulge, t04_bulge, sizeof h->bulge);
+    memcpy(h->interior, t04_interior, sizeof h->interior);
+    h->ml_base = T04_ML_BASE; h->ml_closing = T04_ML_CLOSING; h->ml_intern = T04_ML_INTERN;
+    h->ninio = T04_NINIO; h->max_ninio = T04_MAX_NINIO; h->term_au = T04_TERMINAL_AU;
+    h->n_tri = T04_N_TRILOOPS; h->n_tetra = T04_N_TETRALOOPS; h->n_hexa = T04_N_HEXALOOPS;
+    for (int i = 0; i < T04_N_TRILOOPS; i++) { h->tri_key[i] = key_of(t04_triloops_seq[i], 5); h->tri_e[i] = t04_triloops_e[i]; }
+    for (int i = 0; i < T04_N_TETRALOOPS; i++) { h->tetra_key[i] = key_of(t04_tetraloops_seq[i], 6); h->tetra_e[i] = t04_tetraloops_e[i]; }
+    for (int i = 0; i < T04_N_HEXALOOPS; i++) { h->hexa_key[i] = key_of(t04_hexaloops_seq[i], 8); h->hexa_e[i] = t04_hexaloops_e[i]; }
+    for (int sz = 31; sz <= RAFFT_MAX_LEN + 1; sz++) h->logext[sz] = (int)(T04_LXC * log(sz / 30.));
+    HIPCHK(hipMalloc((void **)&g.T, sizeof(EnergyTables)));
+    HIPCHK(hipMemcpy(g.T, h, sizeof(EnergyTables), hipMemcpyHostToDevice));
+    delete h;
+    std::vector<float2> tw(MAX_P / 2);
+    for (int m = 0; m < MAX_P / 2; m++) {
+        double a = -2.0 * M_PI * (double)m / (double)MAX_P;
+        tw[m] = make_float2((float)cos(a), (float)sin(a));
+    }
+    HIPCHK(hipMalloc((void **)&g.tw, sizeof(float2) * tw.size()));
+    HIPCHK(hipMemcpy(g.tw, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice));
+    g.device = device;
+    g.ready = true;
+    return 0;
+}
+
+struct ClsCfg { int nt, Pmax, span, nmax, Kmax, lds; };
+
+int class_cfg(int K, ClsCfg out[3])
+{
+    const int P[3] = {CLS0_P, CLS1_P, MAX_P}, SP[3] = {CLS0_SPAN, RAFFT_MAX_LEN, RAFFT_MAX_LEN}, NT[3] = {64, 256, 512};
+    for (int c = 0; c < 3; c++) {
+        int nmax = P[c] / 2;
+        int Kmax = std::max(1, std::min(K, P[c] - 1));
+        ExpandLds l = expand_lds(P[c], SP[c], nmax, Kmax);
+        out[c] = {NT[c], P[c], SP[c], nmax, Kmax, l.total};
+        if (l.total > 160 * 1024)
+            return fail(RAFFT_ERR_PARAM, "nb_mode too large for the LDS-resident expand kernel");
+    }
+    return 0;
+}
+
+template <int NT>
+int launch_expand(const Dev &d, int cls, const ClsCfg &cf, unsigned n_items)
+{
+    static int lds_set = 0;
+    if (cf.lds > lds_set) {
+        HIPCHK(hipFuncSetAttribute((const void *)expand_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, cf.lds));
+        lds_set = cf.lds;
+    }
+    hipLaunchKernelGGL(expand_kernel<NT>, dim3(n_items), dim3(NT), cf.lds, g.stream, d, cls, cf.Pmax, cf.span, cf.nmax, cf.Kmax);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_expand_cls(const Dev &d, int cls, const ClsCfg cf[3], unsigned n_items)
+{
+    if (cls == 0) return launch_expand<64>(d, 0, cf[0], n_items);
+    if (cls == 1) return launch_expand<256>(d, 1, cf[1], n_items);
+    return launch_expand<512>(d, 2, cf[2], n_items);
+}
+
+hipEvent_t next_event()
+{
+    if (g.ev_used == g.ev_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        g.ev_pool.push_back(e);
+    }
+    return g.ev_pool[g.ev_used++];
+}
+
+struct Span { hipEvent_t a, b; int kind; };
+
+struct Caps {
+    size_t st, nd, pos, pt, cand, seen, trec, tsid, work, mat;
+    int ch_cap, sort_cap;
+    size_t bytes;
+};
+
+Caps plan_caps(size_t S, size_t sumL, const rafft_params &p, double est)
+{
+    Caps c;
+    const size_t B = (size_t)p.max_stack;
+    double avgL = S ? (double)sumL / (double)S : 1.0;
+    double nstruct = (double)S * (1.0 + (double)B * est);
+    c.st = (size_t)std::min(nstruct, 2.0e9) + 64;
+    double nodes_per = avgL / 10.0 + 4.0;
+    c.nd = (size_t)std::min((double)c.st * nodes_per, 2.0e9) + 64;
+    c.pos = (size_t)((double)sumL + (double)(c.st - S) * avgL) + 4096;
+    c.pt = c.pos;
+    c.cand = c.nd * (size_t)std::min(std::max(p.nb_mode, 1), 24) + 4096;
+    double per_seq_seen = std::min(std::max(8.0 * est * ((double)B + (double)p.max_branch / 8.0), 4096.0), 4194304.0);
+    c.seen = S * 1024 + (size_t)((double)S * per_seq_seen);
+    c.trec = p.traj ? S * (size_t)(est * 3 + 16) : S + 16;
+    c.tsid = c.trec * B + 16;
+    c.work = c.nd;
+    c.mat = S * B + 16;
+    c.ch_cap = p.max_branch + p.max_stack + 8;
+    int need = p.max_branch + 2 * p.max_stack + 8;
+    c.sort_cap = 2; while (c.sort_cap < need) c.sort_cap <<= 1;
+    c.bytes = c.st * (4 * 5 + 8 * 5) + c.nd * (4 * 5 + 8 * 2) + c.pos * 2 + c.pt * 2 + c.cand * 32 + c.seen * 16 +
+              c.trec * 16 + c.tsid * 4 + c.work * 4 * 3 + c.mat * 4 + S * (size_t)c.ch_cap * 32 + S * B * 4;
+    return c;
+}
+
+struct SeqIn { const char *s; int len; int idx; };
+
+struct HostOut {   // owner of a rafft_result
+    std::vector<rafft_seq_result> seq;
+    std::vector<std::vector<int>> step_size, step_off, dcal;
+    std::vector<std::vector<char>> db;
+    rafft_result res;
+};
+
+// run one wave; returns 0, or RAFFT_ERR_CAPACITY with *ovf_bits set, or another error
+int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, HostOut &out, unsigned *ovf_bits,
+             std::vector<Span> &spans, const DebugOut *dbg_single = nullptr, const std::vector<int16_t> *dbg_pt = nullptr,
+             const std::vector<int> *dbg_pos = nullptr, int dbg_ci = -1, int dbg_cj = 0, int dbg_dcal = 0)
+{
+    const size_t S = seqs.size();
+    *ovf_bits = 0;
+    std::vector<int> off(S), len(S);
+    size_t sumL = 0;
+    for (size_t i = 0; i < S; i++) { off[i] = (int)sumL; len[i] = seqs[i].len; sumL += seqs[i].len; }
+    std::vector<uint8_t> codes(sumL + 16, 0);
+    for (size_t i = 0; i < S; i++)
+        for (int x = 0; x < seqs[i].len; x++) {
+            char ch = seqs[i].s[x];
+            codes[off[i] + x] = ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : ch == 'U' ? 4 : 0;
+        }
+    ClsCfg cf[3];
+    if (int rc = class_cfg(p.nb_mode, cf)) return rc;
+    Caps c = plan_caps(S, sumL, p, est);
+    if ((size_t)c.sort_cap * 8 + MAX_PROD * 12 + (size_t)(p.max_stack + 4) * 4 + 256 > 150 * 1024)
+        return fail(RAFFT_ERR_PARAM, "max_branch + 2*max_stack too large for the LDS-resident beam sort");
+    const size_t B = (size_t)p.max_stack;
+
+#define ENS(buf, bytes) do { if (int rc_ = ensure(g.buf, (bytes))) return rc_; } while (0)
+    ENS(codes, sumL + 16); ENS(seq_off, S * 4); ENS(seq_len, S * 4);
+    ENS(beam, S * B * 4); ENS(beam_n, S * 4); ENS(done, S * 4); ENS(nsteps, S * 4);
+    ENS(ch_parent, S * c.ch_cap * 2); ENS(ch_combo, S * c.ch_cap * 8); ENS(ch_dcal, S * c.ch_cap * 4); ENS(ch_h, S * c.ch_cap * 16);
+    ENS(seen, c.seen * 16); ENS(seen_off, S * 8); ENS(seen_cap, S * 4); ENS(seen_cnt, S * 4);
+    ENS(st_seq, c.st * 4); ENS(st_dcal, c.st * 4); ENS(st_node0, c.st * 4); ENS(st_nnodes, c.st * 4); ENS(st_parent, c.st * 4);
+    ENS(st_h, c.st * 16); ENS(st_pt, c.st * 8); ENS(st_cursor, c.st * 8); ENS(st_combo, c.st * 8);
+    ENS(nd_sid, c.nd * 4); ENS(nd_n, c.nd * 4); ENS(nd_ci, c.nd * 4); ENS(nd_cj, c.nd * 4); ENS(nd_ncand, c.nd * 4);
+    ENS(nd_pos, c.nd * 8); ENS(nd_cand, c.nd * 8);
+    ENS(pos, c.pos * 2); ENS(pt, c.pt * 2); ENS(cand, c.cand * 32);
+    ENS(trec, c.trec * 16); ENS(tsid, c.tsid * 4);
+    ENS(work0, c.work * 4); ENS(work1, c.work * 4); ENS(work2, c.work * 4); ENS(mat, c.mat * 4);
+    ENS(counters, sizeof(Counters));
+#undef ENS
+
+    Dev d;
+    memset(&d, 0, sizeof d);
+    d.T = g.T; d.tw = g.tw; d.S = (int)S;
+    d.codes = (const uint8_t *)g.codes.p; d.seq_off = (const int *)g.seq_off.p; d.seq_len = (const int *)g.seq_len.p;
+    d.K = p.nb_mode; d.B = p.max_stack; d.max_branch = p.max_branch; d.min_hp = p.min_hp; d.traj = p.traj;
+    d.min_nrj = p.min_nrj; d.gc = p.gc_wei; d.au = p.au_wei; d.gu = p.gu_wei;
+    d.beam = (int *)g.beam.p; d.beam_n = (int *)g.beam_n.p; d.done = (int *)g.done.p; d.nsteps = (int *)g.nsteps.p;
+    d.ch_cap = c.ch_cap;
+    d.ch_parent = (uint16_t *)g.ch_parent.p; d.ch_combo = (uint64_t *)g.ch_combo.p; d.ch_dcal = (int *)g.ch_dcal.p; d.ch_h = (uint64_t *)g.ch_h.p;
+    d.seen = (uint64_t *)g.seen.p; d.seen_cap_total = c.seen;
+    d.seen_off = (uint64_t *)g.seen_off.p; d.seen_cap = (uint32_t *)g.seen_cap.p; d.seen_cnt = (uint32_t *)g.seen_cnt.p;
+    d.st_cap = (uint32_t)c.st;
+    d.st_seq = (int *)g.st_seq.p; d.st_dcal = (int *)g.st_dcal.p; d.st_node0 = (int *)g.st_node0.p; d.st_nnodes = (int *)g.st_nnodes.p;
+    d.st_parent = (int *)g.st_parent.p; d.st_h = (uint64_t *)g.st_h.p; d.st_pt = (uint64_t *)g.st_pt.p;
+    d.st_cursor = (uint64_t *)g.st_cursor.p; d.st_combo = (uint64_t *)g.st_combo.p;
+    d.nd_cap = (uint32_t)c.nd;
+    d.nd_sid = (int *)g.nd_sid.p; d.nd_n = (int *)g.nd_n.p; d.nd_ci = (int *)g.nd_ci.p; d.nd_cj = (int *)g.nd_cj.p;
+    d.nd_ncand = (int *)g.nd_ncand.p; d.nd_pos = (uint64_t *)g.nd_pos.p; d.nd_cand = (uint64_t *)g.nd_cand.p;
+    d.pos = (uint16_t *)g.pos.p; d.pos_cap = c.pos; d.pt = (int16_t *)g.pt.p; d.pt_cap = c.pt;
+    d.cand = (Cand *)g.cand.p; d.cand_cap = c.cand;
+    d.trec = (int4 *)g.trec.p; d.trec_cap = (uint32_t)c.trec; d.tsid = (int *)g.tsid.p; d.tsid_cap = c.tsid;
+    d.work[0] = (int *)g.work0.p; d.work[1] = (int *)g.work1.p; d.work[2] = (int *)g.work2.p; d.work_cap = (uint32_t)c.work;
+    d.mat = (int *)g.mat.p; d.mat_cap = (uint32_t)c.mat;
+    d.c = (Counters *)g.counters.p;
+    if (dbg_single) d.dbg = *dbg_single;
+
+    hipStream_t st = g.stream;
+    HIPCHK(hipMemcpyAsync(g.codes.p, codes.data(), sumL + 16, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(g.seq_off.p, off.data(), S * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(g.seq_len.p, len.data(), S * 4, hipMemcpyHostToDevice, st));
+    Counters hc;
+    memset(&hc, 0, sizeof hc);
+    hc.n_struct = S; hc.n_node = S; hc.pos_top = sumL; hc.pt_top = sumL; hc.seen_top = S * 1024;
+    HIPCHK(hipMemcpyAsync(g.counters.p, &hc, sizeof hc, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(g.seen.p, 0, c.seen * 16, st));
+    hipLaunchKernelGGL(init_roots_kernel, dim3((unsigned)S), dim3(64), 0, st, d, (const int *)g.seq_off.p);
+    HIPCHK(hipGetLastError());
+
+    if (dbg_single) {
+        // seam: overwrite the root structure/node of sequence 0 with the given structure + region
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipMemcpy(g.pt.p, dbg_pt->data(), dbg_pt->size() * 2, hipMemcpyHostToDevice));
+        std::vector<uint16_t> p16(dbg_pos->begin(), dbg_pos->end());
+        HIPCHK(hipMemcpy(g.pos.p, p16.data(), p16.size() * 2, hipMemcpyHostToDevice));
+        int n = (int)p16.size();
+        HIPCHK(hipMemcpy(g.nd_n.p, &n, 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(g.nd_ci.p, &dbg_ci, 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(g.nd_cj.p, &dbg_cj, 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(g.st_dcal.p, &dbg_dcal, 4, hipMemcpyHostToDevice));
+        int cls = node_class(n, dbg_ci < 0 ? seqs[0].len : dbg_cj - dbg_ci + 1);
+        int zero = 0;
+        memset(&hc.n_work, 0, sizeof hc.n_work);
+        hc.n_work[cls] = 1;
+        HIPCHK(hipMemcpy(g.counters.p, &hc, sizeof hc, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d.work[cls], &zero, 4, hipMemcpyHostToDevice));
+        if (int rc = launch_expand_cls(d, cls, cf, 1)) return rc;
+        HIPCHK(hipStreamSynchronize(st));
+        return 0;
+    }
+
+    const size_t bs_lds = (size_t)c.sort_cap * 8 + MAX_PROD * 12 + ((B + 3) & ~(size_t)3) * 4 + 128;
+    static size_t bs_lds_set = 0;
+    if (bs_lds > bs_lds_set) {
+        HIPCHK(hipFuncSetAttribute((const void *)beam_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds));
+        bs_lds_set = bs_lds;
+    }
+    const size_t cnt_work_off = offsetof(Counters, n_work);
+    int steps = 0;
+    for (;;) {
+        HIPCHK(hipMemcpyAsync(&hc, g.counters.p, sizeof hc, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (hc.overflow) { *ovf_bits = hc.overflow; break; }
+        for (int cls = 0; cls < 3; cls++)
+            if (hc.n_work[cls]) {
+                Span sp{next_event(), next_event(), 0};
+                HIPCHK(hipEventRecord(sp.a, st));
+                if (int rc = launch_expand_cls(d, cls, cf, hc.n_work[cls])) return rc;
+                HIPCHK(hipEventRecord(sp.b, st));
+                spans.push_back(sp);
+                g.stats.n_expand_launches++;
+            }
+        HIPCHK(hipMemsetAsync((char *)g.counters.p + cnt_work_off, 0, 4 * sizeof(unsigned), st)); // n_work[3], n_mat
+        {
+            Span sp{next_event(), next_event(), 1};
+            HIPCHK(hipEventRecord(sp.a, st));
+            hipLaunchKernelGGL(beam_step_kernel, dim3((unsigned)S), dim3(BS_NT), bs_lds, st, d, c.sort_cap);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(sp.b, st));
+            spans.push_back(sp);
+        }
+        steps++;
+        HIPCHK(hipMemcpyAsync(&hc, g.counters.p, sizeof hc, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (hc.overflow) { *ovf_bits = hc.overflow; break; }
+        if (hc.n_mat == 0) break;
+        {
+            Span sp{next_event(), next_event(), 2};
+            HIPCHK(hipEventRecord(sp.a, st));
+            hipLaunchKernelGGL(materialize_kernel, dim3(hc.n_mat), dim3(MAT_NT), 0, st, d);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(sp.b, st));
+            spans.push_back(sp);
+        }
+    }
+    g.stats.n_steps = std::max<int64_t>(g.stats.n_steps, steps);
+    if (*ovf_bits) {
+        if (*ovf_bits & (OVF_PROD | OVF_SORT))
+            return fail(RAFFT_ERR_PARAM, "structure with more than 1024 productive regions or sort capacity exceeded");
+        return RAFFT_ERR_CAPACITY;
+    }
+    // statistics (SURVEY.md 8d algorithmic bytes)
+    g.stats.n_node_expansions += hc.n_expand;
+    g.stats.sum_node_len += hc.sum_n;
+    g.stats.sum_lags += hc.sum_lags;
+    g.stats.n_structs += (int64_t)hc.n_struct;
+    g.stats.n_children += hc.n_children;
+    g.stats.sum_struct_len += (int64_t)(hc.sum_struct_len + sumL);
+    {
+        int64_t ex = 3 * (int64_t)hc.sum_n + 16 * (int64_t)hc.sum_lags + 3 * (int64_t)(hc.sum_struct_len + sumL);
+        g.stats.alg_bytes_expand += ex;
+        g.stats.alg_bytes += ex + 2 * (int64_t)hc.sum_struct_len + 8 * (int64_t)(hc.n_struct - S);
+    }
+
+    // ---- gather the trajectory records and format rows on the device
+    std::vector<int4> trec(hc.trec_n);
+    if (hc.trec_n) HIPCHK(hipMemcpy(trec.data(), g.trec.p, hc.trec_n * sizeof(int4), hipMemcpyDeviceToHost));
+    std::vector<int> tsid(hc.tsid_top);
+    if (hc.tsid_top) HIPCHK(hipMemcpy(tsid.data(), g.tsid.p, hc.tsid_top * 4, hipMemcpyDeviceToHost));
+    std::vector<std::vector<int4>> per(S);
+    for (auto &r : trec) per[r.x].push_back(r);
+    std::vector<int> row_sid;
+    std::vector<long long> row_off;
+    std::vector<long long> seq_db_off(S);
+    long long tot_bytes = 0;
+    for (size_t i = 0; i < S; i++) {
+        auto &v = per[i];
+        std::sort(v.begin(), v.end(), [](const int4 &a, const int4 &b) { return a.y < b.y; });
+        seq_db_off[i] = tot_bytes;
+        for (auto &r : v)
+            for (int k = 0; k < r.z; k++) {
+                row_sid.push_back(tsid[r.w + k]);
+                row_off.push_back(tot_bytes);
+                tot_bytes += len[i] + 1;
+            }
+    }
+    const size_t nrows = row_sid.size();
+    std::vector<char> all_db(tot_bytes + 1);
+    std::vector<int> all_dcal(nrows + 1);
+    if (nrows) {
+        if (int rc = ensure(g.row_sid, nrows * 4)) return rc;
+        if (int rc = ensure(g.row_off, nrows * 8)) return rc;
+        if (int rc = ensure(g.out_db, (size_t)tot_bytes)) return rc;
+        if (int rc = ensure(g.out_dcal, nrows * 4)) return rc;
+        HIPCHK(hipMemcpyAsync(g.row_sid.p, row_sid.data(), nrows * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(g.row_off.p, row_off.data(), nrows * 8, hipMemcpyHostToDevice, st));
+        Span sp{next_event(), next_event(), 3};
+        HIPCHK(hipEventRecord(sp.a, st));
+        unsigned grid = (unsigned)std::min<size_t>(nrows, 65536);
+        hipLaunchKernelGGL(output_kernel, dim3(grid), dim3(64), 0, st, d, (int)nrows, (const int *)g.row_sid.p,
+                           (const long long *)g.row_off.p, (char *)g.out_db.p, (int *)g.out_dcal.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(sp.b, st));
+        spans.push_back(sp);
+        HIPCHK(hipMemcpyAsync(all_db.data(), g.out_db.p, (size_t)tot_bytes, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(all_dcal.data(), g.out_dcal.p, nrows * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    size_t row = 0;
+    for (size_t i = 0; i < S; i++) {
+        int gi = seqs[i].idx;
+        auto &v = per[i];
+        int nst = 0;
+        for (auto &r : v) nst += r.z;
+        out.step_size[gi].clear(); out.step_off[gi].clear();
+        int o = 0;
+        for (auto &r : v) { out.step_size[gi].push_back(r.z); out.step_off[gi].push_back(o); o += r.z; }
+        out.dcal[gi].assign(all_dcal.begin() + row, all_dcal.begin() + row + nst);
+        out.db[gi].assign(all_db.begin() + seq_db_off[i], all_db.begin() + seq_db_off[i] + (long long)nst * (len[i] + 1));
+        rafft_seq_result &sr = out.seq[gi];
+        sr.status = RAFFT_OK; sr.length = len[i]; sr.n_steps = (int)v.size(); sr.n_structs = nst;
+        row += nst;
+    }
+    return 0;
+}
+
+int fold_range(const rafft_params &p, std::vector<SeqIn> seqs, double est, HostOut &out, std::vector<Span> &spans, int depth)
+{
+    if (seqs.empty()) return 0;
+    size_t sumL = 0;
+    for (auto &s : seqs) sumL += s.len;
+    const size_t budget = (size_t)((double)g.hbm_total * 0.55);
+    Caps c = plan_caps(seqs.size(), sumL, p, est);
+    if (c.bytes > budget && seqs.size() > 1) {
+        size_t h = seqs.size() / 2;
+        std::vector<SeqIn> a(seqs.begin(), seqs.begin() + h), b(seqs.begin() + h, seqs.end());
+        if (int rc = fold_range(p, a, est, out, spans, depth)) return rc;
+        return fold_range(p, b, est, out, spans, depth);
+    }
+    unsigned ovf = 0;
+    int rc = run_wave(p, seqs, est, out, &ovf, spans);
+    if (rc == RAFFT_ERR_CAPACITY) {
+        if (depth >= 8) return fail(RAFFT_ERR_CAPACITY, "HBM arena overflow after 8 regrowths (bits " + std::to_string(ovf) + ")");
+        return fold_range(p, seqs, est * 2.0, out, spans, depth + 1);
+    }
+    return rc;
+}
+
+void free_out(HostOut *o) { delete o; }
+
+} // namespace
+
+extern "C" {
+
+const char *rafft_last_error(void) { return g_err.c_str(); }
+
+const char *rafft_version(void) { return "raffthip 0.1 (gfx950, HIP; Turner-2004 37C tables)"; }
+
+int rafft_init(int device)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    return init_ctx(device);
+}
+
+int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs, const int *lens, int device, rafft_result **out_)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!p || !out_ || n_seq < 0) return fail(RAFFT_ERR_PARAM, "null argument");
+    *out_ = nullptr;
+    if (p->temp != 37.0) return fail(RAFFT_ERR_TEMP, "only temp=37.0 is supported (no enthalpy tables to rescale with)");
+    if (p->max_stack < 1 || p->max_stack > 65535) return fail(RAFFT_ERR_PARAM, "max_stack must be in [1, 65535]");
+    if (p->nb_mode < 0 || p->max_branch < 0) return fail(RAFFT_ERR_PARAM, "nb_mode/max_branch must be >= 0");
+    if (int rc = init_ctx(device)) return rc;
+    auto t0 = std::chrono::steady_clock::now();
+    memset(&g.stats, 0, sizeof g.stats);
+    g.ev_used = 0;
+    HostOut *ho = new HostOut();
+    ho->seq.resize(n_seq); ho->step_size.resize(n_seq); ho->step_off.resize(n_seq); ho->dcal.resize(n_seq); ho->db.resize(n_seq);
+    std::vector<SeqIn> good;
+    for (int i = 0; i < n_seq; i++) {
+        int L = lens ? lens[i] : (int)strlen(seqs[i]);
+        rafft_seq_result &sr = ho->seq[i];
+        memset(&sr, 0, sizeof sr);
+        sr.length = L;
+        if (L == 0) { sr.status = RAFFT_ERR_EMPTY; continue; }
+        bool ok = true;
+        for (int x = 0; x < L && ok; x++) {
+            char ch = seqs[i][x];
+            ok = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'U' || ch == 'N';
+        }
+        if (!ok) { sr.status = RAFFT_ERR_BAD_CHAR; continue; }
+        if (L > RAFFT_MAX_LEN) { sr.status = RAFFT_ERR_TOO_LONG; continue; }
+        good.push_back({seqs[i], L, i});
+    }
+    std::vector<Span> spans;
+    int rc = fold_range(*p, good, 12.0, *ho, spans, 0);
+    if (rc) { free_out(ho); return rc; }
+    for (auto &sp : spans) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+            if (sp.kind == 0) g.stats.ms_expand += ms;
+            else if (sp.kind == 1) g.stats.ms_beam += ms;
+            else if (sp.kind == 2) g.stats.ms_materialize += ms;
+            else g.stats.ms_output += ms;
+        }
+    }
+    for (int i = 0; i < n_seq; i++) {
+        rafft_seq_result &sr = ho->seq[i];
+        sr.step_size = ho->step_size[i].data(); sr.step_off = ho->step_off[i].data();
+        sr.db = ho->db[i].data(); sr.dcal = ho->dcal[i].data();
+    }
+    ho->res.n_seq = n_seq; ho->res.seq = ho->seq.data(); ho->res._owner = ho;
+    *out_ = &ho->res;
+    g.stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+
+void rafft_free_result(rafft_result *r)
+{
+    if (r && r->_owner) free_out((HostOut *)r->_owner);
+}
+
+int rafft_get_stats(rafft_stats *o)
+{
+    if (!o) return RAFFT_ERR_PARAM;
+    *o = g.stats;
+    return 0;
+}
+
+static int parse_db(const char *seq, const char *db, int L, std::vector<int16_t> &pt)
+{
+    pt.assign(L, -1);
+    std::vector<int> stk;
+    for (int i = 0; i < L; i++) {
+        if (db[i] == '(') stk.push_back(i);
+        else if (db[i] == ')') {
+            if (stk.empty()) return RAFFT_ERR_STRUCT;
+            int j = stk.back(); stk.pop_back();
+            pt[i] = (int16_t)j; pt[j] = (int16_t)i;
+        } else if (db[i] != '.') return RAFFT_ERR_STRUCT;
+    }
+    return stk.empty() ? 0 : RAFFT_ERR_STRUCT;
+}
+
+static int eval_structures_impl(int n, const char *const *seqs, const char *const *dbs, int *dcal_out, int *status_out)
+{
+    if (int rc = init_ctx(-1)) return rc;
+    std::vector<long long> off(n);
+    std::vector<int> len(n), status(n, 0);
+    long long tot = 0;
+    for (int i = 0; i < n; i++) {
+        len[i] = (int)strlen(seqs[i]);
+        off[i] = tot;
+        if ((int)strlen(dbs[i]) != len[i] || len[i] > 32767) { status[i] = RAFFT_ERR_STRUCT; len[i] = 0; }
+        tot += len[i];
+    }
+    std::vector<uint8_t> codes(tot + 16, 0);
+    std::vector<int16_t> pts(tot + 16, -1);
+    for (int i = 0; i < n; i++) {
+        if (status[i]) continue;
+        std::vector<int16_t> pt;
+        if (parse_db(seqs[i], dbs[i], len[i], pt)) { status[i] = RAFFT_ERR_STRUCT; len[i] = 0; continue; }
+        for (int x = 0; x < len[i]; x++) {
+            char ch = seqs[i][x];
+            int c = ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : ch == 'U' ? 4 : ch == 'N' ? 0 : -1;
+            if (c < 0) { status[i] = RAFFT_ERR_BAD_CHAR; break; }
+            codes[off[i] + x] = (uint8_t)c;
+            pts[off[i] + x] = pt[x];
+        }
+        if (status[i]) len[i] = 0;
+    }
+    void *dc = nullptr, *dp = nullptr, *doff = nullptr, *dlen = nullptr, *dout = nullptr, *dst = nullptr;
+    HIPCHK(hipMalloc(&dc, tot + 16)); HIPCHK(hipMalloc(&dp, (tot + 16) * 2)); HIPCHK(hipMalloc(&doff, n * 8 + 8));
+    HIPCHK(hipMalloc(&dlen, n * 4 + 4)); HIPCHK(hipMalloc(&dout, n * 4 + 4)); HIPCHK(hipMalloc(&dst, n * 4 + 4));
+    HIPCHK(hipMemcpy(dc, codes.data(), tot + 16, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dp, pts.data(), (tot + 16) * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(doff, off.data(), n * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dlen, len.data(), n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(eval_kernel, dim3(n), dim3(64), 0, g.stream, g.T, n, (const uint8_t *)dc, (const int16_t *)dp,
+                       (const long long *)doff, (const int *)dlen, (int *)dout, (int *)dst);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(g.stream));
+    std::vector<int> st2(n);
+    HIPCHK(hipMemcpy(dcal_out, dout, n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(st2.data(), dst, n * 4, hipMemcpyDeviceToHost));
+    for (void *q : {dc, dp, doff, dlen, dout, dst}) { hipError_t fe = hipFree(q); (void)fe; }
+    int worst = 0;
+    for (int i = 0; i < n; i++) {
+        int s = status[i] ? status[i] : st2[i];
+        if (status_out) status_out[i] = s;
+        if (s && !worst) worst = s;
+    }
+    if (worst && !status_out) return fail(worst, "malformed structure, bad character or non-canonical pair");
+    return 0;
+}
+
+int rafft_eval_structures(int n, const char *const *seqs, const char *const *dbs, int *dcal_out, int *status_out)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    return eval_structures_impl(n, seqs, dbs, dcal_out, status_out);
+}
+
+int rafft_eval_structure(const char *seq, const char *db, int *dcal_out)
+{
+    return rafft_eval_structures(1, &seq, &db, dcal_out, nullptr);
+}
+
+int rafft_expand_node(const rafft_params *p, const char *seq, const char *db, const int *pos, int n,
+                      int *n_ranked, int *lag, double *corval, int *nb, int *mi, int *mj,
+                      double *score, int *ddcal, int *n_kept, int *kept)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (int rc = init_ctx(-1)) return rc;
+    const int L = (int)strlen(seq);
+    if (L == 0 || L > RAFFT_MAX_LEN || n < 1 || n > L) return fail(RAFFT_ERR_PARAM, "bad node");
+    std::vector<int16_t> pt;
+    if (parse_db(seq, db, L, pt)) return fail(RAFFT_ERR_STRUCT, "malformed dot-bracket");
+    // enclosing loop of the region: nearest pair (i,j) with i < pos[0] < j
+    int ci = -1, cj = L;
+    for (int x = pos[0] - 1, depth = 0; x >= 0; x--) {
+        if (pt[x] < 0) continue;
+        if (pt[x] < x) { depth++; continue; }      // ')' partner to the left: skip its helix
+        if (depth > 0) { depth--; continue; }
+        if (pt[x] > pos[0]) { ci = x; cj = pt[x]; break; }
+    }
+    int par_dcal = 0;
+    if (int rc = eval_structures_impl(1, &seq, &db, &par_dcal, nullptr)) return rc;
+    const int K = std::max(1, std::min(p->nb_mode, 2 * n - 1));
+    if (int rc = ensure(g.dbg, (size_t)K * (4 * 7 + 8 * 2) + 64)) return rc;
+    char *b = (char *)g.dbg.p;
+    DebugOut dbg;
+    dbg.n_ranked = (int *)b; b += 16;
+    dbg.lag = (int *)b; b += 4 * K; dbg.nb = (int *)b; b += 4 * K; dbg.mi = (int *)b; b += 4 * K; dbg.mj = (int *)b; b += 4 * K;
+    dbg.ddcal = (int *)b; b += 4 * K; dbg.kept = (int *)b; b += 4 * K;
+    b = (char *)(((uintptr_t)b + 15) & ~(uintptr_t)15);
+    dbg.corval = (double *)b; b += 8 * K; dbg.score = (double *)b;
+    std::vector<SeqIn> one{{seq, L, 0}};
+    HostOut ho;
+    ho.seq.resize(1); ho.step_size.resize(1); ho.step_off.resize(1); ho.dcal.resize(1); ho.db.resize(1);
+    unsigned ovf = 0;
+    std::vector<Span> spans;
+    std::vector<int> posv(pos, pos + n);
+    g.ev_used = 0;
+    rafft_params pp = *p;
+    pp.max_stack = std::max(1, pp.max_stack);
+    if (int rc = run_wave(pp, one, 4.0, ho, &ovf, spans, &dbg, &pt, &posv, ci, cj, par_dcal)) return rc;
+    int hdr[4];
+    HIPCHK(hipMemcpy(hdr, dbg.n_ranked, 16, hipMemcpyDeviceToHost));
+    *n_ranked = hdr[0]; *n_kept = hdr[1];
+    int r = hdr[0];
+    HIPCHK(hipMemcpy(lag, dbg.lag, 4 * r, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(nb, dbg.nb, 4 * r, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(mi, dbg.mi, 4 * r, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(mj, dbg.mj, 4 * r, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ddcal, dbg.ddcal, 4 * r, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(kept, dbg.kept, 4 * hdr[1], hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(corval, dbg.corval, 8 * r, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(score, dbg.score, 8 * r, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+} // extern "C"

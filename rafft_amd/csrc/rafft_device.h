@@ -1,0 +1,187 @@
+// rafft_device.h - device-side Turner-2004 loop energies for gfx950.
+//
+// Replaces the ViennaRNA call inside the reference's inner loop
+// (rafft/utils.py:135-138 eval_one_struct -> fold_compound.eval_structure):
+// instead of re-evaluating the whole structure in O(L) for every candidate stem
+// (rafft/rafft.py:98) the fold kernels evaluate only the loops a stem changes
+// (nearest-neighbour energies are a sum over loops), in integer dcal.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RAFFT_MAX_LEN 4096
+
+struct EnergyTables {
+    int16_t stack[7][7];
+    int16_t mmH[7][5][5], mmI[7][5][5], mm1n[7][5][5], mm23[7][5][5], mmM[7][5][5], mmE[7][5][5];
+    int16_t d5[7][5], d3[7][5];
+    int16_t int11[7][7][5][5];
+    int16_t int21[7][7][5][5][5];
+    int16_t int22[7][7][5][5][5][5];
+    int32_t hairpin[31], bulge[31], interior[31];
+    int32_t ml_base, ml_closing, ml_intern, ninio, max_ninio, term_au;
+    int32_t n_tri, n_tetra, n_hexa;
+    uint32_t tri_key[4];   int32_t tri_e[4];
+    uint32_t tetra_key[32]; int32_t tetra_e[32];
+    uint32_t hexa_key[8];  int32_t hexa_e[8];
+    int32_t logext[RAFFT_MAX_LEN + 2];   // (int)(lxc*log(size/30.)), host libm, size > 30
+};
+
+__device__ __constant__ static const int8_t kPairType[5][5] = {
+    {0, 0, 0, 0, 0}, {0, 0, 0, 0, 5}, {0, 0, 0, 1, 0}, {0, 0, 2, 0, 3}, {0, 6, 0, 4, 0}};
+__device__ __constant__ static const int8_t kRtype[7] = {0, 2, 1, 4, 3, 6, 5};
+
+__device__ __forceinline__ int pair_type(int a, int b) { return kPairType[a][b]; }
+
+// special-loop key: 3 bits per base, first base in the low bits
+__device__ __forceinline__ uint32_t loop_key(const uint8_t *S, int i, int m)
+{
+    uint32_t k = 0;
+    for (int t = 0; t < m; t++) k |= (uint32_t)S[i + t] << (3 * t);
+    return k;
+}
+
+__device__ inline int e_hairpin(const EnergyTables *T, int size, int type, const uint8_t *S, int ci, int cj)
+{
+    int e = (size <= 30) ? T->hairpin[size] : T->hairpin[30] + T->logext[size];
+    if (size < 3) return e;
+    if (size == 4) {
+        uint32_t k = loop_key(S, ci, 6);
+        for (int t = 0; t < T->n_tetra; t++)
+            if (T->tetra_key[t] == k) return T->tetra_e[t];
+    } else if (size == 6) {
+        uint32_t k = loop_key(S, ci, 8);
+        for (int t = 0; t < T->n_hexa; t++)
+            if (T->hexa_key[t] == k) return T->hexa_e[t];
+    } else if (size == 3) {
+        uint32_t k = loop_key(S, ci, 5);
+        for (int t = 0; t < T->n_tri; t++)
+            if (T->tri_key[t] == k) return T->tri_e[t];
+        return e + (type > 2 ? T->term_au : 0);
+    }
+    return e + T->mmH[type][S[ci + 1]][S[cj - 1]];
+}
+
+__device__ inline int e_intloop(const EnergyTables *T, int n1, int n2, int type, int type2,
+                                int si1, int sj1, int sp1, int sq1)
+{
+    int nl = n1 > n2 ? n1 : n2, ns = n1 > n2 ? n2 : n1, e, u;
+    if (nl == 0) return T->stack[type][type2];
+    if (ns == 0) {
+        e = (nl <= 30) ? T->bulge[nl] : T->bulge[30] + T->logext[nl];
+        if (nl == 1) e += T->stack[type][type2];
+        else {
+            if (type > 2) e += T->term_au;
+            if (type2 > 2) e += T->term_au;
+        }
+        return e;
+    }
+    if (ns == 1) {
+        if (nl == 1) return T->int11[type][type2][si1][sj1];
+        if (nl == 2) {
+            if (n1 == 1) return T->int21[type][type2][si1][sq1][sj1];
+            return T->int21[type2][type][sq1][si1][sp1];
+        }
+        u = nl + 1;
+        e = (u <= 30) ? T->interior[u] : T->interior[30] + T->logext[u];
+        e += min(T->max_ninio, (nl - ns) * T->ninio);
+        e += T->mm1n[type][si1][sj1] + T->mm1n[type2][sq1][sp1];
+        return e;
+    }
+    if (ns == 2) {
+        if (nl == 2) return T->int22[type][type2][si1][sp1][sq1][sj1];
+        if (nl == 3) {
+            e = T->interior[5] + T->ninio;
+            e += T->mm23[type][si1][sj1] + T->mm23[type2][sq1][sp1];
+            return e;
+        }
+    }
+    u = nl + ns;
+    e = (u <= 30) ? T->interior[u] : T->interior[30] + T->logext[u];
+    e += min(T->max_ninio, (nl - ns) * T->ninio);
+    e += T->mmI[type][si1][sj1] + T->mmI[type2][sq1][sp1];
+    return e;
+}
+
+// si1/sj1 < 0: neighbour does not exist (sequence end)
+__device__ inline int e_stem(const EnergyTables *T, int type, int si1, int sj1, bool ext)
+{
+    int e = 0;
+    if (si1 >= 0 && sj1 >= 0) e += ext ? T->mmE[type][si1][sj1] : T->mmM[type][si1][sj1];
+    else if (si1 >= 0) e += T->d5[type][si1];
+    else if (sj1 >= 0) e += T->d3[type][sj1];
+    if (type > 2) e += T->term_au;
+    if (!ext) e += T->ml_intern;
+    return e;
+}
+
+// Energy of the single loop closed by (ci,cj) in 0-based root coordinates; ci < 0 means
+// the exterior loop (cj == L).  `pv(x)` returns the partner of x or -1.  S is indexed
+// in the same coordinates (S may be a pointer shifted by a window base).
+// `bad` is set when a non-canonical pair is met (cannot happen inside the fold).
+template <class PV>
+__device__ inline int loop_energy(const EnergyTables *T, const uint8_t *S, int L, const PV &pv, int ci, int cj, int *bad)
+{
+    if (ci < 0) {
+        int e = 0;
+        for (int p = 0; p < L;) {
+            int q = pv(p);
+            if (q < 0) { p++; continue; }
+            int tt = pair_type(S[p], S[q]);
+            if (!tt) { *bad = 1; return 0; }
+            e += e_stem(T, tt, p > 0 ? (int)S[p - 1] : -1, q < L - 1 ? (int)S[q + 1] : -1, true);
+            p = q + 1;
+        }
+        return e;
+    }
+    int type = pair_type(S[ci], S[cj]);
+    if (!type) { *bad = 1; return 0; }
+    int nbr = 0, p1 = 0, q1 = 0;
+    for (int p = ci + 1; p < cj;) {
+        int q = pv(p);
+        if (q < 0) { p++; continue; }
+        if (!nbr) { p1 = p; q1 = q; }
+        nbr++;
+        p = q + 1;
+    }
+    if (nbr == 0) return e_hairpin(T, cj - ci - 1, type, S, ci, cj);
+    if (nbr == 1) {
+        int t2 = pair_type(S[p1], S[q1]);
+        if (!t2) { *bad = 1; return 0; }
+        return e_intloop(T, p1 - ci - 1, cj - q1 - 1, type, kRtype[t2], S[ci + 1], S[cj - 1], S[p1 - 1], S[q1 + 1]);
+    }
+    int e = 0, u = cj - ci - 1;
+    for (int p = ci + 1; p < cj;) {
+        int q = pv(p);
+        if (q < 0) { p++; continue; }
+        int tt = pair_type(S[p], S[q]);
+        if (!tt) { *bad = 1; return 0; }
+        e += e_stem(T, tt, S[p - 1], S[q + 1], false);
+        u -= q - p + 1;
+        p = q + 1;
+    }
+    e += e_stem(T, kRtype[type], S[cj - 1], S[ci + 1], false);
+    e += T->ml_closing + u * T->ml_base;
+    return e;
+}
+
+// ViennaRNA returns `(float)en / 100.` through a float (rafft compares these floats)
+__device__ __host__ inline double dcal_to_energy(int dcal)
+{
+    return (double)(float)((double)(float)dcal / 100.);
+}
+
+// commutative 128-bit hash of a pair set: sum over pairs of two independent mixes
+__device__ __host__ inline uint64_t mix64(uint64_t z)
+{
+    z += 0x9e3779b97f4a7c15ULL;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+__device__ __host__ inline void pair_hash(int i, int j, uint64_t *h1, uint64_t *h2)
+{
+    uint64_t k = ((uint64_t)(uint32_t)i << 20) | (uint32_t)j;
+    *h1 = mix64(k);
+    *h2 = mix64(k ^ 0xa5a5a5a5deadbeefULL);
+}

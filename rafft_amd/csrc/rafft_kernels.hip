@@ -1,0 +1,800 @@
+// rafft_kernels.hip - the HIP kernels of the fold hot path (gfx950 / MI355X only).
+//
+//   expand_kernel       one workgroup (one wavefront for the common size class) per
+//                       unpaired region: LDS-resident complex FFT correlation
+//                       (rafft/utils.py:115-132), lag ranking (rafft/rafft.py:117-118,92),
+//                       window_slide (rafft/rafft.py:36-83), local Turner dE of every
+//                       candidate stem + filter/sort (rafft/rafft.py:86-109)
+//   beam_step_kernel    one workgroup per sequence: helix combination in product
+//                       order with `seen` dedupe and the max_branch rule, stable
+//                       energy sort and beam cut (rafft/rafft.py:176-214)
+//   materialize_kernel  one wavefront per new beam member: pair table + child
+//                       nodes (rafft/rafft.py:127-152, rafft/utils.py:141-152)
+//   output_kernel       pair tables -> dot-bracket rows (rafft/utils.py:42-50)
+//   eval_kernel         whole-structure energy (rafft/utils.py:135-138), C-ABI hook
+//
+// This is bandwidth/latency-bound small-FFT + integer table work: no MFMA.
+#include "rafft_kernels.h"
+
+// ---------------------------------------------------------------- helpers
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) // a * conj(b)
+{
+    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+
+// exclusive prefix sum of one int per thread over the workgroup; returns total in *tot.
+// `scratch` needs (NT/64 + 1) ints of LDS.
+template <int NT>
+__device__ inline int block_exscan(int v, int *scratch, int *tot)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int x = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        int y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    if (NT == 64) {
+        *tot = __shfl(x, 63, 64);
+        return x - v;
+    }
+    __syncthreads();
+    if (lane == 63) scratch[wv] = x;
+    __syncthreads();
+    int base = 0, t = 0;
+    for (int i = 0; i < NT / 64; i++) {
+        int s = scratch[i];
+        if (i < wv) base += s;
+        t += s;
+    }
+    *tot = t;
+    return base + x - v;
+}
+
+// pair-table view with one candidate stem overlaid (window coordinates are root
+// coordinates through shifted pointers)
+struct StemView {
+    const int16_t *pt;   // partner or -1
+    const int16_t *inv;  // local index in the node or -1
+    const uint16_t *pos;
+    int s5, mi, mj, e3;
+    __device__ __forceinline__ int operator()(int x) const
+    {
+        int q = pt[x];
+        if (q >= 0) return q;
+        int t = inv[x];
+        if (t >= s5 && t <= mi) return pos[mj + (mi - t)];
+        if (t >= mj && t <= e3) return pos[mi - (t - mj)];
+        return -1;
+    }
+};
+struct PlainView {
+    const int16_t *pt;
+    __device__ __forceinline__ int operator()(int x) const { return pt[x]; }
+};
+
+// ------------------------------------------------------------ expand kernel
+
+template <int NT>
+__global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, int spanmax, int nmax, int Kmax)
+{
+    extern __shared__ __align__(16) unsigned char lds[];
+    const ExpandLds lay = expand_lds(Pmax, spanmax, nmax, Kmax);
+    const int tid = threadIdx.x;
+    const int nid = d.work[cls][blockIdx.x];
+    const int sid = d.nd_sid[nid];
+    const int sq = d.st_seq[sid];
+    const int L = d.seq_len[sq], soff = d.seq_off[sq];
+    const int n = d.nd_n[nid], ci = d.nd_ci[nid], cj = d.nd_cj[nid];
+    const uint16_t *posg = d.pos + d.nd_pos[nid];
+    const uint8_t *codes = d.codes + soff;
+    const EnergyTables *T = d.T;
+
+    uint16_t *pos = (uint16_t *)(lds + lay.off_pos);
+    uint8_t *code = lds + lay.off_code;
+    uint16_t *rk = (uint16_t *)(lds + lay.off_rk);
+    uint16_t *wnb = (uint16_t *)(lds + lay.off_nb);
+    uint16_t *wmi = (uint16_t *)(lds + lay.off_mi);
+    uint16_t *wmj = (uint16_t *)(lds + lay.off_mj);
+    int *dd = (int *)(lds + lay.off_dd);
+    uint16_t *keep = (uint16_t *)(lds + lay.off_keep);
+    double *wtab = (double *)(lds + lay.off_w);
+    int *misc = (int *)(lds + lay.off_misc);
+
+    const int m = 2 * n - 1;
+    const int P = next_pow2_ge(m);
+    const int logP = 31 - __clz(P);
+    const int Kp = d.K < m ? (d.K > 0 ? d.K : 0) : m;
+
+    for (int t = tid; t < n; t += NT) {
+        int p = posg[t];
+        pos[t] = (uint16_t)p;
+        code[t] = codes[p];
+    }
+    if (tid < 25) {
+        int a = tid / 5, b = tid % 5;
+        int tp = kPairType[a][b];
+        wtab[tid] = (tp == 5 || tp == 6) ? d.au : (tp == 1 || tp == 2) ? d.gc : (tp == 3 || tp == 4) ? d.gu : 0.0;
+    }
+    __syncthreads();
+
+    // ---- correlation: conv(A,U), conv(G,C), conv(G,U) through two packed complex FFTs
+    float2 *z1 = (float2 *)(lds + lay.offA);
+    float2 *z2 = z1 + P;
+    for (int t = tid; t < P; t += NT) {
+        int c = t < n ? code[t] : 0;
+        z1[t] = make_float2(c == 1 ? 1.f : 0.f, c == 3 ? 1.f : 0.f); // A + iG
+        z2[t] = make_float2(c == 4 ? 1.f : 0.f, c == 2 ? 1.f : 0.f); // U + iC
+    }
+    __syncthreads();
+    for (int s = P >> 1; s >= 1; s >>= 1) {       // DIF, natural in -> bit-reversed out
+        const int tws = (MAX_P / 2) / s;
+        for (int b = tid; b < (P >> 1); b += NT) {
+            int off = b & (s - 1);
+            int j = ((b - off) << 1) + off;
+            float2 w = d.tw[off * tws];
+            float2 a = z1[j], bb = z1[j + s];
+            z1[j] = make_float2(a.x + bb.x, a.y + bb.y);
+            z1[j + s] = cmul(make_float2(a.x - bb.x, a.y - bb.y), w);
+            a = z2[j]; bb = z2[j + s];
+            z2[j] = make_float2(a.x + bb.x, a.y + bb.y);
+            z2[j + s] = cmul(make_float2(a.x - bb.x, a.y - bb.y), w);
+        }
+        __syncthreads();
+    }
+    for (int k = tid; k <= (P >> 1); k += NT) {   // separate the packed real spectra, multiply
+        int km = (P - k) & (P - 1);
+        int jk = (int)(__brev((unsigned)k) >> (32 - logP));
+        int jm = (int)(__brev((unsigned)km) >> (32 - logP));
+        float2 A1 = z1[jk], B1 = z1[jm], A2 = z2[jk], B2 = z2[jm];
+        float2 Fa = make_float2(0.5f * (A1.x + B1.x), 0.5f * (A1.y - B1.y));
+        float2 Fg = make_float2(0.5f * (A1.y + B1.y), -0.5f * (A1.x - B1.x));
+        float2 Fu = make_float2(0.5f * (A2.x + B2.x), 0.5f * (A2.y - B2.y));
+        float2 Fc = make_float2(0.5f * (A2.y + B2.y), -0.5f * (A2.x - B2.x));
+        float2 X = cmul(Fa, Fu), Y = cmul(Fg, Fc), Z = cmul(Fg, Fu);
+        z1[jk] = make_float2(X.x - Y.y, X.y + Y.x);
+        z2[jk] = Z;
+        if (jm != jk) {
+            z1[jm] = make_float2(X.x + Y.y, Y.x - X.y);
+            z2[jm] = make_float2(Z.x, -Z.y);
+        }
+    }
+    __syncthreads();
+    for (int s = 1; s < P; s <<= 1) {             // DIT inverse, bit-reversed in -> natural out
+        const int tws = (MAX_P / 2) / s;
+        for (int b = tid; b < (P >> 1); b += NT) {
+            int off = b & (s - 1);
+            int j = ((b - off) << 1) + off;
+            float2 w = d.tw[off * tws];
+            float2 a = z1[j], bb = cmulc(z1[j + s], w);
+            z1[j] = make_float2(a.x + bb.x, a.y + bb.y);
+            z1[j + s] = make_float2(a.x - bb.x, a.y - bb.y);
+            a = z2[j]; bb = cmulc(z2[j + s], w);
+            z2[j] = make_float2(a.x + bb.x, a.y + bb.y);
+            z2[j + s] = make_float2(a.x - bb.x, a.y - bb.y);
+        }
+        __syncthreads();
+    }
+
+    // ---- lag values (exact integer pair counts, IEEE fp64 divide) and ranking
+    double *keyv = (double *)(lds + lay.offA);
+    uint16_t *lagk = (uint16_t *)(lds + lay.offA + 8 * P);
+    {
+        // keyv[k] aliases z1[k] byte for byte and is written by the thread that read it;
+        // lagk aliases the head of z2, so it is filled only after every read of z2.
+        const float invP = 1.0f / (float)P;
+        for (int k = tid; k < P; k += NT) {
+            double v = -INFINITY;
+            if (k < m) {
+                double nAU = 2.0 * (double)rintf(z1[k].x * invP);
+                double nGC = 2.0 * (double)rintf(z1[k].y * invP);
+                double nGU = 2.0 * (double)rintf(z2[k].x * invP);
+                double raw = nAU * d.au + nGC * d.gc + nGU * d.gu;
+                int nk = k < m - 1 - k ? k : m - 1 - k;
+                v = raw / ((double)nk + 1.0);
+            }
+            keyv[k] = v;
+        }
+        __syncthreads();
+        for (int k = tid; k < P; k += NT) lagk[k] = (uint16_t)k;
+        __syncthreads();
+    }
+    for (int k2 = 2; k2 <= P; k2 <<= 1) {
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P; i += NT) {
+                int ixj = i ^ j;
+                if (ixj > i) {
+                    double va = keyv[i], vb = keyv[ixj];
+                    uint16_t la = lagk[i], lb = lagk[ixj];
+                    bool a_first = (va > vb) || (va == vb && la > lb);
+                    bool up = (i & k2) == 0;
+                    if (up ? !a_first : a_first) {
+                        keyv[i] = vb; keyv[ixj] = va;
+                        lagk[i] = lb; lagk[ixj] = la;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int r = tid; r < Kp; r += NT) {
+        rk[r] = lagk[r];
+        if (d.dbg.lag) { d.dbg.lag[r] = lagk[r]; d.dbg.corval[r] = keyv[r]; }
+    }
+    if (tid == 0 && d.dbg.n_ranked) *d.dbg.n_ranked = Kp;
+    __syncthreads();
+
+    // ---- window_slide, one lane per ranked lag (rafft/rafft.py:36-83)
+    for (int r = tid; r < Kp; r += NT) {
+        const int lagp = rk[r];
+        const int len = lagp < n ? lagp + 1 : 2 * n - lagp - 1;
+        const int len2 = (len >> 1) + (len & 1);
+        double prev = 0.0, mx_s = 0.0;
+        int tmp = 0, mx_nb = 0, mx_i = 0, mx_j = 0;
+        for (int i = 0; i < len2; i++) {
+            int ip, jp;
+            if (lagp < n) { ip = i; jp = lagp - i; }
+            else { ip = lagp - n + 1 + i; jp = n - i - 1; }
+            double t = wtab[code[ip] * 5 + code[jp]];
+            if (i > 0 && (int)pos[ip] - (int)pos[ip - 1] == 1 && (int)pos[jp + 1] - (int)pos[jp] == 1)
+                t = (prev + t) * t;
+            tmp = (t == 0.0) ? 0 : tmp + 1;
+            if (t >= mx_s && (int)pos[jp] - (int)pos[ip] > d.min_hp) {
+                mx_s = t; mx_nb = tmp; mx_i = ip; mx_j = jp;
+            }
+            prev = t;
+        }
+        wnb[r] = (uint16_t)mx_nb; wmi[r] = (uint16_t)mx_i; wmj[r] = (uint16_t)mx_j;
+        if (d.dbg.nb) { d.dbg.nb[r] = mx_nb; d.dbg.mi[r] = mx_i; d.dbg.mj[r] = mx_j; d.dbg.score[r] = mx_s; }
+    }
+    __syncthreads();
+
+    // ---- energy window of the enclosing loop (aliases the FFT/sort region)
+    const int w0 = ci < 0 ? 0 : ci, w1 = ci < 0 ? L - 1 : cj;
+    const int span = w1 - w0 + 1;
+    uint8_t *wS = lds + lay.offA;
+    const int aspan = (span + 15) & ~15;
+    int16_t *wpt = (int16_t *)(lds + lay.offA + aspan);
+    int16_t *winv = (int16_t *)(lds + lay.offA + aspan + ((2 * span + 15) & ~15));
+    const int16_t *ptg = d.pt + d.st_pt[sid];
+    for (int x = tid; x < span; x += NT) {
+        wS[x] = codes[w0 + x];
+        wpt[x] = ptg[w0 + x];
+        winv[x] = -1;
+    }
+    __syncthreads();
+    for (int t = tid; t < n; t += NT) winv[pos[t] - w0] = (int16_t)t;
+    __syncthreads();
+    const uint8_t *Sv = wS - w0;
+    const int16_t *ptv = wpt - w0, *invv = winv - w0;
+    if (tid == 0) {
+        int bad = 0;
+        PlainView pv{ptv};
+        misc[0] = loop_energy(T, Sv, L, pv, ci, cj, &bad);
+    }
+    __syncthreads();
+    const int e_old = misc[0];
+    const int par_dcal = d.st_dcal[sid];
+    const double par_e = dcal_to_energy(par_dcal);
+    for (int r = tid; r < Kp; r += NT) {
+        int nb = wnb[r];
+        keep[r] = 0;
+        dd[r] = 0;
+        if (nb > 0) {
+            int mi = wmi[r], mj = wmj[r], bad = 0;
+            StemView sv{ptv, invv, pos, mi - nb + 1, mi, mj, mj + nb - 1};
+            int e_new = loop_energy(T, Sv, L, sv, ci, cj, &bad);
+            e_new += loop_energy(T, Sv, L, sv, (int)pos[mi], (int)pos[mj], &bad);
+            for (int t = 1; t < nb; t++) {
+                int a = pos[mi - t], b = pos[mj + t], ap = pos[mi - t + 1], bp = pos[mj + t - 1];
+                if (ap == a + 1 && bp == b - 1)
+                    e_new += T->stack[pair_type(Sv[a], Sv[b])][kRtype[pair_type(Sv[ap], Sv[bp])]];
+                else
+                    e_new += loop_energy(T, Sv, L, sv, a, b, &bad);
+            }
+            int ddc = e_new - e_old;
+            dd[r] = ddc;
+            double dE = dcal_to_energy(par_dcal + ddc) - par_e;
+            keep[r] = (!bad && dE < d.min_nrj) ? 1 : 0;
+            if (d.dbg.ddcal) d.dbg.ddcal[r] = ddc;
+        } else if (d.dbg.ddcal)
+            d.dbg.ddcal[r] = INT_MIN;
+    }
+    __syncthreads();
+
+    // ---- stable sort of the kept candidates by dE (ties keep lag-rank order), emit
+    int nkept = 0;
+    for (int r = 0; r < Kp; r++) nkept += keep[r];   // LDS broadcast reads, Kp <= ~100
+    if (tid == 0) {
+        unsigned long long base = 0;
+        if (nkept) {
+            base = atomicAdd(&d.c->cand_top, (unsigned long long)nkept);
+            if (base + nkept > d.cand_cap) { atomicOr(&d.c->overflow, OVF_CAND); base = 0; misc[2] = 1; }
+            else misc[2] = 0;
+        } else misc[2] = 0;
+        *(unsigned long long *)&misc[4] = base;
+        atomicAdd(&d.c->n_expand, 1ULL);
+        atomicAdd(&d.c->sum_n, (unsigned long long)n);
+        atomicAdd(&d.c->sum_lags, (unsigned long long)Kp);
+        atomicAdd(&d.c->sum_span, (unsigned long long)span);
+    }
+    __syncthreads();
+    const unsigned long long cbase = *(unsigned long long *)&misc[4];
+    const bool ovf = misc[2] != 0;
+    if (!ovf) {
+        for (int r = tid; r < Kp; r += NT) {
+            if (!keep[r]) continue;
+            int my = dd[r], rank = 0;
+            for (int q = 0; q < Kp; q++)
+                if (keep[q] && (dd[q] < my || (dd[q] == my && q < r))) rank++;
+            int mi = wmi[r], mj = wmj[r], nb = wnb[r];
+            uint64_t h1 = 0, h2 = 0;
+            for (int t = 0; t < nb; t++) {
+                uint64_t a, b;
+                pair_hash(pos[mi - t], pos[mj + t], &a, &b);
+                h1 += a; h2 += b;
+            }
+            Cand cd;
+            cd.ddcal = my; cd.mi = (uint16_t)mi; cd.mj = (uint16_t)mj; cd.nb = (uint16_t)nb; cd.pad = 0; cd.pad2 = 0;
+            cd.h1 = h1; cd.h2 = h2;
+            d.cand[cbase + rank] = cd;
+            if (d.dbg.kept) d.dbg.kept[rank] = r;
+        }
+    }
+    if (tid == 0) {
+        d.nd_cand[nid] = cbase;
+        d.nd_ncand[nid] = ovf ? 0 : nkept;
+        if (d.dbg.n_ranked) d.dbg.n_ranked[1] = nkept;
+    }
+}
+
+// --------------------------------------------------------- beam step kernel
+
+__device__ inline bool seen_lookup(const uint64_t *tab, uint32_t cap, uint64_t h1, uint64_t h2)
+{
+    uint32_t mask = cap - 1, sl = (uint32_t)h1 & mask;
+    for (;;) {
+        uint64_t k1 = tab[2 * (uint64_t)sl];
+        if (k1 == 0) return false;
+        if (k1 == h1 && tab[2 * (uint64_t)sl + 1] == h2) return true;
+        sl = (sl + 1) & mask;
+    }
+}
+__device__ inline void seen_insert(uint64_t *tab, uint32_t cap, uint64_t h1, uint64_t h2)
+{
+    uint32_t mask = cap - 1, sl = (uint32_t)h1 & mask;
+    for (;;) {
+        unsigned long long old = atomicCAS((unsigned long long *)&tab[2 * (uint64_t)sl], 0ULL, (unsigned long long)h1);
+        if (old == 0) { tab[2 * (uint64_t)sl + 1] = h2; return; }
+        if (old == h1 && tab[2 * (uint64_t)sl + 1] == h2) return;
+        sl = (sl + 1) & mask;
+    }
+}
+
+#define BS_NT 256
+
+// LDS: sort keys (dynamic) + product description
+__global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
+{
+    extern __shared__ __align__(16) unsigned char lds[];
+    unsigned long long *skey = (unsigned long long *)lds;                       // [sort_cap]
+    int *prod_cnt = (int *)(lds + 8 * (size_t)sort_cap);                        // [MAX_PROD]
+    unsigned long long *prod_off = (unsigned long long *)(prod_cnt + MAX_PROD); // [MAX_PROD]
+    int *oldbeam = (int *)(prod_off + MAX_PROD);                                // [B]
+    int *sh = oldbeam + ((d.B + 3) & ~3);                                       // scratch [32]
+    const int tid = threadIdx.x;
+    const int sq = blockIdx.x;
+    if (d.done[sq]) return;
+    const int nbeam = d.beam_n[sq];
+    int *beam = d.beam + (size_t)sq * d.B;
+    for (int i = tid; i < nbeam; i += BS_NT) oldbeam[i] = beam[i];
+    __syncthreads();
+
+    // glob_traj += [glob_tree]   (rafft/rafft.py:161)
+    if (d.traj) {
+        if (tid == 0) {
+            unsigned long long r = atomicAdd(&d.c->trec_n, 1ULL);
+            unsigned long long o = atomicAdd(&d.c->tsid_top, (unsigned long long)nbeam);
+            if (r >= d.trec_cap || o + nbeam > d.tsid_cap) { atomicOr(&d.c->overflow, OVF_TRAJ); sh[0] = -1; }
+            else { d.trec[r] = make_int4(sq, d.nsteps[sq], nbeam, (int)o); sh[0] = (int)o; }
+        }
+        __syncthreads();
+        int o = sh[0];
+        if (o >= 0) for (int i = tid; i < nbeam; i += BS_NT) d.tsid[o + i] = oldbeam[i];
+        __syncthreads();
+    }
+    if (tid == 0) d.nsteps[sq] += 1;
+
+    uint64_t *stab = d.seen + 2 * d.seen_off[sq];
+    uint32_t scap = d.seen_cap[sq], scnt = d.seen_cnt[sq];
+    const size_t chb = (size_t)sq * d.ch_cap;
+    int nb_branch = 0, nchild = 0;
+
+    for (int b = 0; b < nbeam; b++) {
+        const int sid = oldbeam[b];
+        const int node0 = d.st_node0[sid], nn = d.st_nnodes[sid];
+        // productive nodes in node order (rafft/rafft.py:166-171)
+        int mprod = 0;
+        for (int base = 0; base < nn; base += BS_NT) {
+            int i = base + tid, cnt = 0;
+            if (i < nn) cnt = d.nd_ncand[node0 + i];
+            int tot, ex = block_exscan<BS_NT>(cnt > 0 ? 1 : 0, sh, &tot);
+            if (cnt > 0 && mprod + ex < MAX_PROD) {
+                prod_cnt[mprod + ex] = cnt;
+                prod_off[mprod + ex] = d.nd_cand[node0 + i];
+            }
+            mprod += tot;
+            __syncthreads();
+        }
+        if (mprod > MAX_PROD) { if (tid == 0) atomicOr(&d.c->overflow, OVF_PROD); mprod = MAX_PROD; }
+        if (mprod == 0) continue;
+        unsigned long long total = 1;
+        for (int k = 0; k < mprod; k++) {
+            unsigned long long c = (unsigned long long)prod_cnt[k];
+            total = (total > (1ULL << 62) / c) ? (1ULL << 62) : total * c;
+        }
+        unsigned long long cur = d.st_cursor[sid];
+        const int par_dcal = d.st_dcal[sid];
+        const uint64_t ph1 = d.st_h[2 * (size_t)sid], ph2 = d.st_h[2 * (size_t)sid + 1];
+        bool single = nb_branch >= d.max_branch;  // rafft/rafft.py:202-203: one combo, then break
+        if (single && cur > 0) continue;           // combo 0 is already in `seen`
+        while (cur < total) {
+            unsigned long long left = total - cur;
+            int chunk = single ? 1 : (left < BS_NT ? (int)left : BS_NT);
+            // grow the seen set if this chunk could push the load factor past 1/2
+            if ((unsigned long long)(scnt + chunk) * 2 > scap) {
+                uint32_t ncap = scap;
+                while ((unsigned long long)(scnt + chunk) * 2 > ncap) ncap <<= 1;
+                if (tid == 0) {
+                    unsigned long long o = atomicAdd(&d.c->seen_top, (unsigned long long)ncap);
+                    if (o + ncap > d.seen_cap_total) { atomicOr(&d.c->overflow, OVF_SEEN); *(unsigned long long *)&sh[8] = ~0ULL; }
+                    else *(unsigned long long *)&sh[8] = o;
+                }
+                __syncthreads();
+                unsigned long long o = *(unsigned long long *)&sh[8];
+                __syncthreads();
+                if (o == ~0ULL) { d.done[sq] = 1; return; }
+                uint64_t *ntab = d.seen + 2 * o;
+                for (uint32_t i = tid; i < scap; i += BS_NT) {
+                    uint64_t k1 = stab[2 * (uint64_t)i];
+                    if (k1) seen_insert(ntab, ncap, k1, stab[2 * (uint64_t)i + 1]);
+                }
+                __syncthreads();
+                stab = ntab; scap = ncap;
+                if (tid == 0) { d.seen_off[sq] = o; d.seen_cap[sq] = ncap; }
+            }
+            // decode combo `cur + tid` (itertools.product: last list fastest, rafft.py:180)
+            int isnew = 0, cd_dcal = 0;
+            uint64_t h1 = 0, h2 = 0;
+            if (tid < chunk) {
+                unsigned long long idx = cur + tid;
+                h1 = ph1; h2 = ph2; cd_dcal = par_dcal;
+                if (total <= 0xffffffffULL) {
+                    uint32_t ix = (uint32_t)idx;
+                    for (int k = mprod - 1; k >= 0; k--) {
+                        uint32_t c = (uint32_t)prod_cnt[k], q = ix / c, r = ix - q * c;
+                        ix = q;
+                        const Cand *cp = &d.cand[prod_off[k] + r];
+                        cd_dcal += cp->ddcal; h1 += cp->h1; h2 += cp->h2;
+                    }
+                } else {
+                    for (int k = mprod - 1; k >= 0; k--) {
+                        unsigned long long c = (unsigned long long)prod_cnt[k], q = idx / c, r = idx - q * c;
+                        idx = q;
+                        const Cand *cp = &d.cand[prod_off[k] + r];
+                        cd_dcal += cp->ddcal; h1 += cp->h1; h2 += cp->h2;
+                    }
+                }
+                if (h1 == 0) h1 = 1;
+                if (h2 == 0) h2 = 1;
+                isnew = seen_lookup(stab, scap, h1, h2) ? 0 : 1;
+            }
+            int tot, ex = block_exscan<BS_NT>(isnew, sh, &tot);
+            // first position where nb_branch reaches max_branch (checked after every combo)
+            int incl = ex + isnew;
+            int hit = (tid < chunk && nb_branch + incl >= d.max_branch) ? tid : BS_NT;
+            // block min of `hit`
+            for (int o = 32; o > 0; o >>= 1) hit = min(hit, __shfl_xor(hit, o, 64));
+            __syncthreads();
+            if ((tid & 63) == 0) sh[16 + (tid >> 6)] = hit;
+            __syncthreads();
+            hit = min(min(sh[16], sh[17]), min(sh[18], sh[19]));
+            int processed = hit < BS_NT ? hit + 1 : chunk;
+            int accepted_here = 0;
+            if (tid < processed && isnew) {
+                int ci2 = nchild + ex;
+                if (ci2 < d.ch_cap) {
+                    d.ch_parent[chb + ci2] = (uint16_t)b;
+                    d.ch_combo[chb + ci2] = cur + tid;
+                    d.ch_dcal[chb + ci2] = cd_dcal;
+                    d.ch_h[2 * (chb + ci2)] = h1;
+                    d.ch_h[2 * (chb + ci2) + 1] = h2;
+                } else atomicOr(&d.c->overflow, OVF_SORT);
+                seen_insert(stab, scap, h1, h2);
+                accepted_here = 1;
+            }
+            // number accepted = prefix at `processed`
+            int acc_tot;
+            {
+                int t2, e2 = block_exscan<BS_NT>(accepted_here, sh, &t2);
+                (void)e2;
+                acc_tot = t2;
+            }
+            nchild += acc_tot; nb_branch += acc_tot; scnt += acc_tot;
+            cur += processed;
+            __syncthreads();
+            if (nb_branch >= d.max_branch) break;
+        }
+        if (tid == 0) d.st_cursor[sid] = cur;
+    }
+    if (tid == 0) { d.seen_cnt[sq] = scnt; atomicAdd(&d.c->n_children, (unsigned long long)nchild); }
+    if (nchild > d.ch_cap) nchild = d.ch_cap;
+
+    // ---- new = children + beam, stable sort by energy, cut (rafft/rafft.py:206-210)
+    const int N = nchild + nbeam;
+    int M = 2; while (M < N) M <<= 1;
+    if (M > sort_cap) { if (tid == 0) atomicOr(&d.c->overflow, OVF_SORT); d.done[sq] = 1; return; }
+    for (int i = tid; i < M; i += BS_NT) {
+        unsigned long long key = ~0ULL;
+        if (i < nchild) key = ((unsigned long long)(uint32_t)(d.ch_dcal[chb + i] + 0x40000000) << 32) | (uint32_t)i;
+        else if (i < N) key = ((unsigned long long)(uint32_t)(d.st_dcal[oldbeam[i - nchild]] + 0x40000000) << 32) | (uint32_t)i;
+        skey[i] = key;
+    }
+    __syncthreads();
+    for (int k2 = 2; k2 <= M; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < M; i += BS_NT) {
+                int ixj = i ^ j;
+                if (ixj > i) {
+                    unsigned long long a = skey[i], bb = skey[ixj];
+                    bool up = (i & k2) == 0;
+                    if (up ? a > bb : a < bb) { skey[i] = bb; skey[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    const int nnew = N < d.B ? N : d.B;
+    // children among the survivors
+    int nsurv_child = 0;
+    for (int base = 0; base < nnew; base += BS_NT) {
+        int i = base + tid, f = 0;
+        if (i < nnew) f = ((uint32_t)skey[i] < (uint32_t)nchild) ? 1 : 0;
+        int tot, ex = block_exscan<BS_NT>(f, sh, &tot);
+        (void)ex;
+        nsurv_child += tot;
+        __syncthreads();
+    }
+    if (nsurv_child == 0) {   // same structures as before: fixed point (rafft/rafft.py:213-214)
+        if (tid == 0) {
+            d.done[sq] = 1;
+            atomicAdd(&d.c->n_done, 1u);
+            if (!d.traj) {
+                unsigned long long r = atomicAdd(&d.c->trec_n, 1ULL);
+                unsigned long long o = atomicAdd(&d.c->tsid_top, (unsigned long long)nbeam);
+                if (r >= d.trec_cap || o + nbeam > d.tsid_cap) atomicOr(&d.c->overflow, OVF_TRAJ);
+                else {
+                    d.trec[r] = make_int4(sq, 0, nbeam, (int)o);
+                    for (int i = 0; i < nbeam; i++) d.tsid[o + i] = oldbeam[i];
+                }
+            }
+        }
+        return;
+    }
+    if (tid == 0) {
+        unsigned long long sb = atomicAdd(&d.c->n_struct, (unsigned long long)nsurv_child);
+        unsigned int mb = atomicAdd(&d.c->n_mat, (unsigned int)nsurv_child);
+        if (sb + nsurv_child > d.st_cap || mb + nsurv_child > d.mat_cap) { atomicOr(&d.c->overflow, OVF_STRUCT); sh[24] = -1; }
+        else { sh[24] = (int)sb; sh[25] = (int)mb; }
+    }
+    __syncthreads();
+    const int sbase = sh[24], mbase = sh[25];
+    __syncthreads();
+    if (sbase < 0) { d.done[sq] = 1; return; }
+    int run = 0;
+    for (int base = 0; base < nnew; base += BS_NT) {
+        int i = base + tid, f = 0;
+        uint32_t ord = 0;
+        if (i < nnew) { ord = (uint32_t)skey[i]; f = (ord < (uint32_t)nchild) ? 1 : 0; }
+        int tot, ex = block_exscan<BS_NT>(f, sh, &tot);
+        if (i < nnew) {
+            if (f) {
+                int sid = sbase + run + ex;
+                size_t c = chb + ord;
+                d.st_seq[sid] = sq;
+                d.st_dcal[sid] = d.ch_dcal[c];
+                d.st_h[2 * (size_t)sid] = d.ch_h[2 * c];
+                d.st_h[2 * (size_t)sid + 1] = d.ch_h[2 * c + 1];
+                d.st_parent[sid] = oldbeam[d.ch_parent[c]];
+                d.st_combo[sid] = d.ch_combo[c];
+                d.st_cursor[sid] = 0;
+                d.st_nnodes[sid] = 0;
+                d.mat[mbase + run + ex] = sid;
+                beam[i] = sid;
+            } else
+                beam[i] = oldbeam[ord - nchild];
+        }
+        run += tot;
+        __syncthreads();
+    }
+    if (tid == 0) d.beam_n[sq] = nnew;
+}
+
+// ------------------------------------------------------- materialize kernel
+
+#define MAT_NT 64
+__global__ __launch_bounds__(MAT_NT) void materialize_kernel(Dev d)
+{
+    __shared__ int16_t spt[RAFFT_MAX_LEN];
+    __shared__ int prod_node[MAX_PROD];
+    __shared__ int prod_cnt[MAX_PROD];
+    __shared__ int sel[MAX_PROD];
+    __shared__ unsigned long long sh64[4];
+    __shared__ int shi[8];
+    const int tid = threadIdx.x;
+    const int sid = d.mat[blockIdx.x];
+    const int par = d.st_parent[sid];
+    const int sq = d.st_seq[sid];
+    const int L = d.seq_len[sq];
+    const int node0 = d.st_node0[par], nn = d.st_nnodes[par];
+    int mprod = 0;
+    for (int base = 0; base < nn; base += MAT_NT) {
+        int i = base + tid, cnt = 0;
+        if (i < nn) cnt = d.nd_ncand[node0 + i];
+        unsigned long long bal = __ballot(cnt > 0);
+        int ex = __popcll(bal & ((1ULL << tid) - 1));
+        if (cnt > 0 && mprod + ex < MAX_PROD) { prod_node[mprod + ex] = node0 + i; prod_cnt[mprod + ex] = cnt; }
+        mprod += __popcll(bal);
+    }
+    if (mprod > MAX_PROD) mprod = MAX_PROD;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long idx = d.st_combo[sid];
+        int nnew = 0, npos = 0;
+        for (int k = mprod - 1; k >= 0; k--) {
+            unsigned long long c = (unsigned long long)prod_cnt[k], q = idx / c;
+            sel[k] = (int)(idx - q * c);
+            idx = q;
+        }
+        for (int k = 0; k < mprod; k++) {
+            const Cand cd = d.cand[d.nd_cand[prod_node[k]] + sel[k]];
+            int n = d.nd_n[prod_node[k]];
+            int mi = cd.mi, mj = cd.mj, nb = cd.nb;
+            if (mj - mi > 1) { nnew++; npos += mj - mi - 1; }
+            if (mi - (nb - 1) > 0 || mj + nb < n) { nnew++; npos += (mi - nb + 1) + (n - (mj + nb)); }
+        }
+        unsigned long long nb0 = atomicAdd(&d.c->n_node, (unsigned long long)nnew);
+        unsigned long long pb0 = atomicAdd(&d.c->pos_top, (unsigned long long)npos);
+        unsigned long long tb0 = atomicAdd(&d.c->pt_top, (unsigned long long)L);
+        int ok = 1;
+        if (nb0 + nnew > d.nd_cap) { atomicOr(&d.c->overflow, OVF_NODE); ok = 0; }
+        if (pb0 + npos > d.pos_cap) { atomicOr(&d.c->overflow, OVF_POS); ok = 0; }
+        if (tb0 + L > d.pt_cap) { atomicOr(&d.c->overflow, OVF_PT); ok = 0; }
+        sh64[0] = nb0; sh64[1] = pb0; sh64[2] = tb0;
+        shi[0] = ok; shi[1] = nnew;
+        atomicAdd(&d.c->sum_struct_len, (unsigned long long)L);
+    }
+    __syncthreads();
+    if (!shi[0]) { if (tid == 0) { d.st_nnodes[sid] = 0; d.st_node0[sid] = 0; d.st_pt[sid] = 0; } return; }
+    const unsigned long long nbase = sh64[0], pbase = sh64[1], tbase = sh64[2];
+    const int16_t *ppt = d.pt + d.st_pt[par];
+    for (int x = tid; x < L; x += MAT_NT) spt[x] = ppt[x];
+    __syncthreads();
+    // stems -> pair table (rafft/rafft.py:97,127-128)
+    for (int k = 0; k < mprod; k++) {
+        const Cand cd = d.cand[d.nd_cand[prod_node[k]] + sel[k]];
+        const uint16_t *pp = d.pos + d.nd_pos[prod_node[k]];
+        for (int t = tid; t < cd.nb; t += MAT_NT) {
+            int a = pp[cd.mi - t], b = pp[cd.mj + t];
+            spt[a] = (int16_t)b; spt[b] = (int16_t)a;
+        }
+    }
+    __syncthreads();
+    int16_t *opt = d.pt + tbase;
+    for (int x = tid; x < L; x += MAT_NT) opt[x] = spt[x];
+    // child nodes: for each helix in combo order inner, then outer (rafft/rafft.py:187-190)
+    int nidx = 0;
+    unsigned long long poff = pbase;
+    for (int k = 0; k < mprod; k++) {
+        const int pn = prod_node[k];
+        const Cand cd = d.cand[d.nd_cand[pn] + sel[k]];
+        const uint16_t *pp = d.pos + d.nd_pos[pn];
+        const int n = d.nd_n[pn], pci = d.nd_ci[pn], pcj = d.nd_cj[pn];
+        const int mi = cd.mi, mj = cd.mj, nb = cd.nb;
+        if (mj - mi > 1) {     // inner loop (rafft/utils.py:148-152)
+            int len = mj - mi - 1;
+            for (int t = tid; t < len; t += MAT_NT) d.pos[poff + t] = pp[mi + 1 + t];
+            if (tid == 0) {
+                int nid = (int)(nbase + nidx);
+                int ci = pp[mi], cj = pp[mj];
+                d.nd_sid[nid] = sid; d.nd_pos[nid] = poff; d.nd_n[nid] = len;
+                d.nd_ci[nid] = ci; d.nd_cj[nid] = cj; d.nd_ncand[nid] = -1; d.nd_cand[nid] = 0;
+                int cls = node_class(len, cj - ci + 1);
+                unsigned int w = atomicAdd(&d.c->n_work[cls], 1u);
+                if (w < d.work_cap) d.work[cls][w] = nid; else atomicOr(&d.c->overflow, OVF_WORK);
+            }
+            nidx++; poff += len;
+        }
+        if (mi - (nb - 1) > 0 || mj + nb < n) {   // outer loop (rafft/utils.py:141-145)
+            int left = mi - nb + 1, right = mj + nb, len = left + (n - right);
+            for (int t = tid; t < len; t += MAT_NT) d.pos[poff + t] = t < left ? pp[t] : pp[right + (t - left)];
+            if (tid == 0) {
+                int nid = (int)(nbase + nidx);
+                d.nd_sid[nid] = sid; d.nd_pos[nid] = poff; d.nd_n[nid] = len;
+                d.nd_ci[nid] = pci; d.nd_cj[nid] = pcj; d.nd_ncand[nid] = -1; d.nd_cand[nid] = 0;
+                int cls = node_class(len, pci < 0 ? L : pcj - pci + 1);
+                unsigned int w = atomicAdd(&d.c->n_work[cls], 1u);
+                if (w < d.work_cap) d.work[cls][w] = nid; else atomicOr(&d.c->overflow, OVF_WORK);
+            }
+            nidx++; poff += len;
+        }
+    }
+    if (tid == 0) { d.st_node0[sid] = (int)nbase; d.st_nnodes[sid] = shi[1]; d.st_pt[sid] = tbase; }
+}
+
+// ------------------------------------------------------------- init kernel
+
+__global__ void init_roots_kernel(Dev d, const int *root_pt_off)
+{
+    const int sq = blockIdx.x, tid = threadIdx.x;
+    const int L = d.seq_len[sq];
+    // structure sq / node sq are the unfolded structure and its single node (rafft.py:224-231)
+    const unsigned long long off = (unsigned long long)root_pt_off[sq];
+    for (int x = tid; x < L; x += blockDim.x) { d.pt[off + x] = -1; d.pos[off + x] = (uint16_t)x; }
+    if (tid == 0) {
+        d.st_seq[sq] = sq; d.st_dcal[sq] = 0; d.st_h[2 * (size_t)sq] = 0; d.st_h[2 * (size_t)sq + 1] = 0;
+        d.st_pt[sq] = off; d.st_node0[sq] = sq; d.st_nnodes[sq] = L > 0 ? 1 : 0; d.st_cursor[sq] = 0;
+        d.st_parent[sq] = -1; d.st_combo[sq] = 0;
+        d.nd_sid[sq] = sq; d.nd_pos[sq] = off; d.nd_n[sq] = L; d.nd_ci[sq] = -1; d.nd_cj[sq] = L;
+        d.nd_ncand[sq] = -1; d.nd_cand[sq] = 0;
+        d.beam[(size_t)sq * d.B] = sq; d.beam_n[sq] = 1; d.nsteps[sq] = 0;
+        d.done[sq] = L > 0 ? 0 : 1;
+        d.seen_off[sq] = (uint64_t)sq * 1024; d.seen_cap[sq] = 1024; d.seen_cnt[sq] = 0;
+        if (L > 0) {
+            int cls = node_class(L, L);
+            unsigned int w = atomicAdd(&d.c->n_work[cls], 1u);
+            d.work[cls][w] = sq;
+        }
+    }
+}
+
+// ----------------------------------------------------------- output kernel
+
+__global__ void output_kernel(Dev d, int nrows, const int *row_sid, const long long *row_off, char *out_db, int *out_dcal)
+{
+    for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
+        const int sid = row_sid[r];
+        const int L = d.seq_len[d.st_seq[sid]];
+        const int16_t *pt = d.pt + d.st_pt[sid];
+        char *o = out_db + row_off[r];
+        for (int x = threadIdx.x; x < L; x += blockDim.x) {
+            int q = pt[x];
+            o[x] = q < 0 ? '.' : (q > x ? '(' : ')');
+        }
+        if (threadIdx.x == 0) { o[L] = 0; out_dcal[r] = d.st_dcal[sid]; }
+    }
+}
+
+// ------------------------------------------------------------- eval kernel
+
+// one wavefront per structure: sum of loop energies (rafft/utils.py:135-138)
+__global__ __launch_bounds__(64) void eval_kernel(const EnergyTables *T, int n, const uint8_t *codes, const int16_t *pts,
+                                                  const long long *off, const int *len, int *out, int *status)
+{
+    const int s = blockIdx.x, lane = threadIdx.x;
+    if (s >= n) return;
+    const int L = len[s];
+    const uint8_t *S = codes + off[s];
+    PlainView pv{pts + off[s]};
+    int e = 0, bad = 0;
+    if (lane == 0) e += loop_energy(T, S, L, pv, -1, L, &bad);
+    for (int i = lane; i < L; i += 64) {
+        int j = pv(i);
+        if (j > i) e += loop_energy(T, S, L, pv, i, j, &bad);
+    }
+    for (int o = 32; o > 0; o >>= 1) { e += __shfl_xor(e, o, 64); bad |= __shfl_xor(bad, o, 64); }
+    if (lane == 0) { out[s] = e; status[s] = bad ? 8 : 0; }
+}

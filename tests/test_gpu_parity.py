@@ -1,0 +1,107 @@
+"""Parity of the HIP path (through the C-ABI) against the oracle and the golden
+fixtures.  Everything here needs a real MI355X: run with `-m gpu`."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import rafft_amd
+from rafft_amd import rafft as R
+from conftest import GOLD
+
+pytestmark = pytest.mark.gpu
+
+EX = "GGGUUUGCGGUGUAAGUGCAGCCCGUCUUACACCGUGCGGCACAGGCACUAGUACUGAUGUCGUAUACAGGGCUUUUGACAU"
+
+
+def as_lists(traj):
+    return [[[s.str_struct, s.dcal] for s in st] for st in traj]
+
+
+def test_gpu_energy_kats_exact(energy_kats):
+    """Device Turner-2004 evaluator == the reference's 11 505 published energies (exact dcal)."""
+    seqs = [k[0] for k in energy_kats]
+    dbs = [k[1] for k in energy_kats]
+    got, st = R.eval_structures(seqs, dbs)
+    assert not any(st)
+    bad = [(i, g, k[2]) for i, (g, k) in enumerate(zip(got, energy_kats)) if g != k[2]]
+    assert not bad, bad[:5]
+
+
+@pytest.mark.parametrize("ms,fname", [(5, "example_rafft.out"), (20, "example_rafft_20.out")])
+def test_gpu_reference_example_trajectories(ms, fname):
+    fin, traj = rafft_amd.fold(EX, 100, ms, 1000, traj=True)
+    assert rafft_amd.format_trajectory(EX, traj) == open(os.path.join(GOLD, fname)).read()
+    assert [s.str_struct for s in fin] == [s.str_struct for s in traj[-1]]
+
+
+def test_gpu_expand_node_vs_reference_python_and_oracle(node_records):
+    """correlation profile, lag ranking, window_slide tuples, dE and kept order for single regions"""
+    for r in node_records:
+        g = R.expand_node(r["seq"], r["db"], r["pos"], r["nb_mode"], r["min_hp"], r["min_nrj"], r["gc"], r["au"], r["gu"])
+        o = oracle.expand_node(r["seq"], r["db"], r["pos"], r["nb_mode"], r["min_hp"], r["min_nrj"], r["gc"], r["au"], r["gu"])
+        assert g["lag"] == r["lags"] == o["lag"]
+        cor_sorted = [r["cor"][k] for k in r["lags"]]
+        assert g["cor"] == cor_sorted            # bit-exact fp64: integer counts, IEEE divide
+        ws = [[a, b, c, d] for a, b, c, d in zip(g["nb"], g["mi"], g["mj"], g["score"])]
+        assert ws == r["ws"]
+        assert g["ddcal"] == o["ddcal"]
+        assert g["kept"] == o["kept"]
+        sol = [[g["nb"][k], g["score"][k], g["mi"][k], g["mj"][k], g["ddcal"][k]] for k in g["kept"]]
+        assert sol == r["sol"]
+
+
+def test_gpu_fold_matches_reference_python_golden(fold_cases):
+    """full trajectories for every golden (sequence, params) case, batched per parameter set"""
+    groups = {}
+    for c in fold_cases:
+        groups.setdefault(tuple(sorted(c["params"].items())), []).append(c)
+    for key, cases in groups.items():
+        got = rafft_amd.fold_batch([c["seq"] for c in cases], traj=True, **dict(key))
+        for c, (fin, traj) in zip(cases, got):
+            assert as_lists(traj) == c["traj"], (c["seq"], c["params"])
+
+
+def test_gpu_cfg2_random_L200_vs_oracle():
+    """BASELINE configs[1] shape (L=200 i.i.d., n=100, ms=50), reduced count"""
+    rng = np.random.default_rng(200)
+    seqs = ["".join(rng.choice(list("ACGU"), 200)) for _ in range(48)]
+    got = rafft_amd.fold_batch(seqs, 100, 50, 1000, traj=True)
+    for s, (fin, traj) in zip(seqs, got):
+        _, o = oracle.fold(s, 100, 50, 1000, traj=True)
+        assert as_lists(traj) == as_lists(o), s
+
+
+def test_gpu_mixed_lengths_and_classes_vs_oracle():
+    """ragged batch crossing all three expand size classes (n up to 1500), with N bases"""
+    rng = np.random.default_rng(3000)
+    lens = [1, 2, 5, 17, 33, 64, 129, 257, 300, 511, 700, 1025, 1500]
+    seqs = ["".join(rng.choice(list("ACGU"), n)) for n in lens]
+    seqs.append("".join(rng.choice(list("ACGUN"), 150, p=[.22, .22, .22, .22, .12])))
+    got = rafft_amd.fold_batch(seqs, 100, 8, 1000, traj=True)
+    for s, (fin, traj) in zip(seqs, got):
+        _, o = oracle.fold(s, 100, 8, 1000, traj=True)
+        assert as_lists(traj) == as_lists(o), len(s)
+
+
+def test_gpu_final_only_equals_last_step():
+    rng = np.random.default_rng(5)
+    seqs = ["".join(rng.choice(list("ACGU"), 90)) for _ in range(16)]
+    a = rafft_amd.fold_batch(seqs, 100, 20, 1000, traj=False)
+    b = rafft_amd.fold_batch(seqs, 100, 20, 1000, traj=True)
+    for fin, (fin2, traj) in zip(a, b):
+        assert [(s.str_struct, s.dcal) for s in fin] == [(s.str_struct, s.dcal) for s in traj[-1]]
+
+
+def test_gpu_error_behaviour():
+    with pytest.raises(KeyError):
+        rafft_amd.fold("acgu")
+    with pytest.raises(KeyError):
+        rafft_amd.fold("ACGT")
+    with pytest.raises(np.exceptions.AxisError):
+        rafft_amd.fold("")
+    res = rafft_amd.fold_batch(["GGGAAACCC", "ACGT", ""], max_stack=3, raise_errors=False)
+    assert res[1] is None and res[2] is None and res[0][0].str_struct == oracle.fold("GGGAAACCC", max_stack=3)[0].str_struct
+    with pytest.raises(Exception):
+        rafft_amd.fold("GGGAAACCC", temp=25.0)
