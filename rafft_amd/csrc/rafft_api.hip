@@ -295,6 +295,7 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
     d.mat = (int *)g.mat.p; d.mat_cap = (uint32_t)c.mat;
     d.c = (Counters *)g.counters.p;
     if (dbg_single) d.dbg = *dbg_single;
+    if (const char *rp = getenv("RAFFT_REP")) d.rep = atoi(rp);
 
     hipStream_t st = g.stream;
     HIPCHK(hipMemcpyAsync(g.codes.p, codes.data(), sumL + 16, hipMemcpyHostToDevice, st));

@@ -78,6 +78,7 @@ struct Dev {
     int *mat; uint32_t mat_cap;
     Counters *c;
     DebugOut dbg;
+    int rep;                     // profiling only (RAFFT_REP env): bit k doubles phase k of expand_kernel
 };
 
 // expand-kernel size classes: {max P, max span, threads}

@@ -125,6 +125,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
     // ---- correlation: conv(A,U), conv(G,C), conv(G,U) through two packed complex FFTs
     float2 *z1 = (float2 *)(lds + lay.offA);
     float2 *z2 = z1 + P;
+    for (int rep_ = 0; rep_ < 1 + (d.rep & 1); rep_++) {   // d.rep: profiling-only phase doubling
     for (int t = tid; t < P; t += NT) {
         int c = t < n ? code[t] : 0;
         z1[t] = make_float2(c == 1 ? 1.f : 0.f, c == 3 ? 1.f : 0.f); // A + iG
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         }
         __syncthreads();
     }
+    }
 
     // ---- lag values (exact integer pair counts, IEEE fp64 divide) and ranking
     double *keyv = (double *)(lds + lay.offA);
@@ -203,6 +205,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         for (int k = tid; k < P; k += NT) lagk[k] = (uint16_t)k;
         __syncthreads();
     }
+    for (int rep_ = 0; rep_ < 1 + ((d.rep >> 1) & 1); rep_++)
     for (int k2 = 2; k2 <= P; k2 <<= 1) {
         for (int j = k2 >> 1; j > 0; j >>= 1) {
             for (int i = tid; i < P; i += NT) {
@@ -229,6 +232,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
     __syncthreads();
 
     // ---- window_slide, one lane per ranked lag (rafft/rafft.py:36-83)
+    for (int rep_ = 0; rep_ < 1 + ((d.rep >> 2) & 1); rep_++)
     for (int r = tid; r < Kp; r += NT) {
         const int lagp = rk[r];
         const int len = lagp < n ? lagp + 1 : 2 * n - lagp - 1;
@@ -280,6 +284,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
     const int e_old = misc[0];
     const int par_dcal = d.st_dcal[sid];
     const double par_e = dcal_to_energy(par_dcal);
+    for (int rep_ = 0; rep_ < 1 + ((d.rep >> 3) & 1); rep_++)
     for (int r = tid; r < Kp; r += NT) {
         int nb = wnb[r];
         keep[r] = 0;
