@@ -164,7 +164,10 @@ def main():
                          "alg_bytes_per_launch": round(bytes_per_launch, 1),
                          "mean_launch_ms": round(dur_s * 1e3, 4), "launches_per_step": launches / args.steps},
             "kernel_ms_per_step": {k: round(agg[k] / args.steps, 3) for k in
-                                   ("ms_total", "ms_expand", "ms_beam", "ms_materialize", "ms_output")},
+                                   ("ms_total", "ms_expand", "ms_expand_c1", "ms_expand_c2", "ms_expand_wall", "ms_beam",
+                                    "ms_materialize", "ms_output")},
+            "memoization": {"regions_created": agg["n_nodes_created"] // args.steps,
+                            "regions_expanded": agg["n_node_expansions"] // args.steps},
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -75,13 +75,18 @@ typedef struct {
  * device (HIP events on the library's own stream). */
 typedef struct {
     double ms_total;          /* wall time of the call, host side */
-    double ms_expand;         /* sum of expand-kernel durations (HIP events) */
+    double ms_expand;         /* sum of expand_kernel<64> durations (HIP events on its stream) */
+    double ms_expand_c1;      /* expand_kernel<256> (regions with 512 < P <= 2048), runs concurrently */
+    double ms_expand_c2;      /* expand_kernel<512> (P > 2048), runs concurrently */
+    double ms_expand_wall;    /* fork->join wall time of the three concurrent expand launches */
     double ms_beam;           /* sum of beam-step kernel durations */
     double ms_materialize;    /* sum of materialize kernel durations */
     double ms_output;         /* output formatting kernel */
     int64_t n_expand_launches;
     int64_t n_steps;          /* folding steps executed (max over sequences) */
-    int64_t n_node_expansions;/* unique (structure,node) pairs expanded */
+    int64_t n_node_expansions;/* regions really expanded (identical loops are expanded once) */
+    int64_t n_nodes_created;  /* (structure,node) pairs created, incl. aliases of known loops */
+    int64_t n_nodes_aliased;  /* regions that re-used an earlier identical loop's expansion */
     int64_t sum_node_len;     /* sum of n over expansions */
     int64_t sum_lags;         /* sum of min(nb_mode, 2n-1) over expansions */
     int64_t n_structs;        /* structures materialized (beam survivors) */

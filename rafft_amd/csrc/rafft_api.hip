@@ -48,14 +48,18 @@ struct Ctx {
     bool ready = false;
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t cls_stream[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    int n_cu = 256;
     EnergyTables *T = nullptr;
     float2 *tw = nullptr;
     size_t hbm_total = 0;
     std::vector<Buf *> bufs;
     // named workspace buffers (grow-only)
     Buf codes, seq_off, seq_len, beam, beam_n, done, nsteps, ch_parent, ch_combo, ch_dcal, ch_h, seen, seen_off,
-        seen_cap, seen_cnt, st_seq, st_dcal, st_node0, st_nnodes, st_parent, st_h, st_pt, st_cursor, st_combo, nd_sid,
-        nd_n, nd_ci, nd_cj, nd_ncand, nd_pos, nd_cand, pos, pt, cand, trec, tsid, work0, work1, work2, mat, counters,
+        seen_cap, seen_cnt, st_seq, st_dcal, st_node0, st_nnodes, st_parent, st_h, st_db, st_cursor, st_combo, nd_seq, nd_pdcal,
+        nd_n, nd_ci, nd_cj, nd_nbr, nd_canon, nd_ncand, nd_pos, nd_br, nd_cand, pos, br, db, cand, looptab, trec, tsid,
+        work0, work1, work2, mat, newnodes, counters,
         row_sid, row_off, out_db, out_dcal, dbg;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
@@ -103,6 +107,12 @@ int init_ctx(int device)
     HIPCHK(hipGetDeviceProperties(&prop, device));
     g.hbm_total = prop.totalGlobalMem;
     HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    for (int c = 0; c < 3; c++) {
+        HIPCHK(hipStreamCreateWithFlags(&g.cls_stream[c], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&g.ev_join[c], hipEventDisableTiming));
+    }
+    HIPCHK(hipEventCreateWithFlags(&g.ev_fork, hipEventDisableTiming));
+    g.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     // energy tables
     EnergyTables *h = new EnergyTables();
     memset(h, 0, sizeof *h);
@@ -143,16 +153,18 @@ int init_ctx(int device)
     return 0;
 }
 
-struct ClsCfg { int nt, Pmax, span, nmax, Kmax, lds; };
+struct ClsCfg { int nt, Pmax, Lmax, nmax, brmax, Kmax, lds, grid; };
 
 int class_cfg(int K, ClsCfg out[3])
 {
-    const int P[3] = {CLS0_P, CLS1_P, MAX_P}, SP[3] = {CLS0_SPAN, RAFFT_MAX_LEN, RAFFT_MAX_LEN}, NT[3] = {64, 256, 512};
+    const int P[3] = {CLS0_P, CLS1_P, MAX_P}, LM[3] = {CLS0_L, RAFFT_MAX_LEN, RAFFT_MAX_LEN}, NT[3] = {64, 256, 512};
+    const int BR[3] = {CLS0_BR, MAX_BR, MAX_BR};
     for (int c = 0; c < 3; c++) {
         int nmax = P[c] / 2;
         int Kmax = std::max(1, std::min(K, P[c] - 1));
-        ExpandLds l = expand_lds(P[c], SP[c], nmax, Kmax);
-        out[c] = {NT[c], P[c], SP[c], nmax, Kmax, l.total};
+        ExpandLds l = expand_lds(P[c], LM[c], nmax, BR[c], Kmax);
+        int per_cu = std::max(1, std::min(32 / (NT[c] / 64), (160 * 1024) / l.total));
+        out[c] = {NT[c], P[c], LM[c], nmax, BR[c], Kmax, l.total, g.n_cu * per_cu};
         if (l.total > 160 * 1024)
             return fail(RAFFT_ERR_PARAM, "nb_mode too large for the LDS-resident expand kernel");
     }
@@ -160,23 +172,23 @@ int class_cfg(int K, ClsCfg out[3])
 }
 
 template <int NT>
-int launch_expand(const Dev &d, int cls, const ClsCfg &cf, unsigned n_items)
+int launch_expand(const Dev &d, int cls, const ClsCfg &cf, unsigned n_blocks, hipStream_t st)
 {
     static int lds_set = 0;
     if (cf.lds > lds_set) {
         HIPCHK(hipFuncSetAttribute((const void *)expand_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, cf.lds));
         lds_set = cf.lds;
     }
-    hipLaunchKernelGGL(expand_kernel<NT>, dim3(n_items), dim3(NT), cf.lds, g.stream, d, cls, cf.Pmax, cf.span, cf.nmax, cf.Kmax);
+    hipLaunchKernelGGL(expand_kernel<NT>, dim3(n_blocks), dim3(NT), cf.lds, st, d, cls, cf.Pmax, cf.Lmax, cf.nmax, cf.brmax, cf.Kmax);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
-int launch_expand_cls(const Dev &d, int cls, const ClsCfg cf[3], unsigned n_items)
+int launch_expand_cls(const Dev &d, int cls, const ClsCfg cf[3], unsigned n_blocks, hipStream_t st)
 {
-    if (cls == 0) return launch_expand<64>(d, 0, cf[0], n_items);
-    if (cls == 1) return launch_expand<256>(d, 1, cf[1], n_items);
-    return launch_expand<512>(d, 2, cf[2], n_items);
+    if (cls == 0) return launch_expand<64>(d, 0, cf[0], n_blocks, st);
+    if (cls == 1) return launch_expand<256>(d, 1, cf[1], n_blocks, st);
+    return launch_expand<512>(d, 2, cf[2], n_blocks, st);
 }
 
 hipEvent_t next_event()
@@ -192,7 +204,7 @@ hipEvent_t next_event()
 struct Span { hipEvent_t a, b; int kind; };
 
 struct Caps {
-    size_t st, nd, pos, pt, cand, seen, trec, tsid, work, mat;
+    size_t st, nd, pos, br, db, cand, seen, trec, tsid, work, mat, looptab;
     int ch_cap, sort_cap;
     size_t bytes;
 };
@@ -204,22 +216,24 @@ Caps plan_caps(size_t S, size_t sumL, const rafft_params &p, double est)
     double avgL = S ? (double)sumL / (double)S : 1.0;
     double nstruct = (double)S * (1.0 + (double)B * est);
     c.st = (size_t)std::min(nstruct, 2.0e9) + 64;
-    double nodes_per = avgL / 10.0 + 4.0;
+    double nodes_per = avgL / 16.0 + 3.0;
     c.nd = (size_t)std::min((double)c.st * nodes_per, 2.0e9) + 64;
     c.pos = (size_t)((double)sumL + (double)(c.st - S) * avgL) + 4096;
-    c.pt = c.pos;
-    c.cand = c.nd * (size_t)std::min(std::max(p.nb_mode, 1), 24) + 4096;
+    c.br = c.pos / 2 + 4096;
+    c.db = c.pos;
+    c.cand = c.nd * (size_t)std::min(std::max(p.nb_mode, 1), 12) + 4096;
     double per_seq_seen = std::min(std::max(8.0 * est * ((double)B + (double)p.max_branch / 8.0), 4096.0), 4194304.0);
     c.seen = S * 1024 + (size_t)((double)S * per_seq_seen);
     c.trec = p.traj ? S * (size_t)(est * 3 + 16) : S + 16;
     c.tsid = c.trec * B + 16;
     c.work = c.nd;
     c.mat = S * B + 16;
+    c.looptab = 1024; while (c.looptab < 2 * c.nd) c.looptab <<= 1;
     c.ch_cap = p.max_branch + p.max_stack + 8;
     int need = p.max_branch + 2 * p.max_stack + 8;
     c.sort_cap = 2; while (c.sort_cap < need) c.sort_cap <<= 1;
-    c.bytes = c.st * (4 * 5 + 8 * 5) + c.nd * (4 * 5 + 8 * 2) + c.pos * 2 + c.pt * 2 + c.cand * 32 + c.seen * 16 +
-              c.trec * 16 + c.tsid * 4 + c.work * 4 * 3 + c.mat * 4 + S * (size_t)c.ch_cap * 32 + S * B * 4;
+    c.bytes = c.st * (4 * 5 + 8 * 5) + c.nd * (4 * 8 + 8 * 3 + 4 * 4) + c.pos * 2 + c.br * 4 + c.db + c.cand * 32 + c.seen * 16 +
+              c.looptab * 8 + c.trec * 16 + c.tsid * 4 + c.mat * 4 + S * (size_t)c.ch_cap * 32 + S * B * 4;
     return c;
 }
 
@@ -232,10 +246,16 @@ struct HostOut {   // owner of a rafft_result
     rafft_result res;
 };
 
+struct SeamIn {     // rafft_expand_node: one region of one given structure
+    DebugOut dbg;
+    std::vector<uint16_t> pos;
+    std::vector<uint32_t> br;
+    int ci, cj, pdcal;
+};
+
 // run one wave; returns 0, or RAFFT_ERR_CAPACITY with *ovf_bits set, or another error
 int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, HostOut &out, unsigned *ovf_bits,
-             std::vector<Span> &spans, const DebugOut *dbg_single = nullptr, const std::vector<int16_t> *dbg_pt = nullptr,
-             const std::vector<int> *dbg_pos = nullptr, int dbg_ci = -1, int dbg_cj = 0, int dbg_dcal = 0)
+             std::vector<Span> &spans, const SeamIn *seam = nullptr)
 {
     const size_t S = seqs.size();
     *ovf_bits = 0;
@@ -261,12 +281,14 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
     ENS(ch_parent, S * c.ch_cap * 2); ENS(ch_combo, S * c.ch_cap * 8); ENS(ch_dcal, S * c.ch_cap * 4); ENS(ch_h, S * c.ch_cap * 16);
     ENS(seen, c.seen * 16); ENS(seen_off, S * 8); ENS(seen_cap, S * 4); ENS(seen_cnt, S * 4);
     ENS(st_seq, c.st * 4); ENS(st_dcal, c.st * 4); ENS(st_node0, c.st * 4); ENS(st_nnodes, c.st * 4); ENS(st_parent, c.st * 4);
-    ENS(st_h, c.st * 16); ENS(st_pt, c.st * 8); ENS(st_cursor, c.st * 8); ENS(st_combo, c.st * 8);
-    ENS(nd_sid, c.nd * 4); ENS(nd_n, c.nd * 4); ENS(nd_ci, c.nd * 4); ENS(nd_cj, c.nd * 4); ENS(nd_ncand, c.nd * 4);
-    ENS(nd_pos, c.nd * 8); ENS(nd_cand, c.nd * 8);
-    ENS(pos, c.pos * 2); ENS(pt, c.pt * 2); ENS(cand, c.cand * 32);
+    ENS(st_h, c.st * 16); ENS(st_db, c.st * 8); ENS(st_cursor, c.st * 8); ENS(st_combo, c.st * 8);
+    ENS(nd_seq, c.nd * 4); ENS(nd_pdcal, c.nd * 4); ENS(nd_n, c.nd * 4); ENS(nd_ci, c.nd * 4); ENS(nd_cj, c.nd * 4);
+    ENS(nd_nbr, c.nd * 4); ENS(nd_canon, c.nd * 4); ENS(nd_ncand, c.nd * 4);
+    ENS(nd_pos, c.nd * 8); ENS(nd_br, c.nd * 8); ENS(nd_cand, c.nd * 8);
+    ENS(pos, c.pos * 2); ENS(br, c.br * 4); ENS(db, c.db); ENS(cand, c.cand * 32);
+    ENS(looptab, c.looptab * 8);
     ENS(trec, c.trec * 16); ENS(tsid, c.tsid * 4);
-    ENS(work0, c.work * 4); ENS(work1, c.work * 4); ENS(work2, c.work * 4); ENS(mat, c.mat * 4);
+    ENS(work0, c.work * 4); ENS(work1, c.work * 4); ENS(work2, c.work * 4); ENS(mat, c.mat * 4); ENS(newnodes, c.work * 4);
     ENS(counters, sizeof(Counters));
 #undef ENS
 
@@ -276,6 +298,10 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
     d.codes = (const uint8_t *)g.codes.p; d.seq_off = (const int *)g.seq_off.p; d.seq_len = (const int *)g.seq_len.p;
     d.K = p.nb_mode; d.B = p.max_stack; d.max_branch = p.max_branch; d.min_hp = p.min_hp; d.traj = p.traj;
     d.min_nrj = p.min_nrj; d.gc = p.gc_wei; d.au = p.au_wei; d.gu = p.gu_wei;
+    // identical loops share one expansion only when the energy filter cannot depend on the
+    // parent's absolute energy through float32 rounding, i.e. for the default min_nrj == 0
+    d.memo = (p.min_nrj == 0.0) ? 1 : 0;
+    if (const char *e = getenv("RAFFT_NO_MEMO")) if (atoi(e)) d.memo = 0;
     d.beam = (int *)g.beam.p; d.beam_n = (int *)g.beam_n.p; d.done = (int *)g.done.p; d.nsteps = (int *)g.nsteps.p;
     d.ch_cap = c.ch_cap;
     d.ch_parent = (uint16_t *)g.ch_parent.p; d.ch_combo = (uint64_t *)g.ch_combo.p; d.ch_dcal = (int *)g.ch_dcal.p; d.ch_h = (uint64_t *)g.ch_h.p;
@@ -283,18 +309,22 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
     d.seen_off = (uint64_t *)g.seen_off.p; d.seen_cap = (uint32_t *)g.seen_cap.p; d.seen_cnt = (uint32_t *)g.seen_cnt.p;
     d.st_cap = (uint32_t)c.st;
     d.st_seq = (int *)g.st_seq.p; d.st_dcal = (int *)g.st_dcal.p; d.st_node0 = (int *)g.st_node0.p; d.st_nnodes = (int *)g.st_nnodes.p;
-    d.st_parent = (int *)g.st_parent.p; d.st_h = (uint64_t *)g.st_h.p; d.st_pt = (uint64_t *)g.st_pt.p;
+    d.st_parent = (int *)g.st_parent.p; d.st_h = (uint64_t *)g.st_h.p; d.st_db = (uint64_t *)g.st_db.p;
     d.st_cursor = (uint64_t *)g.st_cursor.p; d.st_combo = (uint64_t *)g.st_combo.p;
     d.nd_cap = (uint32_t)c.nd;
-    d.nd_sid = (int *)g.nd_sid.p; d.nd_n = (int *)g.nd_n.p; d.nd_ci = (int *)g.nd_ci.p; d.nd_cj = (int *)g.nd_cj.p;
-    d.nd_ncand = (int *)g.nd_ncand.p; d.nd_pos = (uint64_t *)g.nd_pos.p; d.nd_cand = (uint64_t *)g.nd_cand.p;
-    d.pos = (uint16_t *)g.pos.p; d.pos_cap = c.pos; d.pt = (int16_t *)g.pt.p; d.pt_cap = c.pt;
+    d.nd_seq = (int *)g.nd_seq.p; d.nd_pdcal = (int *)g.nd_pdcal.p; d.nd_n = (int *)g.nd_n.p; d.nd_ci = (int *)g.nd_ci.p;
+    d.nd_cj = (int *)g.nd_cj.p; d.nd_nbr = (int *)g.nd_nbr.p; d.nd_canon = (int *)g.nd_canon.p; d.nd_ncand = (int *)g.nd_ncand.p;
+    d.nd_pos = (uint64_t *)g.nd_pos.p; d.nd_br = (uint64_t *)g.nd_br.p; d.nd_cand = (uint64_t *)g.nd_cand.p;
+    d.looptab = (unsigned long long *)g.looptab.p; d.looptab_cap = c.looptab;
+    d.pos = (uint16_t *)g.pos.p; d.pos_cap = c.pos; d.br = (uint32_t *)g.br.p; d.br_cap = c.br;
+    d.db = (uint8_t *)g.db.p; d.db_cap = c.db;
     d.cand = (Cand *)g.cand.p; d.cand_cap = c.cand;
     d.trec = (int4 *)g.trec.p; d.trec_cap = (uint32_t)c.trec; d.tsid = (int *)g.tsid.p; d.tsid_cap = c.tsid;
     d.work[0] = (int *)g.work0.p; d.work[1] = (int *)g.work1.p; d.work[2] = (int *)g.work2.p; d.work_cap = (uint32_t)c.work;
     d.mat = (int *)g.mat.p; d.mat_cap = (uint32_t)c.mat;
+    d.newnodes = (int *)g.newnodes.p; d.new_cap = (uint32_t)c.work;
     d.c = (Counters *)g.counters.p;
-    if (dbg_single) d.dbg = *dbg_single;
+    if (seam) d.dbg = seam->dbg;
     if (const char *rp = getenv("RAFFT_REP")) d.rep = atoi(rp);
 
     hipStream_t st = g.stream;
@@ -303,30 +333,31 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
     HIPCHK(hipMemcpyAsync(g.seq_len.p, len.data(), S * 4, hipMemcpyHostToDevice, st));
     Counters hc;
     memset(&hc, 0, sizeof hc);
-    hc.n_struct = S; hc.n_node = S; hc.pos_top = sumL; hc.pt_top = sumL; hc.seen_top = S * 1024;
+    hc.n_struct = S; hc.n_node = S; hc.pos_top = sumL; hc.db_top = sumL; hc.seen_top = S * 1024;
     HIPCHK(hipMemcpyAsync(g.counters.p, &hc, sizeof hc, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(g.seen.p, 0, c.seen * 16, st));
-    hipLaunchKernelGGL(init_roots_kernel, dim3((unsigned)S), dim3(64), 0, st, d, (const int *)g.seq_off.p);
+    if (d.memo) HIPCHK(hipMemsetAsync(g.looptab.p, 0, c.looptab * 8, st));
+    hipLaunchKernelGGL(init_roots_kernel, dim3((unsigned)S), dim3(64), 0, st, d);
     HIPCHK(hipGetLastError());
 
-    if (dbg_single) {
-        // seam: overwrite the root structure/node of sequence 0 with the given structure + region
+    if (seam) {
+        // seam: overwrite the root region of sequence 0 with the given loop of the given structure
         HIPCHK(hipStreamSynchronize(st));
-        HIPCHK(hipMemcpy(g.pt.p, dbg_pt->data(), dbg_pt->size() * 2, hipMemcpyHostToDevice));
-        std::vector<uint16_t> p16(dbg_pos->begin(), dbg_pos->end());
-        HIPCHK(hipMemcpy(g.pos.p, p16.data(), p16.size() * 2, hipMemcpyHostToDevice));
-        int n = (int)p16.size();
+        HIPCHK(hipMemcpy(g.pos.p, seam->pos.data(), seam->pos.size() * 2, hipMemcpyHostToDevice));
+        if (!seam->br.empty()) HIPCHK(hipMemcpy(g.br.p, seam->br.data(), seam->br.size() * 4, hipMemcpyHostToDevice));
+        int n = (int)seam->pos.size(), nbr = (int)seam->br.size();
         HIPCHK(hipMemcpy(g.nd_n.p, &n, 4, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(g.nd_ci.p, &dbg_ci, 4, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(g.nd_cj.p, &dbg_cj, 4, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(g.st_dcal.p, &dbg_dcal, 4, hipMemcpyHostToDevice));
-        int cls = node_class(n, dbg_ci < 0 ? seqs[0].len : dbg_cj - dbg_ci + 1);
+        HIPCHK(hipMemcpy(g.nd_nbr.p, &nbr, 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(g.nd_ci.p, &seam->ci, 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(g.nd_cj.p, &seam->cj, 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(g.nd_pdcal.p, &seam->pdcal, 4, hipMemcpyHostToDevice));
+        int cls = node_class(n, seqs[0].len, nbr);
         int zero = 0;
         memset(&hc.n_work, 0, sizeof hc.n_work);
         hc.n_work[cls] = 1;
         HIPCHK(hipMemcpy(g.counters.p, &hc, sizeof hc, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(d.work[cls], &zero, 4, hipMemcpyHostToDevice));
-        if (int rc = launch_expand_cls(d, cls, cf, 1)) return rc;
+        if (int rc = launch_expand_cls(d, cls, cf, 1, st)) return rc;
         HIPCHK(hipStreamSynchronize(st));
         return 0;
     }
@@ -338,21 +369,28 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
         bs_lds_set = bs_lds;
     }
     const size_t cnt_work_off = offsetof(Counters, n_work);
+    const size_t cnt_work_len = offsetof(Counters, overflow) - cnt_work_off;   // n_work[3], n_mat, n_new, next_work[3]
     int steps = 0;
     for (;;) {
-        HIPCHK(hipMemcpyAsync(&hc, g.counters.p, sizeof hc, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        if (hc.overflow) { *ovf_bits = hc.overflow; break; }
-        for (int cls = 0; cls < 3; cls++)
-            if (hc.n_work[cls]) {
-                Span sp{next_event(), next_event(), 0};
-                HIPCHK(hipEventRecord(sp.a, st));
-                if (int rc = launch_expand_cls(d, cls, cf, hc.n_work[cls])) return rc;
-                HIPCHK(hipEventRecord(sp.b, st));
-                spans.push_back(sp);
-                g.stats.n_expand_launches++;
-            }
-        HIPCHK(hipMemsetAsync((char *)g.counters.p + cnt_work_off, 0, 4 * sizeof(unsigned), st)); // n_work[3], n_mat
+        // ---- expand: the three size classes run concurrently on their own streams
+        HIPCHK(hipEventRecord(g.ev_fork, st));
+        Span wall{next_event(), next_event(), 4};
+        HIPCHK(hipEventRecord(wall.a, st));
+        for (int cls = 0; cls < 3; cls++) {
+            hipStream_t cs = g.cls_stream[cls];
+            HIPCHK(hipStreamWaitEvent(cs, g.ev_fork, 0));
+            Span sp{next_event(), next_event(), 10 + cls};
+            HIPCHK(hipEventRecord(sp.a, cs));
+            if (int rc = launch_expand_cls(d, cls, cf, (unsigned)cf[cls].grid, cs)) return rc;
+            HIPCHK(hipEventRecord(sp.b, cs));
+            spans.push_back(sp);
+            HIPCHK(hipEventRecord(g.ev_join[cls], cs));
+            HIPCHK(hipStreamWaitEvent(st, g.ev_join[cls], 0));
+        }
+        HIPCHK(hipEventRecord(wall.b, st));
+        spans.push_back(wall);
+        g.stats.n_expand_launches++;
+        HIPCHK(hipMemsetAsync((char *)g.counters.p + cnt_work_off, 0, cnt_work_len, st));
         {
             Span sp{next_event(), next_event(), 1};
             HIPCHK(hipEventRecord(sp.a, st));
@@ -371,6 +409,8 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
             HIPCHK(hipEventRecord(sp.a, st));
             hipLaunchKernelGGL(materialize_kernel, dim3(hc.n_mat), dim3(MAT_NT), 0, st, d);
             HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(dedupe_kernel, dim3(g.n_cu * 4), dim3(256), 0, st, d);
+            HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(sp.b, st));
             spans.push_back(sp);
         }
@@ -381,8 +421,10 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
             return fail(RAFFT_ERR_PARAM, "structure with more than 1024 productive regions or sort capacity exceeded");
         return RAFFT_ERR_CAPACITY;
     }
-    // statistics (SURVEY.md 8d algorithmic bytes)
+    // statistics (SURVEY.md 8d algorithmic bytes; only expansions the kernels really executed)
     g.stats.n_node_expansions += hc.n_expand;
+    g.stats.n_nodes_created += (int64_t)hc.n_node;
+    g.stats.n_nodes_aliased += (int64_t)hc.n_alias;
     g.stats.sum_node_len += hc.sum_n;
     g.stats.sum_lags += hc.sum_lags;
     g.stats.n_structs += (int64_t)hc.n_struct;
@@ -530,7 +572,10 @@ int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs, 
     for (auto &sp : spans) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
-            if (sp.kind == 0) g.stats.ms_expand += ms;
+            if (sp.kind == 10) g.stats.ms_expand += ms;
+            else if (sp.kind == 11) g.stats.ms_expand_c1 += ms;
+            else if (sp.kind == 12) g.stats.ms_expand_c2 += ms;
+            else if (sp.kind == 4) g.stats.ms_expand_wall += ms;
             else if (sp.kind == 1) g.stats.ms_beam += ms;
             else if (sp.kind == 2) g.stats.ms_materialize += ms;
             else g.stats.ms_output += ms;
@@ -651,16 +696,25 @@ int rafft_expand_node(const rafft_params *p, const char *seq, const char *db, co
     int ci = -1, cj = L;
     for (int x = pos[0] - 1, depth = 0; x >= 0; x--) {
         if (pt[x] < 0) continue;
-        if (pt[x] < x) { depth++; continue; }      // ')' partner to the left: skip its helix
+        if (pt[x] < x) { depth++; continue; }
         if (depth > 0) { depth--; continue; }
         if (pt[x] > pos[0]) { ci = x; cj = pt[x]; break; }
     }
+    SeamIn sm;
+    sm.ci = ci; sm.cj = cj;
+    for (int x = ci + 1; x < cj;) {            // branch helices hanging in that loop
+        if (pt[x] < 0) { x++; continue; }
+        sm.br.push_back((uint32_t)x | ((uint32_t)pt[x] << 16));
+        x = pt[x] + 1;
+    }
+    sm.pos.assign(pos, pos + n);
     int par_dcal = 0;
     if (int rc = eval_structures_impl(1, &seq, &db, &par_dcal, nullptr)) return rc;
+    sm.pdcal = par_dcal;
     const int K = std::max(1, std::min(p->nb_mode, 2 * n - 1));
     if (int rc = ensure(g.dbg, (size_t)K * (4 * 7 + 8 * 2) + 64)) return rc;
     char *b = (char *)g.dbg.p;
-    DebugOut dbg;
+    DebugOut &dbg = sm.dbg;
     dbg.n_ranked = (int *)b; b += 16;
     dbg.lag = (int *)b; b += 4 * K; dbg.nb = (int *)b; b += 4 * K; dbg.mi = (int *)b; b += 4 * K; dbg.mj = (int *)b; b += 4 * K;
     dbg.ddcal = (int *)b; b += 4 * K; dbg.kept = (int *)b; b += 4 * K;
@@ -671,11 +725,10 @@ int rafft_expand_node(const rafft_params *p, const char *seq, const char *db, co
     ho.seq.resize(1); ho.step_size.resize(1); ho.step_off.resize(1); ho.dcal.resize(1); ho.db.resize(1);
     unsigned ovf = 0;
     std::vector<Span> spans;
-    std::vector<int> posv(pos, pos + n);
     g.ev_used = 0;
     rafft_params pp = *p;
     pp.max_stack = std::max(1, pp.max_stack);
-    if (int rc = run_wave(pp, one, 4.0, ho, &ovf, spans, &dbg, &pt, &posv, ci, cj, par_dcal)) return rc;
+    if (int rc = run_wave(pp, one, 4.0, ho, &ovf, spans, &sm)) return rc;
     int hdr[4];
     HIPCHK(hipMemcpy(hdr, dbg.n_ranked, 16, hipMemcpyDeviceToHost));
     *n_ranked = hdr[0]; *n_kept = hdr[1];

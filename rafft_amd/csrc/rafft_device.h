@@ -185,3 +185,61 @@ __device__ __host__ inline void pair_hash(int i, int j, uint64_t *h1, uint64_t *
     *h1 = mix64(k);
     *h2 = mix64(k ^ 0xa5a5a5a5deadbeefULL);
 }
+
+// ---- loop energy from an explicit (virtual) branch list -------------------
+// A loop of the structure = closing pair (ci,cj) + the ordered outermost pairs of the
+// helices hanging in it.  Candidate stems change loops only by splicing branch lists,
+// so the fold kernels never walk a pair table: br[a0..a1) ++ [mid] ++ br[b0..b1).
+struct BrList {
+    const uint32_t *br;
+    int a0, a1, b0, b1, has_mid, mp, mq;
+    __device__ __forceinline__ int count() const { return (a1 - a0) + has_mid + (b1 - b0); }
+    __device__ __forceinline__ void get(int i, int &p, int &q) const
+    {
+        const int na = a1 - a0;
+        if (has_mid && i == na) { p = mp; q = mq; return; }
+        uint32_t u = i < na ? br[a0 + i] : br[b0 + (i - na - has_mid)];
+        p = (int)(u & 0xffffu); q = (int)(u >> 16);
+    }
+};
+
+__device__ inline int loop_energy_br(const EnergyTables *T, const uint8_t *S, int L, int ci, int cj, const BrList &bl)
+{
+    const int k = bl.count();
+    if (ci < 0) {
+        int e = 0;
+        for (int i = 0; i < k; i++) {
+            int p, q;
+            bl.get(i, p, q);
+            e += e_stem(T, pair_type(S[p], S[q]), p > 0 ? (int)S[p - 1] : -1, q < L - 1 ? (int)S[q + 1] : -1, true);
+        }
+        return e;
+    }
+    const int type = pair_type(S[ci], S[cj]);
+    if (k == 0) return e_hairpin(T, cj - ci - 1, type, S, ci, cj);
+    if (k == 1) {
+        int p, q;
+        bl.get(0, p, q);
+        return e_intloop(T, p - ci - 1, cj - q - 1, type, kRtype[pair_type(S[p], S[q])], S[ci + 1], S[cj - 1], S[p - 1], S[q + 1]);
+    }
+    int e = 0, u = cj - ci - 1;
+    for (int i = 0; i < k; i++) {
+        int p, q;
+        bl.get(i, p, q);
+        e += e_stem(T, pair_type(S[p], S[q]), S[p - 1], S[q + 1], false);
+        u -= q - p + 1;
+    }
+    e += e_stem(T, kRtype[type], S[cj - 1], S[ci + 1], false);
+    return e + T->ml_closing + u * T->ml_base;
+}
+
+// number of branches whose 5' end lies before x (branches sorted by p)
+__device__ __forceinline__ int br_lower(const uint32_t *br, int nbr, int x)
+{
+    int lo = 0, hi = nbr;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if ((int)(br[mid] & 0xffffu) < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}

@@ -1,17 +1,22 @@
-// rafft_kernels.h - device state + HIP kernels of the RAFFT fold engine (gfx950).
+// rafft_kernels.h - device state of the RAFFT fold engine (gfx950).
 //
-// Data layout in HBM (one batch = many independent sequences, SoA arenas, all
-// bump-allocated and monotonic inside a batch so no kernel ever frees):
-//   codes[sum L]            uint8 base codes (N=0 A=1 C=2 G=3 U=4)
-//   struct table st_*[]     one row per beam survivor: energy (dcal), 128-bit pair-set
-//                           hash, pair-table offset, node range, product cursor
-//   pt arena                int16 pair table per structure (partner or -1), L entries
-//   node table nd_*[]       one row per unpaired region (= one loop of the structure):
-//                           pos offset/len, closing pair (ci,cj), candidate list
-//   pos arena               uint16 root positions of every node, ascending
-//   cand arena              32-byte stem candidates, dE-sorted per node
-//   seen arena              per-sequence open-addressing sets of 128-bit hashes
-//   children[S][cap]        per-step accepted children (parent, combo, dcal, hash)
+// Data layout in HBM (one batch = many independent sequences; SoA tables + bump
+// arenas, monotonic inside a batch so no kernel ever frees):
+//   codes[sum L]        uint8 base codes (N=0 A=1 C=2 G=3 U=4)
+//   struct table st_*   one row per beam survivor: energy (dcal), 128-bit pair-set hash,
+//                       dot-bracket row offset, node range, product cursor, lineage
+//   db arena            dot-bracket bytes of every survivor (L per structure)
+//   node table nd_*     one row per unpaired region.  A region is exactly one loop of
+//                       the structure: closing pair (ci,cj) (ci<0: exterior loop), the
+//                       ordered unpaired positions `pos` and the ordered branch helices
+//                       `br` hanging in that loop.  Its candidate stems depend on
+//                       nothing else, so identical loops met in different structures
+//                       are expanded ONCE (nd_canon -> canonical node; `loop table`).
+//   pos arena           uint16 root positions of every node, ascending
+//   br arena            uint32 (p | q<<16) outermost pair of every branch, ascending
+//   cand arena          32-byte stem candidates, dE-sorted per canonical node
+//   seen arena          per-sequence open-addressing sets of 128-bit structure hashes
+//   children[S][cap]    per-step accepted children (parent, combo, dcal, hash)
 // Names follow the reference: Node/Structure (rafft/utils.py:24-39), beam =
 // glob_tree, trajectory = glob_traj (rafft/rafft.py:156-216).
 #pragma once
@@ -26,17 +31,20 @@ struct alignas(16) Cand {
 static_assert(sizeof(Cand) == 32, "Cand must be 32 bytes");
 
 struct Counters {
-    unsigned long long n_struct, n_node, pos_top, pt_top, cand_top, seen_top, trec_n, tsid_top;
-    unsigned int n_work[3];
-    unsigned int n_mat;
+    unsigned long long n_struct, n_node, pos_top, db_top, cand_top, seen_top, trec_n, tsid_top, br_top;
+    unsigned int n_work[3];     // expand work items per size class (filled by dedupe_kernel)
+    unsigned int n_mat;         // structures to materialize (filled by beam_step_kernel)
+    unsigned int n_new;         // nodes created by materialize_kernel, input of dedupe_kernel
+    unsigned int next_work[3];  // dynamic fetch cursors of the persistent expand kernels
     unsigned int overflow;      // bit mask of which arena overflowed
     unsigned int n_done;
+    unsigned int pad_;
     // statistics
-    unsigned long long n_expand, sum_n, sum_lags, n_children, sum_struct_len, sum_span;
+    unsigned long long n_expand, sum_n, sum_lags, n_children, sum_struct_len, n_alias, sum_nbr;
 };
 
-enum { OVF_STRUCT = 1, OVF_NODE = 2, OVF_POS = 4, OVF_PT = 8, OVF_CAND = 16, OVF_SEEN = 32,
-       OVF_TRAJ = 64, OVF_WORK = 128, OVF_PROD = 256, OVF_SORT = 512 };
+enum { OVF_STRUCT = 1, OVF_NODE = 2, OVF_POS = 4, OVF_DB = 8, OVF_CAND = 16, OVF_SEEN = 32,
+       OVF_TRAJ = 64, OVF_WORK = 128, OVF_PROD = 256, OVF_SORT = 512, OVF_BR = 1024, OVF_LOOPTAB = 2048 };
 
 struct DebugOut {       // kernel-level seam (rafft_expand_node); null in production
     int *n_ranked, *lag, *nb, *mi, *mj, *ddcal, *kept;
@@ -49,7 +57,7 @@ struct Dev {
     int S;
     const uint8_t *codes;
     const int *seq_off, *seq_len;
-    int K, B, max_branch, min_hp, traj;
+    int K, B, max_branch, min_hp, traj, memo;
     double min_nrj, gc, au, gu;
     int *beam, *beam_n, *done, *nsteps;
     // children of the current step
@@ -61,14 +69,17 @@ struct Dev {
     // structures
     uint32_t st_cap;
     int *st_seq, *st_dcal, *st_node0, *st_nnodes, *st_parent;
-    uint64_t *st_h, *st_pt, *st_cursor, *st_combo;
+    uint64_t *st_h, *st_db, *st_cursor, *st_combo;
     // nodes
     uint32_t nd_cap;
-    int *nd_sid, *nd_n, *nd_ci, *nd_cj, *nd_ncand;
-    uint64_t *nd_pos, *nd_cand;
+    int *nd_seq, *nd_pdcal, *nd_n, *nd_ci, *nd_cj, *nd_nbr, *nd_canon, *nd_ncand;
+    uint64_t *nd_pos, *nd_br, *nd_cand;
+    // loop table: open addressing, word = (hash tag << 32) | (node id + 1)
+    unsigned long long *looptab; uint64_t looptab_cap;   // power of two
     // arenas
     uint16_t *pos; uint64_t pos_cap;
-    int16_t *pt; uint64_t pt_cap;
+    uint32_t *br; uint64_t br_cap;
+    uint8_t *db; uint64_t db_cap;
     Cand *cand; uint64_t cand_cap;
     // trajectory records: (seq, step, count, offset into tsid)
     int4 *trec; uint32_t trec_cap;
@@ -76,42 +87,46 @@ struct Dev {
     // work lists
     int *work[3]; uint32_t work_cap;
     int *mat; uint32_t mat_cap;
+    int *newnodes; uint32_t new_cap;
     Counters *c;
     DebugOut dbg;
     int rep;                     // profiling only (RAFFT_REP env): bit k doubles phase k of expand_kernel
 };
 
-// expand-kernel size classes: {max P, max span, threads}
+// expand-kernel size classes
 #define CLS0_P 512
-#define CLS0_SPAN 1280
+#define CLS0_L 1280
+#define CLS0_BR 256
 #define CLS1_P 2048
 #define MAX_P 8192
+#define MAX_BR 1024
 #define MAX_PROD 1024
 
 __host__ __device__ inline int next_pow2_ge(int x) { int p = 2; while (p < x) p <<= 1; return p; }
-__host__ __device__ inline int node_class(int n, int span)
+__host__ __device__ inline int node_class(int n, int L, int nbr)
 {
     int P = next_pow2_ge(2 * n - 1);
-    if (P <= CLS0_P && span <= CLS0_SPAN) return 0;
+    if (P <= CLS0_P && L <= CLS0_L && nbr <= CLS0_BR) return 0;
     if (P <= CLS1_P) return 1;
     return 2;
 }
 
 // LDS layout of the expand kernel (bytes).  Region A is time-shared between the FFT
-// buffers, the sort keys and the energy window; region B holds the node itself.
+// buffers and the sort keys; region B holds the loop itself.
 struct ExpandLds {
-    int offA, szA, off_pos, off_code, off_rk, off_nb, off_mi, off_mj, off_dd, off_keep, off_w, off_misc, total;
+    int offA, szA, off_pos, off_code, off_S, off_br, off_rk, off_nb, off_mi, off_mj, off_dd, off_keep, off_w, off_misc, total;
 };
-__host__ __device__ inline ExpandLds expand_lds(int Pmax, int span_max, int nmax, int Kmax)
+__host__ __device__ inline ExpandLds expand_lds(int Pmax, int Lmax, int nmax, int brmax, int Kmax)
 {
     ExpandLds l;
     auto al = [](int x) { return (x + 15) & ~15; };
-    int szE = al(span_max) + 2 * al(2 * span_max);
     l.offA = 0;
-    l.szA = al(16 * Pmax > szE ? 16 * Pmax : szE);
+    l.szA = al(16 * Pmax);
     int o = l.szA;
-    l.off_pos = o; o += al(2 * nmax);
+    l.off_pos = o; o += al(2 * nmax + 2);
     l.off_code = o; o += al(nmax);
+    l.off_S = o; o += al(Lmax + 8);
+    l.off_br = o; o += al(4 * brmax);
     l.off_rk = o; o += al(2 * Kmax);
     l.off_nb = o; o += al(2 * Kmax);
     l.off_mi = o; o += al(2 * Kmax);

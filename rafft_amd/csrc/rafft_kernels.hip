@@ -1,16 +1,19 @@
 // rafft_kernels.hip - the HIP kernels of the fold hot path (gfx950 / MI355X only).
 //
-//   expand_kernel       one workgroup (one wavefront for the common size class) per
-//                       unpaired region: LDS-resident complex FFT correlation
-//                       (rafft/utils.py:115-132), lag ranking (rafft/rafft.py:117-118,92),
-//                       window_slide (rafft/rafft.py:36-83), local Turner dE of every
-//                       candidate stem + filter/sort (rafft/rafft.py:86-109)
+//   expand_kernel       persistent workgroups (one wavefront for the common size class)
+//                       fetch unpaired regions from a work list: LDS-resident packed
+//                       complex FFT correlation (rafft/utils.py:115-132), lag ranking
+//                       (rafft/rafft.py:117-118,92), window_slide (rafft/rafft.py:36-83),
+//                       local Turner dE of every candidate stem from the loop's branch
+//                       list + filter/sort (rafft/rafft.py:86-109)
 //   beam_step_kernel    one workgroup per sequence: helix combination in product
 //                       order with `seen` dedupe and the max_branch rule, stable
 //                       energy sort and beam cut (rafft/rafft.py:176-214)
-//   materialize_kernel  one wavefront per new beam member: pair table + child
-//                       nodes (rafft/rafft.py:127-152, rafft/utils.py:141-152)
-//   output_kernel       pair tables -> dot-bracket rows (rafft/utils.py:42-50)
+//   materialize_kernel  one wavefront per new beam member: dot-bracket row + child
+//                       regions (rafft/rafft.py:127-152, rafft/utils.py:141-152)
+//   dedupe_kernel       identical loops reached through different structures share one
+//                       expansion (no counterpart in the reference, which recomputes)
+//   output_kernel       gathers dot-bracket rows (rafft/utils.py:42-50)
 //   eval_kernel         whole-structure energy (rafft/utils.py:135-138), C-ABI hook
 //
 // This is bandwidth/latency-bound small-FFT + integer table work: no MFMA.
@@ -55,23 +58,6 @@ __device__ inline int block_exscan(int v, int *scratch, int *tot)
     return base + x - v;
 }
 
-// pair-table view with one candidate stem overlaid (window coordinates are root
-// coordinates through shifted pointers)
-struct StemView {
-    const int16_t *pt;   // partner or -1
-    const int16_t *inv;  // local index in the node or -1
-    const uint16_t *pos;
-    int s5, mi, mj, e3;
-    __device__ __forceinline__ int operator()(int x) const
-    {
-        int q = pt[x];
-        if (q >= 0) return q;
-        int t = inv[x];
-        if (t >= s5 && t <= mi) return pos[mj + (mi - t)];
-        if (t >= mj && t <= e3) return pos[mi - (t - mj)];
-        return -1;
-    }
-};
 struct PlainView {
     const int16_t *pt;
     __device__ __forceinline__ int operator()(int x) const { return pt[x]; }
@@ -80,22 +66,16 @@ struct PlainView {
 // ------------------------------------------------------------ expand kernel
 
 template <int NT>
-__global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, int spanmax, int nmax, int Kmax)
+__global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, int Lmax, int nmax, int brmax, int Kmax)
 {
     extern __shared__ __align__(16) unsigned char lds[];
-    const ExpandLds lay = expand_lds(Pmax, spanmax, nmax, Kmax);
+    const ExpandLds lay = expand_lds(Pmax, Lmax, nmax, brmax, Kmax);
     const int tid = threadIdx.x;
-    const int nid = d.work[cls][blockIdx.x];
-    const int sid = d.nd_sid[nid];
-    const int sq = d.st_seq[sid];
-    const int L = d.seq_len[sq], soff = d.seq_off[sq];
-    const int n = d.nd_n[nid], ci = d.nd_ci[nid], cj = d.nd_cj[nid];
-    const uint16_t *posg = d.pos + d.nd_pos[nid];
-    const uint8_t *codes = d.codes + soff;
     const EnergyTables *T = d.T;
-
     uint16_t *pos = (uint16_t *)(lds + lay.off_pos);
     uint8_t *code = lds + lay.off_code;
+    uint8_t *Sl = lds + lay.off_S;
+    uint32_t *brl = (uint32_t *)(lds + lay.off_br);
     uint16_t *rk = (uint16_t *)(lds + lay.off_rk);
     uint16_t *wnb = (uint16_t *)(lds + lay.off_nb);
     uint16_t *wmi = (uint16_t *)(lds + lay.off_mi);
@@ -105,255 +85,261 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
     double *wtab = (double *)(lds + lay.off_w);
     int *misc = (int *)(lds + lay.off_misc);
 
-    const int m = 2 * n - 1;
-    const int P = next_pow2_ge(m);
-    const int logP = 31 - __clz(P);
-    const int Kp = d.K < m ? (d.K > 0 ? d.K : 0) : m;
-
-    for (int t = tid; t < n; t += NT) {
-        int p = posg[t];
-        pos[t] = (uint16_t)p;
-        code[t] = codes[p];
-    }
     if (tid < 25) {
         int a = tid / 5, b = tid % 5;
         int tp = kPairType[a][b];
         wtab[tid] = (tp == 5 || tp == 6) ? d.au : (tp == 1 || tp == 2) ? d.gc : (tp == 3 || tp == 4) ? d.gu : 0.0;
     }
-    __syncthreads();
+    const unsigned n_items = d.c->n_work[cls];
 
-    // ---- correlation: conv(A,U), conv(G,C), conv(G,U) through two packed complex FFTs
-    float2 *z1 = (float2 *)(lds + lay.offA);
-    float2 *z2 = z1 + P;
-    for (int rep_ = 0; rep_ < 1 + (d.rep & 1); rep_++) {   // d.rep: profiling-only phase doubling
-    for (int t = tid; t < P; t += NT) {
-        int c = t < n ? code[t] : 0;
-        z1[t] = make_float2(c == 1 ? 1.f : 0.f, c == 3 ? 1.f : 0.f); // A + iG
-        z2[t] = make_float2(c == 4 ? 1.f : 0.f, c == 2 ? 1.f : 0.f); // U + iC
-    }
-    __syncthreads();
-    for (int s = P >> 1; s >= 1; s >>= 1) {       // DIF, natural in -> bit-reversed out
-        const int tws = (MAX_P / 2) / s;
-        for (int b = tid; b < (P >> 1); b += NT) {
-            int off = b & (s - 1);
-            int j = ((b - off) << 1) + off;
-            float2 w = d.tw[off * tws];
-            float2 a = z1[j], bb = z1[j + s];
-            z1[j] = make_float2(a.x + bb.x, a.y + bb.y);
-            z1[j + s] = cmul(make_float2(a.x - bb.x, a.y - bb.y), w);
-            a = z2[j]; bb = z2[j + s];
-            z2[j] = make_float2(a.x + bb.x, a.y + bb.y);
-            z2[j + s] = cmul(make_float2(a.x - bb.x, a.y - bb.y), w);
-        }
+    for (;;) {
+        __syncthreads();                       // previous region's LDS use is over
+        if (tid == 0) misc[8] = (int)atomicAdd(&d.c->next_work[cls], 1u);
         __syncthreads();
-    }
-    for (int k = tid; k <= (P >> 1); k += NT) {   // separate the packed real spectra, multiply
-        int km = (P - k) & (P - 1);
-        int jk = (int)(__brev((unsigned)k) >> (32 - logP));
-        int jm = (int)(__brev((unsigned)km) >> (32 - logP));
-        float2 A1 = z1[jk], B1 = z1[jm], A2 = z2[jk], B2 = z2[jm];
-        float2 Fa = make_float2(0.5f * (A1.x + B1.x), 0.5f * (A1.y - B1.y));
-        float2 Fg = make_float2(0.5f * (A1.y + B1.y), -0.5f * (A1.x - B1.x));
-        float2 Fu = make_float2(0.5f * (A2.x + B2.x), 0.5f * (A2.y - B2.y));
-        float2 Fc = make_float2(0.5f * (A2.y + B2.y), -0.5f * (A2.x - B2.x));
-        float2 X = cmul(Fa, Fu), Y = cmul(Fg, Fc), Z = cmul(Fg, Fu);
-        z1[jk] = make_float2(X.x - Y.y, X.y + Y.x);
-        z2[jk] = Z;
-        if (jm != jk) {
-            z1[jm] = make_float2(X.x + Y.y, Y.x - X.y);
-            z2[jm] = make_float2(Z.x, -Z.y);
-        }
-    }
-    __syncthreads();
-    for (int s = 1; s < P; s <<= 1) {             // DIT inverse, bit-reversed in -> natural out
-        const int tws = (MAX_P / 2) / s;
-        for (int b = tid; b < (P >> 1); b += NT) {
-            int off = b & (s - 1);
-            int j = ((b - off) << 1) + off;
-            float2 w = d.tw[off * tws];
-            float2 a = z1[j], bb = cmulc(z1[j + s], w);
-            z1[j] = make_float2(a.x + bb.x, a.y + bb.y);
-            z1[j + s] = make_float2(a.x - bb.x, a.y - bb.y);
-            a = z2[j]; bb = cmulc(z2[j + s], w);
-            z2[j] = make_float2(a.x + bb.x, a.y + bb.y);
-            z2[j + s] = make_float2(a.x - bb.x, a.y - bb.y);
-        }
-        __syncthreads();
-    }
-    }
+        const unsigned item = (unsigned)misc[8];
+        if (item >= n_items) break;
+        const int nid = d.work[cls][item];
+        const int sq = d.nd_seq[nid];
+        const int L = d.seq_len[sq];
+        const int n = d.nd_n[nid], ci = d.nd_ci[nid], cj = d.nd_cj[nid], nbr = d.nd_nbr[nid];
+        const uint16_t *posg = d.pos + d.nd_pos[nid];
+        const uint32_t *brg = d.br + d.nd_br[nid];
+        const uint8_t *codes = d.codes + d.seq_off[sq];
+        const int m = 2 * n - 1;
+        const int P = next_pow2_ge(m);
+        const int logP = 31 - __clz(P);
+        const int Kp = d.K < m ? (d.K > 0 ? d.K : 0) : m;
 
-    // ---- lag values (exact integer pair counts, IEEE fp64 divide) and ranking
-    double *keyv = (double *)(lds + lay.offA);
-    uint16_t *lagk = (uint16_t *)(lds + lay.offA + 8 * P);
-    {
-        // keyv[k] aliases z1[k] byte for byte and is written by the thread that read it;
-        // lagk aliases the head of z2, so it is filled only after every read of z2.
-        const float invP = 1.0f / (float)P;
-        for (int k = tid; k < P; k += NT) {
-            double v = -INFINITY;
-            if (k < m) {
-                double nAU = 2.0 * (double)rintf(z1[k].x * invP);
-                double nGC = 2.0 * (double)rintf(z1[k].y * invP);
-                double nGU = 2.0 * (double)rintf(z2[k].x * invP);
-                double raw = nAU * d.au + nGC * d.gc + nGU * d.gu;
-                int nk = k < m - 1 - k ? k : m - 1 - k;
-                v = raw / ((double)nk + 1.0);
+        for (int t = tid; t < n; t += NT) {
+            int p = posg[t];
+            pos[t] = (uint16_t)p;
+            code[t] = codes[p];
+        }
+        for (int x = tid; x < L; x += NT) Sl[x] = codes[x];
+        for (int t = tid; t < nbr; t += NT) brl[t] = brg[t];
+        __syncthreads();
+
+        // ---- correlation: conv(A,U), conv(G,C), conv(G,U) through two packed complex FFTs
+        float2 *z1 = (float2 *)(lds + lay.offA);
+        float2 *z2 = z1 + P;
+        for (int rep_ = 0; rep_ < 1 + (d.rep & 1); rep_++) {   // d.rep: profiling-only phase doubling
+            for (int t = tid; t < P; t += NT) {
+                int c = t < n ? code[t] : 0;
+                z1[t] = make_float2(c == 1 ? 1.f : 0.f, c == 3 ? 1.f : 0.f); // A + iG
+                z2[t] = make_float2(c == 4 ? 1.f : 0.f, c == 2 ? 1.f : 0.f); // U + iC
             }
-            keyv[k] = v;
-        }
-        __syncthreads();
-        for (int k = tid; k < P; k += NT) lagk[k] = (uint16_t)k;
-        __syncthreads();
-    }
-    for (int rep_ = 0; rep_ < 1 + ((d.rep >> 1) & 1); rep_++)
-    for (int k2 = 2; k2 <= P; k2 <<= 1) {
-        for (int j = k2 >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < P; i += NT) {
-                int ixj = i ^ j;
-                if (ixj > i) {
-                    double va = keyv[i], vb = keyv[ixj];
-                    uint16_t la = lagk[i], lb = lagk[ixj];
-                    bool a_first = (va > vb) || (va == vb && la > lb);
-                    bool up = (i & k2) == 0;
-                    if (up ? !a_first : a_first) {
-                        keyv[i] = vb; keyv[ixj] = va;
-                        lagk[i] = lb; lagk[ixj] = la;
-                    }
+            __syncthreads();
+            for (int s = P >> 1; s >= 1; s >>= 1) {       // DIF, natural in -> bit-reversed out
+                const int tws = (MAX_P / 2) / s;
+                for (int b = tid; b < (P >> 1); b += NT) {
+                    int off = b & (s - 1);
+                    int j = ((b - off) << 1) + off;
+                    float2 w = d.tw[off * tws];
+                    float2 a = z1[j], bb = z1[j + s];
+                    z1[j] = make_float2(a.x + bb.x, a.y + bb.y);
+                    z1[j + s] = cmul(make_float2(a.x - bb.x, a.y - bb.y), w);
+                    a = z2[j]; bb = z2[j + s];
+                    z2[j] = make_float2(a.x + bb.x, a.y + bb.y);
+                    z2[j + s] = cmul(make_float2(a.x - bb.x, a.y - bb.y), w);
+                }
+                __syncthreads();
+            }
+            for (int k = tid; k <= (P >> 1); k += NT) {   // separate the packed real spectra, multiply
+                int km = (P - k) & (P - 1);
+                int jk = (int)(__brev((unsigned)k) >> (32 - logP));
+                int jm = (int)(__brev((unsigned)km) >> (32 - logP));
+                float2 A1 = z1[jk], B1 = z1[jm], A2 = z2[jk], B2 = z2[jm];
+                float2 Fa = make_float2(0.5f * (A1.x + B1.x), 0.5f * (A1.y - B1.y));
+                float2 Fg = make_float2(0.5f * (A1.y + B1.y), -0.5f * (A1.x - B1.x));
+                float2 Fu = make_float2(0.5f * (A2.x + B2.x), 0.5f * (A2.y - B2.y));
+                float2 Fc = make_float2(0.5f * (A2.y + B2.y), -0.5f * (A2.x - B2.x));
+                float2 X = cmul(Fa, Fu), Y = cmul(Fg, Fc), Z = cmul(Fg, Fu);
+                z1[jk] = make_float2(X.x - Y.y, X.y + Y.x);
+                z2[jk] = Z;
+                if (jm != jk) {
+                    z1[jm] = make_float2(X.x + Y.y, Y.x - X.y);
+                    z2[jm] = make_float2(Z.x, -Z.y);
                 }
             }
             __syncthreads();
-        }
-    }
-    for (int r = tid; r < Kp; r += NT) {
-        rk[r] = lagk[r];
-        if (d.dbg.lag) { d.dbg.lag[r] = lagk[r]; d.dbg.corval[r] = keyv[r]; }
-    }
-    if (tid == 0 && d.dbg.n_ranked) *d.dbg.n_ranked = Kp;
-    __syncthreads();
-
-    // ---- window_slide, one lane per ranked lag (rafft/rafft.py:36-83)
-    for (int rep_ = 0; rep_ < 1 + ((d.rep >> 2) & 1); rep_++)
-    for (int r = tid; r < Kp; r += NT) {
-        const int lagp = rk[r];
-        const int len = lagp < n ? lagp + 1 : 2 * n - lagp - 1;
-        const int len2 = (len >> 1) + (len & 1);
-        double prev = 0.0, mx_s = 0.0;
-        int tmp = 0, mx_nb = 0, mx_i = 0, mx_j = 0;
-        for (int i = 0; i < len2; i++) {
-            int ip, jp;
-            if (lagp < n) { ip = i; jp = lagp - i; }
-            else { ip = lagp - n + 1 + i; jp = n - i - 1; }
-            double t = wtab[code[ip] * 5 + code[jp]];
-            if (i > 0 && (int)pos[ip] - (int)pos[ip - 1] == 1 && (int)pos[jp + 1] - (int)pos[jp] == 1)
-                t = (prev + t) * t;
-            tmp = (t == 0.0) ? 0 : tmp + 1;
-            if (t >= mx_s && (int)pos[jp] - (int)pos[ip] > d.min_hp) {
-                mx_s = t; mx_nb = tmp; mx_i = ip; mx_j = jp;
+            for (int s = 1; s < P; s <<= 1) {             // DIT inverse, bit-reversed in -> natural out
+                const int tws = (MAX_P / 2) / s;
+                for (int b = tid; b < (P >> 1); b += NT) {
+                    int off = b & (s - 1);
+                    int j = ((b - off) << 1) + off;
+                    float2 w = d.tw[off * tws];
+                    float2 a = z1[j], bb = cmulc(z1[j + s], w);
+                    z1[j] = make_float2(a.x + bb.x, a.y + bb.y);
+                    z1[j + s] = make_float2(a.x - bb.x, a.y - bb.y);
+                    a = z2[j]; bb = cmulc(z2[j + s], w);
+                    z2[j] = make_float2(a.x + bb.x, a.y + bb.y);
+                    z2[j + s] = make_float2(a.x - bb.x, a.y - bb.y);
+                }
+                __syncthreads();
             }
-            prev = t;
         }
-        wnb[r] = (uint16_t)mx_nb; wmi[r] = (uint16_t)mx_i; wmj[r] = (uint16_t)mx_j;
-        if (d.dbg.nb) { d.dbg.nb[r] = mx_nb; d.dbg.mi[r] = mx_i; d.dbg.mj[r] = mx_j; d.dbg.score[r] = mx_s; }
-    }
-    __syncthreads();
 
-    // ---- energy window of the enclosing loop (aliases the FFT/sort region)
-    const int w0 = ci < 0 ? 0 : ci, w1 = ci < 0 ? L - 1 : cj;
-    const int span = w1 - w0 + 1;
-    uint8_t *wS = lds + lay.offA;
-    const int aspan = (span + 15) & ~15;
-    int16_t *wpt = (int16_t *)(lds + lay.offA + aspan);
-    int16_t *winv = (int16_t *)(lds + lay.offA + aspan + ((2 * span + 15) & ~15));
-    const int16_t *ptg = d.pt + d.st_pt[sid];
-    for (int x = tid; x < span; x += NT) {
-        wS[x] = codes[w0 + x];
-        wpt[x] = ptg[w0 + x];
-        winv[x] = -1;
-    }
-    __syncthreads();
-    for (int t = tid; t < n; t += NT) winv[pos[t] - w0] = (int16_t)t;
-    __syncthreads();
-    const uint8_t *Sv = wS - w0;
-    const int16_t *ptv = wpt - w0, *invv = winv - w0;
-    if (tid == 0) {
-        int bad = 0;
-        PlainView pv{ptv};
-        misc[0] = loop_energy(T, Sv, L, pv, ci, cj, &bad);
-    }
-    __syncthreads();
-    const int e_old = misc[0];
-    const int par_dcal = d.st_dcal[sid];
-    const double par_e = dcal_to_energy(par_dcal);
-    for (int rep_ = 0; rep_ < 1 + ((d.rep >> 3) & 1); rep_++)
-    for (int r = tid; r < Kp; r += NT) {
-        int nb = wnb[r];
-        keep[r] = 0;
-        dd[r] = 0;
-        if (nb > 0) {
-            int mi = wmi[r], mj = wmj[r], bad = 0;
-            StemView sv{ptv, invv, pos, mi - nb + 1, mi, mj, mj + nb - 1};
-            int e_new = loop_energy(T, Sv, L, sv, ci, cj, &bad);
-            e_new += loop_energy(T, Sv, L, sv, (int)pos[mi], (int)pos[mj], &bad);
-            for (int t = 1; t < nb; t++) {
-                int a = pos[mi - t], b = pos[mj + t], ap = pos[mi - t + 1], bp = pos[mj + t - 1];
-                if (ap == a + 1 && bp == b - 1)
-                    e_new += T->stack[pair_type(Sv[a], Sv[b])][kRtype[pair_type(Sv[ap], Sv[bp])]];
-                else
-                    e_new += loop_energy(T, Sv, L, sv, a, b, &bad);
+        // ---- lag values (exact integer pair counts, IEEE fp64 divide) and ranking
+        double *keyv = (double *)(lds + lay.offA);
+        uint16_t *lagk = (uint16_t *)(lds + lay.offA + 8 * P);
+        {
+            // keyv[k] aliases z1[k] byte for byte and is written by the thread that read it;
+            // lagk aliases the head of z2, so it is filled only after every read of z2.
+            const float invP = 1.0f / (float)P;
+            for (int k = tid; k < P; k += NT) {
+                double v = -INFINITY;
+                if (k < m) {
+                    double nAU = 2.0 * (double)rintf(z1[k].x * invP);
+                    double nGC = 2.0 * (double)rintf(z1[k].y * invP);
+                    double nGU = 2.0 * (double)rintf(z2[k].x * invP);
+                    double raw = nAU * d.au + nGC * d.gc + nGU * d.gu;
+                    int nk = k < m - 1 - k ? k : m - 1 - k;
+                    v = raw / ((double)nk + 1.0);
+                }
+                keyv[k] = v;
             }
-            int ddc = e_new - e_old;
-            dd[r] = ddc;
-            double dE = dcal_to_energy(par_dcal + ddc) - par_e;
-            keep[r] = (!bad && dE < d.min_nrj) ? 1 : 0;
-            if (d.dbg.ddcal) d.dbg.ddcal[r] = ddc;
-        } else if (d.dbg.ddcal)
-            d.dbg.ddcal[r] = INT_MIN;
-    }
-    __syncthreads();
-
-    // ---- stable sort of the kept candidates by dE (ties keep lag-rank order), emit
-    int nkept = 0;
-    for (int r = 0; r < Kp; r++) nkept += keep[r];   // LDS broadcast reads, Kp <= ~100
-    if (tid == 0) {
-        unsigned long long base = 0;
-        if (nkept) {
-            base = atomicAdd(&d.c->cand_top, (unsigned long long)nkept);
-            if (base + nkept > d.cand_cap) { atomicOr(&d.c->overflow, OVF_CAND); base = 0; misc[2] = 1; }
-            else misc[2] = 0;
-        } else misc[2] = 0;
-        *(unsigned long long *)&misc[4] = base;
-        atomicAdd(&d.c->n_expand, 1ULL);
-        atomicAdd(&d.c->sum_n, (unsigned long long)n);
-        atomicAdd(&d.c->sum_lags, (unsigned long long)Kp);
-        atomicAdd(&d.c->sum_span, (unsigned long long)span);
-    }
-    __syncthreads();
-    const unsigned long long cbase = *(unsigned long long *)&misc[4];
-    const bool ovf = misc[2] != 0;
-    if (!ovf) {
+            __syncthreads();
+            for (int k = tid; k < P; k += NT) lagk[k] = (uint16_t)k;
+            __syncthreads();
+        }
+        for (int rep_ = 0; rep_ < 1 + ((d.rep >> 1) & 1); rep_++)
+            for (int k2 = 2; k2 <= P; k2 <<= 1) {
+                for (int j = k2 >> 1; j > 0; j >>= 1) {
+                    for (int i = tid; i < P; i += NT) {
+                        int ixj = i ^ j;
+                        if (ixj > i) {
+                            double va = keyv[i], vb = keyv[ixj];
+                            uint16_t la = lagk[i], lb = lagk[ixj];
+                            bool a_first = (va > vb) || (va == vb && la > lb);
+                            bool up = (i & k2) == 0;
+                            if (up ? !a_first : a_first) {
+                                keyv[i] = vb; keyv[ixj] = va;
+                                lagk[i] = lb; lagk[ixj] = la;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
         for (int r = tid; r < Kp; r += NT) {
-            if (!keep[r]) continue;
-            int my = dd[r], rank = 0;
-            for (int q = 0; q < Kp; q++)
-                if (keep[q] && (dd[q] < my || (dd[q] == my && q < r))) rank++;
-            int mi = wmi[r], mj = wmj[r], nb = wnb[r];
-            uint64_t h1 = 0, h2 = 0;
-            for (int t = 0; t < nb; t++) {
-                uint64_t a, b;
-                pair_hash(pos[mi - t], pos[mj + t], &a, &b);
-                h1 += a; h2 += b;
-            }
-            Cand cd;
-            cd.ddcal = my; cd.mi = (uint16_t)mi; cd.mj = (uint16_t)mj; cd.nb = (uint16_t)nb; cd.pad = 0; cd.pad2 = 0;
-            cd.h1 = h1; cd.h2 = h2;
-            d.cand[cbase + rank] = cd;
-            if (d.dbg.kept) d.dbg.kept[rank] = r;
+            rk[r] = lagk[r];
+            if (d.dbg.lag) { d.dbg.lag[r] = lagk[r]; d.dbg.corval[r] = keyv[r]; }
         }
-    }
-    if (tid == 0) {
-        d.nd_cand[nid] = cbase;
-        d.nd_ncand[nid] = ovf ? 0 : nkept;
-        if (d.dbg.n_ranked) d.dbg.n_ranked[1] = nkept;
+        if (tid == 0 && d.dbg.n_ranked) *d.dbg.n_ranked = Kp;
+        __syncthreads();
+
+        // ---- window_slide, one lane per ranked lag (rafft/rafft.py:36-83)
+        for (int rep_ = 0; rep_ < 1 + ((d.rep >> 2) & 1); rep_++)
+            for (int r = tid; r < Kp; r += NT) {
+                const int lagp = rk[r];
+                const int len = lagp < n ? lagp + 1 : 2 * n - lagp - 1;
+                const int len2 = (len >> 1) + (len & 1);
+                double prev = 0.0, mx_s = 0.0;
+                int tmp = 0, mx_nb = 0, mx_i = 0, mx_j = 0;
+                for (int i = 0; i < len2; i++) {
+                    int ip, jp;
+                    if (lagp < n) { ip = i; jp = lagp - i; }
+                    else { ip = lagp - n + 1 + i; jp = n - i - 1; }
+                    double t = wtab[code[ip] * 5 + code[jp]];
+                    if (i > 0 && (int)pos[ip] - (int)pos[ip - 1] == 1 && (int)pos[jp + 1] - (int)pos[jp] == 1)
+                        t = (prev + t) * t;
+                    tmp = (t == 0.0) ? 0 : tmp + 1;
+                    if (t >= mx_s && (int)pos[jp] - (int)pos[ip] > d.min_hp) {
+                        mx_s = t; mx_nb = tmp; mx_i = ip; mx_j = jp;
+                    }
+                    prev = t;
+                }
+                wnb[r] = (uint16_t)mx_nb; wmi[r] = (uint16_t)mx_i; wmj[r] = (uint16_t)mx_j;
+                if (d.dbg.nb) { d.dbg.nb[r] = mx_nb; d.dbg.mi[r] = mx_i; d.dbg.mj[r] = mx_j; d.dbg.score[r] = mx_s; }
+            }
+        __syncthreads();
+
+        // ---- dE of every candidate stem: only the loops it changes, from the branch list
+        const int par_dcal = d.nd_pdcal[nid];
+        const double par_e = dcal_to_energy(par_dcal);
+        for (int rep_ = 0; rep_ < 1 + ((d.rep >> 3) & 1); rep_++)
+            for (int r = tid; r < Kp; r += NT) {
+                const int nb = wnb[r];
+                keep[r] = 0;
+                dd[r] = 0;
+                if (nb > 0) {
+                    const int mi = wmi[r], mj = wmj[r];
+                    const int a0 = pos[mi], b0 = pos[mj], ao = pos[mi - nb + 1], bo = pos[mj + nb - 1];
+                    BrList all{brl, 0, nbr, 0, 0, 0, 0, 0};
+                    const int e_old = loop_energy_br(T, Sl, L, ci, cj, all);
+                    int lo = br_lower(brl, nbr, a0), hi = br_lower(brl, nbr, b0);
+                    const int lo_o = br_lower(brl, nbr, ao), hi_o = br_lower(brl, nbr, bo);
+                    BrList outer{brl, 0, lo_o, hi_o, nbr, 1, ao, bo};
+                    int e_new = loop_energy_br(T, Sl, L, ci, cj, outer);
+                    BrList inner{brl, lo, hi, 0, 0, 0, 0, 0};
+                    e_new += loop_energy_br(T, Sl, L, a0, b0, inner);
+                    int pa = a0, pb = b0;
+                    for (int t = 1; t < nb; t++) {
+                        const int a = pos[mi - t], b = pos[mj + t];
+                        if (pa == a + 1 && pb == b - 1)
+                            e_new += T->stack[pair_type(Sl[a], Sl[b])][kRtype[pair_type(Sl[pa], Sl[pb])]];
+                        else {
+                            const int lo2 = br_lower(brl, nbr, a), hi2 = br_lower(brl, nbr, b);
+                            BrList mid{brl, lo2, lo, hi, hi2, 1, pa, pb};
+                            e_new += loop_energy_br(T, Sl, L, a, b, mid);
+                            lo = lo2; hi = hi2;
+                        }
+                        pa = a; pb = b;
+                    }
+                    const int ddc = e_new - e_old;
+                    dd[r] = ddc;
+                    const double dE = dcal_to_energy(par_dcal + ddc) - par_e;
+                    keep[r] = (dE < d.min_nrj) ? 1 : 0;
+                    if (d.dbg.ddcal) d.dbg.ddcal[r] = ddc;
+                } else if (d.dbg.ddcal)
+                    d.dbg.ddcal[r] = INT_MIN;
+            }
+        __syncthreads();
+
+        // ---- stable sort of the kept candidates by dE (ties keep lag-rank order), emit
+        int nkept = 0;
+        for (int r = 0; r < Kp; r++) nkept += keep[r];   // LDS broadcast reads
+        if (tid == 0) {
+            unsigned long long base = 0;
+            misc[2] = 0;
+            if (nkept) {
+                base = atomicAdd(&d.c->cand_top, (unsigned long long)nkept);
+                if (base + nkept > d.cand_cap) { atomicOr(&d.c->overflow, OVF_CAND); base = 0; misc[2] = 1; }
+            }
+            *(unsigned long long *)&misc[4] = base;
+            atomicAdd(&d.c->n_expand, 1ULL);
+            atomicAdd(&d.c->sum_n, (unsigned long long)n);
+            atomicAdd(&d.c->sum_lags, (unsigned long long)Kp);
+            atomicAdd(&d.c->sum_nbr, (unsigned long long)nbr);
+        }
+        __syncthreads();
+        const unsigned long long cbase = *(unsigned long long *)&misc[4];
+        const bool ovf = misc[2] != 0;
+        if (!ovf) {
+            for (int r = tid; r < Kp; r += NT) {
+                if (!keep[r]) continue;
+                int my = dd[r], rank = 0;
+                for (int q = 0; q < Kp; q++)
+                    if (keep[q] && (dd[q] < my || (dd[q] == my && q < r))) rank++;
+                int mi = wmi[r], mj = wmj[r], nb = wnb[r];
+                uint64_t h1 = 0, h2 = 0;
+                for (int t = 0; t < nb; t++) {
+                    uint64_t a, b;
+                    pair_hash(pos[mi - t], pos[mj + t], &a, &b);
+                    h1 += a; h2 += b;
+                }
+                Cand cd;
+                cd.ddcal = my; cd.mi = (uint16_t)mi; cd.mj = (uint16_t)mj; cd.nb = (uint16_t)nb; cd.pad = 0; cd.pad2 = 0;
+                cd.h1 = h1; cd.h2 = h2;
+                d.cand[cbase + rank] = cd;
+                if (d.dbg.kept) d.dbg.kept[rank] = r;
+            }
+        }
+        if (tid == 0) {
+            d.nd_cand[nid] = cbase;
+            d.nd_ncand[nid] = ovf ? 0 : nkept;
+            if (d.dbg.n_ranked) d.dbg.n_ranked[1] = nkept;
+        }
     }
 }
 
@@ -426,11 +412,12 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
         int mprod = 0;
         for (int base = 0; base < nn; base += BS_NT) {
             int i = base + tid, cnt = 0;
-            if (i < nn) cnt = d.nd_ncand[node0 + i];
+            int cn = 0;
+            if (i < nn) { cn = d.nd_canon[node0 + i]; cnt = d.nd_ncand[cn]; }
             int tot, ex = block_exscan<BS_NT>(cnt > 0 ? 1 : 0, sh, &tot);
             if (cnt > 0 && mprod + ex < MAX_PROD) {
                 prod_cnt[mprod + ex] = cnt;
-                prod_off[mprod + ex] = d.nd_cand[node0 + i];
+                prod_off[mprod + ex] = d.nd_cand[cn];
             }
             mprod += tot;
             __syncthreads();
@@ -631,12 +618,18 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
 // ------------------------------------------------------- materialize kernel
 
 #define MAT_NT 64
+// One wavefront per new beam member.  Child regions are spliced from the parent's
+// regions: inner = positions/branches strictly inside the innermost stem pair, outer =
+// the rest of the parent's loop with the whole stem as one new branch.
 __global__ __launch_bounds__(MAT_NT) void materialize_kernel(Dev d)
 {
-    __shared__ int16_t spt[RAFFT_MAX_LEN];
+    __shared__ uint8_t sdb[RAFFT_MAX_LEN];
     __shared__ int prod_node[MAX_PROD];
     __shared__ int prod_cnt[MAX_PROD];
     __shared__ int sel[MAX_PROD];
+    // per-tile descriptors (one lane per productive region)
+    __shared__ int k_mi[64], k_mj[64], k_nb[64], k_lo0[64], k_hi0[64], k_loo[64], k_hio[64], k_flags[64];
+    __shared__ int k_node[64], k_pos[64], k_br[64];
     __shared__ unsigned long long sh64[4];
     __shared__ int shi[8];
     const int tid = threadIdx.x;
@@ -644,122 +637,231 @@ __global__ __launch_bounds__(MAT_NT) void materialize_kernel(Dev d)
     const int par = d.st_parent[sid];
     const int sq = d.st_seq[sid];
     const int L = d.seq_len[sq];
+    const int my_dcal = d.st_dcal[sid];
     const int node0 = d.st_node0[par], nn = d.st_nnodes[par];
     int mprod = 0;
     for (int base = 0; base < nn; base += MAT_NT) {
-        int i = base + tid, cnt = 0;
-        if (i < nn) cnt = d.nd_ncand[node0 + i];
+        int i = base + tid, cnt = 0, cn = 0;
+        if (i < nn) { cn = d.nd_canon[node0 + i]; cnt = d.nd_ncand[cn]; }
         unsigned long long bal = __ballot(cnt > 0);
         int ex = __popcll(bal & ((1ULL << tid) - 1));
-        if (cnt > 0 && mprod + ex < MAX_PROD) { prod_node[mprod + ex] = node0 + i; prod_cnt[mprod + ex] = cnt; }
+        if (cnt > 0 && mprod + ex < MAX_PROD) { prod_node[mprod + ex] = cn; prod_cnt[mprod + ex] = cnt; }
         mprod += __popcll(bal);
     }
     if (mprod > MAX_PROD) mprod = MAX_PROD;
     __syncthreads();
     if (tid == 0) {
         unsigned long long idx = d.st_combo[sid];
-        int nnew = 0, npos = 0;
         for (int k = mprod - 1; k >= 0; k--) {
             unsigned long long c = (unsigned long long)prod_cnt[k], q = idx / c;
             sel[k] = (int)(idx - q * c);
             idx = q;
         }
-        for (int k = 0; k < mprod; k++) {
-            const Cand cd = d.cand[d.nd_cand[prod_node[k]] + sel[k]];
-            int n = d.nd_n[prod_node[k]];
-            int mi = cd.mi, mj = cd.mj, nb = cd.nb;
-            if (mj - mi > 1) { nnew++; npos += mj - mi - 1; }
-            if (mi - (nb - 1) > 0 || mj + nb < n) { nnew++; npos += (mi - nb + 1) + (n - (mj + nb)); }
+    }
+    __syncthreads();
+
+    // pass 1: sizes
+    int tot_nodes = 0, tot_pos = 0, tot_br = 0;
+    for (int base = 0; base < mprod; base += MAT_NT) {
+        int k = base + tid, nnod = 0, npos = 0, nbrr = 0;
+        if (k < mprod) {
+            const int pn = prod_node[k];
+            const Cand cd = d.cand[d.nd_cand[pn] + sel[k]];
+            const int n = d.nd_n[pn], nbr = d.nd_nbr[pn];
+            const uint16_t *pp = d.pos + d.nd_pos[pn];
+            const uint32_t *bb = d.br + d.nd_br[pn];
+            const int mi = cd.mi, mj = cd.mj, nb = cd.nb;
+            if (mj - mi > 1) {
+                nnod++; npos += mj - mi - 1;
+                nbrr += br_lower(bb, nbr, pp[mj]) - br_lower(bb, nbr, pp[mi]);
+            }
+            if (mi - (nb - 1) > 0 || mj + nb < n) {
+                nnod++; npos += (mi - nb + 1) + (n - (mj + nb));
+                nbrr += br_lower(bb, nbr, pp[mi - nb + 1]) + 1 + (nbr - br_lower(bb, nbr, pp[mj + nb - 1]));
+            }
         }
-        unsigned long long nb0 = atomicAdd(&d.c->n_node, (unsigned long long)nnew);
-        unsigned long long pb0 = atomicAdd(&d.c->pos_top, (unsigned long long)npos);
-        unsigned long long tb0 = atomicAdd(&d.c->pt_top, (unsigned long long)L);
+        for (int o = 32; o > 0; o >>= 1) {
+            nnod += __shfl_xor(nnod, o, 64); npos += __shfl_xor(npos, o, 64); nbrr += __shfl_xor(nbrr, o, 64);
+        }
+        tot_nodes += nnod; tot_pos += npos; tot_br += nbrr;
+    }
+    if (tid == 0) {
+        unsigned long long nb0 = atomicAdd(&d.c->n_node, (unsigned long long)tot_nodes);
+        unsigned long long pb0 = atomicAdd(&d.c->pos_top, (unsigned long long)tot_pos);
+        unsigned long long bb0 = atomicAdd(&d.c->br_top, (unsigned long long)tot_br);
+        unsigned long long tb0 = atomicAdd(&d.c->db_top, (unsigned long long)L);
+        unsigned int nw0 = atomicAdd(&d.c->n_new, (unsigned int)tot_nodes);
         int ok = 1;
-        if (nb0 + nnew > d.nd_cap) { atomicOr(&d.c->overflow, OVF_NODE); ok = 0; }
-        if (pb0 + npos > d.pos_cap) { atomicOr(&d.c->overflow, OVF_POS); ok = 0; }
-        if (tb0 + L > d.pt_cap) { atomicOr(&d.c->overflow, OVF_PT); ok = 0; }
-        sh64[0] = nb0; sh64[1] = pb0; sh64[2] = tb0;
-        shi[0] = ok; shi[1] = nnew;
+        if (nb0 + tot_nodes > d.nd_cap) { atomicOr(&d.c->overflow, OVF_NODE); ok = 0; }
+        if (pb0 + tot_pos > d.pos_cap) { atomicOr(&d.c->overflow, OVF_POS); ok = 0; }
+        if (bb0 + tot_br > d.br_cap) { atomicOr(&d.c->overflow, OVF_BR); ok = 0; }
+        if (tb0 + L > d.db_cap) { atomicOr(&d.c->overflow, OVF_DB); ok = 0; }
+        if (nw0 + tot_nodes > d.new_cap) { atomicOr(&d.c->overflow, OVF_WORK); ok = 0; }
+        sh64[0] = nb0; sh64[1] = pb0; sh64[2] = tb0; sh64[3] = bb0;
+        shi[0] = ok; shi[1] = (int)nw0;
         atomicAdd(&d.c->sum_struct_len, (unsigned long long)L);
     }
     __syncthreads();
-    if (!shi[0]) { if (tid == 0) { d.st_nnodes[sid] = 0; d.st_node0[sid] = 0; d.st_pt[sid] = 0; } return; }
-    const unsigned long long nbase = sh64[0], pbase = sh64[1], tbase = sh64[2];
-    const int16_t *ppt = d.pt + d.st_pt[par];
-    for (int x = tid; x < L; x += MAT_NT) spt[x] = ppt[x];
+    if (!shi[0]) { if (tid == 0) { d.st_nnodes[sid] = 0; d.st_node0[sid] = 0; d.st_db[sid] = 0; } return; }
+    const unsigned long long nbase = sh64[0], pbase = sh64[1], tbase = sh64[2], bbase = sh64[3];
+    const int nwbase = shi[1];
+
+    // dot-bracket row: parent's row + the stems (rafft/rafft.py:97,127-128)
+    const uint8_t *pdb = d.db + d.st_db[par];
+    for (int x = tid; x < L; x += MAT_NT) sdb[x] = pdb[x];
     __syncthreads();
-    // stems -> pair table (rafft/rafft.py:97,127-128)
-    for (int k = 0; k < mprod; k++) {
-        const Cand cd = d.cand[d.nd_cand[prod_node[k]] + sel[k]];
-        const uint16_t *pp = d.pos + d.nd_pos[prod_node[k]];
-        for (int t = tid; t < cd.nb; t += MAT_NT) {
-            int a = pp[cd.mi - t], b = pp[cd.mj + t];
-            spt[a] = (int16_t)b; spt[b] = (int16_t)a;
+
+    // pass 2: per tile descriptors, prefix, copy
+    int run_nodes = 0, run_pos = 0, run_br = 0;
+    for (int base = 0; base < mprod; base += MAT_NT) {
+        const int k = base + tid;
+        int nnod = 0, npos = 0, nbrr = 0, flags = 0;
+        if (k < mprod) {
+            const int pn = prod_node[k];
+            const Cand cd = d.cand[d.nd_cand[pn] + sel[k]];
+            const int n = d.nd_n[pn], nbr = d.nd_nbr[pn];
+            const uint16_t *pp = d.pos + d.nd_pos[pn];
+            const uint32_t *bb = d.br + d.nd_br[pn];
+            const int mi = cd.mi, mj = cd.mj, nb = cd.nb;
+            k_mi[tid] = mi; k_mj[tid] = mj; k_nb[tid] = nb;
+            const int lo0 = br_lower(bb, nbr, pp[mi]), hi0 = br_lower(bb, nbr, pp[mj]);
+            const int loo = br_lower(bb, nbr, pp[mi - nb + 1]), hio = br_lower(bb, nbr, pp[mj + nb - 1]);
+            k_lo0[tid] = lo0; k_hi0[tid] = hi0; k_loo[tid] = loo; k_hio[tid] = hio;
+            if (mj - mi > 1) { flags |= 1; nnod++; npos += mj - mi - 1; nbrr += hi0 - lo0; }
+            if (mi - (nb - 1) > 0 || mj + nb < n) { flags |= 2; nnod++; npos += (mi - nb + 1) + (n - (mj + nb)); nbrr += loo + 1 + (nbr - hio); }
+            k_flags[tid] = flags;
+        }
+        // exclusive scans over the tile
+        int xn = nnod, xp = npos, xb = nbrr;
+        for (int o = 1; o < 64; o <<= 1) {
+            int yn = __shfl_up(xn, o, 64), yp = __shfl_up(xp, o, 64), yb = __shfl_up(xb, o, 64);
+            if (tid >= o) { xn += yn; xp += yp; xb += yb; }
+        }
+        const int tn = __shfl(xn, 63, 64), tp = __shfl(xp, 63, 64), tb = __shfl(xb, 63, 64);
+        k_node[tid] = run_nodes + xn - nnod; k_pos[tid] = run_pos + xp - npos; k_br[tid] = run_br + xb - nbrr;
+        __syncthreads();
+        const int kt = mprod - base < MAT_NT ? mprod - base : MAT_NT;
+        for (int kk = 0; kk < kt; kk++) {
+            const int pn = prod_node[base + kk];
+            const int n = d.nd_n[pn], nbr = d.nd_nbr[pn], pci = d.nd_ci[pn], pcj = d.nd_cj[pn];
+            const uint16_t *pp = d.pos + d.nd_pos[pn];
+            const uint32_t *bb = d.br + d.nd_br[pn];
+            const int mi = k_mi[kk], mj = k_mj[kk], nb = k_nb[kk], fl = k_flags[kk];
+            int nidx = k_node[kk];
+            unsigned long long poff = pbase + k_pos[kk], boff = bbase + k_br[kk];
+            for (int t = tid; t < nb; t += MAT_NT) { sdb[pp[mi - t]] = '('; sdb[pp[mj + t]] = ')'; }
+            if (fl & 1) {     // inner region (rafft/utils.py:148-152)
+                const int len = mj - mi - 1, lo0 = k_lo0[kk], nb_in = k_hi0[kk] - lo0;
+                for (int t = tid; t < len; t += MAT_NT) d.pos[poff + t] = pp[mi + 1 + t];
+                for (int t = tid; t < nb_in; t += MAT_NT) d.br[boff + t] = bb[lo0 + t];
+                if (tid == 0) {
+                    const int nid = (int)(nbase + nidx);
+                    d.nd_seq[nid] = sq; d.nd_pdcal[nid] = my_dcal; d.nd_pos[nid] = poff; d.nd_n[nid] = len;
+                    d.nd_ci[nid] = pp[mi]; d.nd_cj[nid] = pp[mj]; d.nd_br[nid] = boff; d.nd_nbr[nid] = nb_in;
+                    d.nd_ncand[nid] = -1; d.nd_cand[nid] = 0; d.nd_canon[nid] = nid;
+                    d.newnodes[nwbase + nidx] = nid;
+                }
+                nidx++; poff += len; boff += nb_in;
+            }
+            if (fl & 2) {     // outer region (rafft/utils.py:141-145)
+                const int left = mi - nb + 1, right = mj + nb, len = left + (n - right);
+                const int loo = k_loo[kk], hio = k_hio[kk], nb_out = loo + 1 + (nbr - hio);
+                for (int t = tid; t < len; t += MAT_NT) d.pos[poff + t] = t < left ? pp[t] : pp[right + (t - left)];
+                for (int t = tid; t < nb_out; t += MAT_NT) {
+                    uint32_t v;
+                    if (t < loo) v = bb[t];
+                    else if (t == loo) v = (uint32_t)pp[mi - nb + 1] | ((uint32_t)pp[mj + nb - 1] << 16);
+                    else v = bb[hio + (t - loo - 1)];
+                    d.br[boff + t] = v;
+                }
+                if (tid == 0) {
+                    const int nid = (int)(nbase + nidx);
+                    d.nd_seq[nid] = sq; d.nd_pdcal[nid] = my_dcal; d.nd_pos[nid] = poff; d.nd_n[nid] = len;
+                    d.nd_ci[nid] = pci; d.nd_cj[nid] = pcj; d.nd_br[nid] = boff; d.nd_nbr[nid] = nb_out;
+                    d.nd_ncand[nid] = -1; d.nd_cand[nid] = 0; d.nd_canon[nid] = nid;
+                    d.newnodes[nwbase + nidx] = nid;
+                }
+            }
+        }
+        run_nodes += tn; run_pos += tp; run_br += tb;
+        __syncthreads();
+    }
+    uint8_t *odb = d.db + tbase;
+    for (int x = tid; x < L; x += MAT_NT) odb[x] = sdb[x];
+    if (tid == 0) { d.st_node0[sid] = (int)nbase; d.st_nnodes[sid] = tot_nodes; d.st_db[sid] = tbase; }
+}
+
+// ------------------------------------------------------------ dedupe kernel
+
+__device__ inline bool same_loop(const Dev &d, int a, int b)
+{
+    if (d.nd_seq[a] != d.nd_seq[b] || d.nd_ci[a] != d.nd_ci[b] || d.nd_cj[a] != d.nd_cj[b] ||
+        d.nd_nbr[a] != d.nd_nbr[b] || d.nd_n[a] != d.nd_n[b]) return false;
+    const uint32_t *x = d.br + d.nd_br[a], *y = d.br + d.nd_br[b];
+    for (int i = 0, k = d.nd_nbr[a]; i < k; i++)
+        if (x[i] != y[i]) return false;
+    return true;
+}
+
+// One thread per region created in this step.  The first region to claim a loop key
+// becomes canonical and goes to the expand work list; later identical loops alias it.
+__global__ void dedupe_kernel(Dev d)
+{
+    const unsigned n_new = d.c->n_new;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n_new; i += gridDim.x * blockDim.x) {
+        const int nid = d.newnodes[i];
+        int canon = nid;
+        if (d.memo) {
+            const uint32_t *bb = d.br + d.nd_br[nid];
+            const int nbr = d.nd_nbr[nid];
+            uint64_t h = mix64(((uint64_t)(uint32_t)d.nd_seq[nid] << 32) ^ ((uint64_t)(uint32_t)(d.nd_ci[nid] + 1) << 16) ^ (uint32_t)d.nd_cj[nid]);
+            for (int t = 0; t < nbr; t++) h += mix64((uint64_t)bb[t] ^ 0x5bd1e9955bd1e995ULL);
+            const unsigned long long tag = (h >> 32) | 0x80000000ULL;
+            const uint64_t mask = d.looptab_cap - 1;
+            uint64_t sl = h & mask;
+            for (unsigned probe = 0;; probe++) {
+                unsigned long long old = atomicCAS(&d.looptab[sl], 0ULL, (tag << 32) | (unsigned long long)(nid + 1));
+                if (old == 0) break;
+                if ((old >> 32) == tag) {
+                    int other = (int)(old & 0xffffffffULL) - 1;
+                    if (same_loop(d, nid, other)) { canon = other; break; }
+                }
+                sl = (sl + 1) & mask;
+                if (probe > d.looptab_cap) { atomicOr(&d.c->overflow, OVF_LOOPTAB); break; }
+            }
+        }
+        if (canon == nid) {
+            int cls = node_class(d.nd_n[nid], d.seq_len[d.nd_seq[nid]], d.nd_nbr[nid]);
+            unsigned int w = atomicAdd(&d.c->n_work[cls], 1u);
+            if (w < d.work_cap) d.work[cls][w] = nid; else atomicOr(&d.c->overflow, OVF_WORK);
+        } else {
+            d.nd_canon[nid] = canon;
+            atomicAdd(&d.c->n_alias, 1ULL);
         }
     }
-    __syncthreads();
-    int16_t *opt = d.pt + tbase;
-    for (int x = tid; x < L; x += MAT_NT) opt[x] = spt[x];
-    // child nodes: for each helix in combo order inner, then outer (rafft/rafft.py:187-190)
-    int nidx = 0;
-    unsigned long long poff = pbase;
-    for (int k = 0; k < mprod; k++) {
-        const int pn = prod_node[k];
-        const Cand cd = d.cand[d.nd_cand[pn] + sel[k]];
-        const uint16_t *pp = d.pos + d.nd_pos[pn];
-        const int n = d.nd_n[pn], pci = d.nd_ci[pn], pcj = d.nd_cj[pn];
-        const int mi = cd.mi, mj = cd.mj, nb = cd.nb;
-        if (mj - mi > 1) {     // inner loop (rafft/utils.py:148-152)
-            int len = mj - mi - 1;
-            for (int t = tid; t < len; t += MAT_NT) d.pos[poff + t] = pp[mi + 1 + t];
-            if (tid == 0) {
-                int nid = (int)(nbase + nidx);
-                int ci = pp[mi], cj = pp[mj];
-                d.nd_sid[nid] = sid; d.nd_pos[nid] = poff; d.nd_n[nid] = len;
-                d.nd_ci[nid] = ci; d.nd_cj[nid] = cj; d.nd_ncand[nid] = -1; d.nd_cand[nid] = 0;
-                int cls = node_class(len, cj - ci + 1);
-                unsigned int w = atomicAdd(&d.c->n_work[cls], 1u);
-                if (w < d.work_cap) d.work[cls][w] = nid; else atomicOr(&d.c->overflow, OVF_WORK);
-            }
-            nidx++; poff += len;
-        }
-        if (mi - (nb - 1) > 0 || mj + nb < n) {   // outer loop (rafft/utils.py:141-145)
-            int left = mi - nb + 1, right = mj + nb, len = left + (n - right);
-            for (int t = tid; t < len; t += MAT_NT) d.pos[poff + t] = t < left ? pp[t] : pp[right + (t - left)];
-            if (tid == 0) {
-                int nid = (int)(nbase + nidx);
-                d.nd_sid[nid] = sid; d.nd_pos[nid] = poff; d.nd_n[nid] = len;
-                d.nd_ci[nid] = pci; d.nd_cj[nid] = pcj; d.nd_ncand[nid] = -1; d.nd_cand[nid] = 0;
-                int cls = node_class(len, pci < 0 ? L : pcj - pci + 1);
-                unsigned int w = atomicAdd(&d.c->n_work[cls], 1u);
-                if (w < d.work_cap) d.work[cls][w] = nid; else atomicOr(&d.c->overflow, OVF_WORK);
-            }
-            nidx++; poff += len;
-        }
-    }
-    if (tid == 0) { d.st_node0[sid] = (int)nbase; d.st_nnodes[sid] = shi[1]; d.st_pt[sid] = tbase; }
 }
 
 // ------------------------------------------------------------- init kernel
 
-__global__ void init_roots_kernel(Dev d, const int *root_pt_off)
+__global__ void init_roots_kernel(Dev d)
 {
     const int sq = blockIdx.x, tid = threadIdx.x;
     const int L = d.seq_len[sq];
-    // structure sq / node sq are the unfolded structure and its single node (rafft.py:224-231)
-    const unsigned long long off = (unsigned long long)root_pt_off[sq];
-    for (int x = tid; x < L; x += blockDim.x) { d.pt[off + x] = -1; d.pos[off + x] = (uint16_t)x; }
+    // structure sq / node sq are the unfolded structure and its single region (rafft.py:224-231)
+    const unsigned long long off = (unsigned long long)d.seq_off[sq];
+    for (int x = tid; x < L; x += blockDim.x) { d.db[off + x] = '.'; d.pos[off + x] = (uint16_t)x; }
     if (tid == 0) {
         d.st_seq[sq] = sq; d.st_dcal[sq] = 0; d.st_h[2 * (size_t)sq] = 0; d.st_h[2 * (size_t)sq + 1] = 0;
-        d.st_pt[sq] = off; d.st_node0[sq] = sq; d.st_nnodes[sq] = L > 0 ? 1 : 0; d.st_cursor[sq] = 0;
+        d.st_db[sq] = off; d.st_node0[sq] = sq; d.st_nnodes[sq] = L > 0 ? 1 : 0; d.st_cursor[sq] = 0;
         d.st_parent[sq] = -1; d.st_combo[sq] = 0;
-        d.nd_sid[sq] = sq; d.nd_pos[sq] = off; d.nd_n[sq] = L; d.nd_ci[sq] = -1; d.nd_cj[sq] = L;
+        d.nd_seq[sq] = sq; d.nd_pdcal[sq] = 0; d.nd_pos[sq] = off; d.nd_n[sq] = L; d.nd_ci[sq] = -1; d.nd_cj[sq] = L;
+        d.nd_br[sq] = 0; d.nd_nbr[sq] = 0; d.nd_canon[sq] = sq;
         d.nd_ncand[sq] = -1; d.nd_cand[sq] = 0;
         d.beam[(size_t)sq * d.B] = sq; d.beam_n[sq] = 1; d.nsteps[sq] = 0;
         d.done[sq] = L > 0 ? 0 : 1;
         d.seen_off[sq] = (uint64_t)sq * 1024; d.seen_cap[sq] = 1024; d.seen_cnt[sq] = 0;
         if (L > 0) {
-            int cls = node_class(L, L);
+            int cls = node_class(L, L, 0);
             unsigned int w = atomicAdd(&d.c->n_work[cls], 1u);
             d.work[cls][w] = sq;
         }
@@ -773,12 +875,9 @@ __global__ void output_kernel(Dev d, int nrows, const int *row_sid, const long l
     for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
         const int sid = row_sid[r];
         const int L = d.seq_len[d.st_seq[sid]];
-        const int16_t *pt = d.pt + d.st_pt[sid];
+        const uint8_t *db = d.db + d.st_db[sid];
         char *o = out_db + row_off[r];
-        for (int x = threadIdx.x; x < L; x += blockDim.x) {
-            int q = pt[x];
-            o[x] = q < 0 ? '.' : (q > x ? '(' : ')');
-        }
+        for (int x = threadIdx.x; x < L; x += blockDim.x) o[x] = (char)db[x];
         if (threadIdx.x == 0) { o[L] = 0; out_dcal[r] = d.st_dcal[sid]; }
     }
 }
