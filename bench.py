@@ -50,7 +50,8 @@ def cpu_baseline(seqs, n, ms, mb, budget_s=20.0):
     import multiprocessing as mp
     import oracle
     oracle.oracle.build()
-    cores = os.cpu_count() or 1
+    # the GPU box exposes many logical CPUs but a job owns a 16-core share: never oversubscribe it
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
     # sample: every k-th sequence of the same workload, sized from a short probe
     t0 = time.time()
     probe = seqs[::97][:16]

@@ -57,7 +57,7 @@ struct Ctx {
     std::vector<Buf *> bufs;
     // named workspace buffers (grow-only)
     Buf codes, seq_off, seq_len, beam, beam_n, done, nsteps, ch_parent, ch_combo, ch_dcal, ch_h, seen, seen_off,
-        seen_cap, seen_cnt, st_seq, st_dcal, st_node0, st_nnodes, st_parent, st_h, st_db, st_cursor, st_combo, nd_seq, nd_pdcal,
+        seen_cap, seen_cnt, st_seq, st_dcal, st_node0, st_nnodes, st_parent, st_h, st_db, st_cursor, st_combo, st_total, nd_seq, nd_pdcal,
         nd_n, nd_ci, nd_cj, nd_nbr, nd_canon, nd_ncand, nd_pos, nd_br, nd_cand, pos, br, db, cand, looptab, trec, tsid,
         work0, work1, work2, mat, newnodes, counters,
         row_sid, row_off, out_db, out_dcal, dbg;
@@ -281,7 +281,7 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
     ENS(ch_parent, S * c.ch_cap * 2); ENS(ch_combo, S * c.ch_cap * 8); ENS(ch_dcal, S * c.ch_cap * 4); ENS(ch_h, S * c.ch_cap * 16);
     ENS(seen, c.seen * 16); ENS(seen_off, S * 8); ENS(seen_cap, S * 4); ENS(seen_cnt, S * 4);
     ENS(st_seq, c.st * 4); ENS(st_dcal, c.st * 4); ENS(st_node0, c.st * 4); ENS(st_nnodes, c.st * 4); ENS(st_parent, c.st * 4);
-    ENS(st_h, c.st * 16); ENS(st_db, c.st * 8); ENS(st_cursor, c.st * 8); ENS(st_combo, c.st * 8);
+    ENS(st_h, c.st * 16); ENS(st_db, c.st * 8); ENS(st_cursor, c.st * 8); ENS(st_combo, c.st * 8); ENS(st_total, c.st * 8);
     ENS(nd_seq, c.nd * 4); ENS(nd_pdcal, c.nd * 4); ENS(nd_n, c.nd * 4); ENS(nd_ci, c.nd * 4); ENS(nd_cj, c.nd * 4);
     ENS(nd_nbr, c.nd * 4); ENS(nd_canon, c.nd * 4); ENS(nd_ncand, c.nd * 4);
     ENS(nd_pos, c.nd * 8); ENS(nd_br, c.nd * 8); ENS(nd_cand, c.nd * 8);
@@ -310,7 +310,7 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
     d.st_cap = (uint32_t)c.st;
     d.st_seq = (int *)g.st_seq.p; d.st_dcal = (int *)g.st_dcal.p; d.st_node0 = (int *)g.st_node0.p; d.st_nnodes = (int *)g.st_nnodes.p;
     d.st_parent = (int *)g.st_parent.p; d.st_h = (uint64_t *)g.st_h.p; d.st_db = (uint64_t *)g.st_db.p;
-    d.st_cursor = (uint64_t *)g.st_cursor.p; d.st_combo = (uint64_t *)g.st_combo.p;
+    d.st_cursor = (uint64_t *)g.st_cursor.p; d.st_combo = (uint64_t *)g.st_combo.p; d.st_total = (uint64_t *)g.st_total.p;
     d.nd_cap = (uint32_t)c.nd;
     d.nd_seq = (int *)g.nd_seq.p; d.nd_pdcal = (int *)g.nd_pdcal.p; d.nd_n = (int *)g.nd_n.p; d.nd_ci = (int *)g.nd_ci.p;
     d.nd_cj = (int *)g.nd_cj.p; d.nd_nbr = (int *)g.nd_nbr.p; d.nd_canon = (int *)g.nd_canon.p; d.nd_ncand = (int *)g.nd_ncand.p;
@@ -418,7 +418,7 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
     g.stats.n_steps = std::max<int64_t>(g.stats.n_steps, steps);
     if (*ovf_bits) {
         if (*ovf_bits & (OVF_PROD | OVF_SORT))
-            return fail(RAFFT_ERR_PARAM, "structure with more than 1024 productive regions or sort capacity exceeded");
+            return fail(RAFFT_ERR_PARAM, "structure with more than 512 productive regions or sort capacity exceeded");
         return RAFFT_ERR_CAPACITY;
     }
     // statistics (SURVEY.md 8d algorithmic bytes; only expansions the kernels really executed)

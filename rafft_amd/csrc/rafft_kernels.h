@@ -69,7 +69,7 @@ struct Dev {
     // structures
     uint32_t st_cap;
     int *st_seq, *st_dcal, *st_node0, *st_nnodes, *st_parent;
-    uint64_t *st_h, *st_db, *st_cursor, *st_combo;
+    uint64_t *st_h, *st_db, *st_cursor, *st_combo, *st_total;
     // nodes
     uint32_t nd_cap;
     int *nd_seq, *nd_pdcal, *nd_n, *nd_ci, *nd_cj, *nd_nbr, *nd_canon, *nd_ncand;
@@ -100,7 +100,7 @@ struct Dev {
 #define CLS1_P 2048
 #define MAX_P 8192
 #define MAX_BR 1024
-#define MAX_PROD 1024
+#define MAX_PROD 512
 
 __host__ __device__ inline int next_pow2_ge(int x) { int p = 2; while (p < x) p <<= 1; return p; }
 __host__ __device__ inline int node_class(int n, int L, int nbr)

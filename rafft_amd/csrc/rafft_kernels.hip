@@ -408,6 +408,12 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
     for (int b = 0; b < nbeam; b++) {
         const int sid = oldbeam[b];
         const int node0 = d.st_node0[sid], nn = d.st_nnodes[sid];
+        {   // a parent whose product is exhausted, or that may only replay combo 0 which is
+            // already in `seen` (rafft/rafft.py:202-203), cannot produce anything: skip early
+            const unsigned long long cur0 = d.st_cursor[sid], tot0 = d.st_total[sid];
+            if (tot0 && cur0 >= tot0) continue;
+            if (nb_branch >= d.max_branch && cur0 > 0) continue;
+        }
         // productive nodes in node order (rafft/rafft.py:166-171)
         int mprod = 0;
         for (int base = 0; base < nn; base += BS_NT) {
@@ -423,7 +429,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
             __syncthreads();
         }
         if (mprod > MAX_PROD) { if (tid == 0) atomicOr(&d.c->overflow, OVF_PROD); mprod = MAX_PROD; }
-        if (mprod == 0) continue;
+        if (mprod == 0) { if (tid == 0) { d.st_total[sid] = 1; d.st_cursor[sid] = 1; } continue; }
         unsigned long long total = 1;
         for (int k = 0; k < mprod; k++) {
             unsigned long long c = (unsigned long long)prod_cnt[k];
@@ -521,7 +527,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
             __syncthreads();
             if (nb_branch >= d.max_branch) break;
         }
-        if (tid == 0) d.st_cursor[sid] = cur;
+        if (tid == 0) { d.st_cursor[sid] = cur; d.st_total[sid] = total; }
     }
     if (tid == 0) { d.seen_cnt[sq] = scnt; atomicAdd(&d.c->n_children, (unsigned long long)nchild); }
     if (nchild > d.ch_cap) nchild = d.ch_cap;
@@ -603,6 +609,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
                 d.st_parent[sid] = oldbeam[d.ch_parent[c]];
                 d.st_combo[sid] = d.ch_combo[c];
                 d.st_cursor[sid] = 0;
+                d.st_total[sid] = 0;
                 d.st_nnodes[sid] = 0;
                 d.mat[mbase + run + ex] = sid;
                 beam[i] = sid;
@@ -852,7 +859,7 @@ __global__ void init_roots_kernel(Dev d)
     for (int x = tid; x < L; x += blockDim.x) { d.db[off + x] = '.'; d.pos[off + x] = (uint16_t)x; }
     if (tid == 0) {
         d.st_seq[sq] = sq; d.st_dcal[sq] = 0; d.st_h[2 * (size_t)sq] = 0; d.st_h[2 * (size_t)sq + 1] = 0;
-        d.st_db[sq] = off; d.st_node0[sq] = sq; d.st_nnodes[sq] = L > 0 ? 1 : 0; d.st_cursor[sq] = 0;
+        d.st_db[sq] = off; d.st_node0[sq] = sq; d.st_nnodes[sq] = L > 0 ? 1 : 0; d.st_cursor[sq] = 0; d.st_total[sq] = 0;
         d.st_parent[sq] = -1; d.st_combo[sq] = 0;
         d.nd_seq[sq] = sq; d.nd_pdcal[sq] = 0; d.nd_pos[sq] = off; d.nd_n[sq] = L; d.nd_ci[sq] = -1; d.nd_cj[sq] = L;
         d.nd_br[sq] = 0; d.nd_nbr[sq] = 0; d.nd_canon[sq] = sq;

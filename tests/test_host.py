@@ -1,0 +1,138 @@
+"""CPU-only tests of the host side: C-ABI library loads and exports every declared symbol,
+the Python mirror of the reference interface, the CLI formats, LPT sharding and the
+world_size-2 gather path (gloo)."""
+import ctypes
+import io
+import os
+import re
+import subprocess
+import sys
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+
+import oracle
+import rafft_amd
+from rafft_amd import _native, cli, sharding, utils
+from conftest import GOLD, ROOT
+
+EX = "GGGUUUGCGGUGUAAGUGCAGCCCGUCUUACACCGUGCGGCACAGGCACUAGUACUGAUGUCGUAUACAGGGCUUUUGACAU"
+
+
+def test_cabi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "rafft_hip.h")).read()
+    declared = set(re.findall(r"\b(rafft_[a-z_]+)\s*\(", hdr))
+    assert declared == set(_native.EXPORTS), declared ^ set(_native.EXPORTS)
+    lib = _native.lib()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert b"gfx950" in lib.rafft_version()
+
+
+def test_struct_layouts_match_header():
+    assert ctypes.sizeof(_native.Params) == 4 * 4 + 8 + 4 + 4 + 8 + 3 * 8
+    assert ctypes.sizeof(_native.SeqResult) == 16 + 4 * 8
+    assert ctypes.sizeof(_native.Stats) == 8 * 8 + 12 * 8
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_native.RafftError) as e:
+        rafft_amd.fold("GGGAAACCC")
+    assert e.value.code == _native.ERR_NO_DEVICE
+
+
+def test_product_never_imports_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, "rafft_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")) and f != "turner2004_tables.h":
+                txt = open(os.path.join(root, f)).read()
+                assert "import oracle" not in txt and "liboracle" not in txt and "from oracle" not in txt, f
+
+
+def test_structure_and_format_helpers(tmp_path):
+    fin, traj = oracle.fold(EX, 100, 5, 1000, traj=True)
+    mine = [[utils.Structure(s.str_struct, s.dcal) for s in st] for st in traj]
+    txt = utils.format_trajectory(EX, mine)
+    assert txt == open(os.path.join(GOLD, "example_rafft.out")).read()
+    p = tmp_path / "x.out"
+    p.write_text(txt)
+    steps, seq = utils.parse_rafft_output(str(p))
+    assert seq == EX and [len(s) for s in steps] == [len(s) for s in traj]
+    assert steps[1][0].str_struct == traj[1][0].str_struct and abs(steps[1][0].energy - (-14.0)) < 1e-9
+    s = mine[2][0]
+    assert utils.dot_bracket(s.pair_list, len(EX)) == s.str_struct
+    assert s.energy == float(np.float32(np.float32(s.dcal) / 100.0))
+
+
+def _oracle_fold_batch(seqs, n_mode=100, max_stack=1, max_branch=100, min_hp=3, min_nrj=0.0, traj=False, temp=37.0,
+                       gc=3.0, au=2.0, gu=1.0, **kw):
+    return [oracle.fold(s, n_mode, max_stack, max_branch, min_hp, min_nrj, traj, temp, gc, au, gu) for s in seqs]
+
+
+def test_cli_formats_match_reference(tmp_path):
+    """final / --bench / --traj text formats of bin/rafft:59-79 (fold injected: no GPU here)"""
+    def run(argv):
+        buf = io.StringIO()
+        with redirect_stdout(buf):
+            cli.main(argv, fold_batch=_oracle_fold_batch)
+        return buf.getvalue()
+    assert run(["-s", EX, "-ms", "5", "--traj"]) == open(os.path.join(GOLD, "example_rafft.out")).read()
+    fin = run(["-s", EX, "-ms", "5"]).splitlines()
+    assert fin[0] == EX and fin[1].endswith(" -24.0") and len(fin) == 6
+    b = run(["-s", EX, "-ms", "2", "--bench"]).splitlines()
+    f = b[0].split()
+    assert f[0] == EX and f[1] == "82" and f[3] == "-24.0" and int(f[4]) == f[2].count("(") and len(b) == 2
+    fa = tmp_path / "s.fa"
+    fa.write_text(">x\nGGGTTTGCGG\nTGTAAGTGCA\n")
+    assert run(["-sf", str(fa)]).splitlines()[0] == "GGGUUUGCGGUGUAAGUGCA"
+    with pytest.raises(AssertionError):
+        cli.main([], fold_batch=_oracle_fold_batch)
+
+
+def test_lpt_shards_balanced_and_complete():
+    rng = np.random.default_rng(1)
+    lens = list(rng.integers(28, 3000, size=500))
+    for n in (1, 2, 4, 8):
+        sh = sharding.lpt_shards(lens, n)
+        assert sorted(i for s in sh for i in s) == list(range(len(lens)))
+        loads = [sum(lens[i] ** 2 for i in s) for s in sh]
+        assert max(loads) <= 1.15 * (sum(loads) / n) + max(lens) ** 2
+
+
+WORKER = r'''
+import os, sys, json
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+import oracle
+from rafft_amd import sharding
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+seqs = json.load(open({seqfile!r}))
+fold = lambda ss, **kw: [oracle.fold(s, 100, 5, 1000) for s in ss]
+res = sharding.fold_sharded(seqs, fold_fn=fold)
+if dist.get_rank() == 0:
+    json.dump([[(x.str_struct, x.dcal) for x in r] for r in res], open({outfile!r}, "w"))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_world_size_2_gloo_sharded_fold(tmp_path):
+    """N>1 path: two ranks, LPT shards, gather on rank 0 - results identical to a single-rank run"""
+    import json
+    rng = np.random.default_rng(2)
+    seqs = ["".join(rng.choice(list("ACGU"), int(n))) for n in rng.integers(20, 120, size=12)]
+    seqfile, outfile = tmp_path / "seqs.json", tmp_path / "out.json"
+    seqfile.write_text(json.dumps(seqs))
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, seqfile=str(seqfile), outfile=str(outfile)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=240) == 0
+    got = json.loads(outfile.read_text())
+    want = [[(x.str_struct, x.dcal) for x in oracle.fold(s, 100, 5, 1000)] for s in seqs]
+    assert [[tuple(x) for x in r] for r in got] == want
