@@ -59,7 +59,7 @@ struct Ctx {
     Buf codes, seq_off, seq_len, beam, beam_n, done, nsteps, ch_parent, ch_combo, ch_dcal, ch_h, seen, seen_off,
         seen_cap, seen_cnt, st_seq, st_dcal, st_node0, st_nnodes, st_parent, st_h, st_db, st_cursor, st_combo, st_total, nd_seq, nd_pdcal,
         nd_n, nd_ci, nd_cj, nd_nbr, nd_canon, nd_ncand, nd_pos, nd_br, nd_cand, pos, br, db, cand, looptab, trec, tsid,
-        work0, work1, work2, mat, newnodes, counters,
+        work0, work1, work2, mat, counters,
         row_sid, row_off, out_db, out_dcal, dbg;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
@@ -271,7 +271,7 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
     ClsCfg cf[3];
     if (int rc = class_cfg(p.nb_mode, cf)) return rc;
     Caps c = plan_caps(S, sumL, p, est);
-    if ((size_t)c.sort_cap * 8 + MAX_PROD * 12 + (size_t)(p.max_stack + 4) * 4 + 256 > 150 * 1024)
+    if ((size_t)c.sort_cap * 8 + MAX_PROD * 12 + (size_t)(p.max_stack + 4) * 36 + 256 > 150 * 1024)
         return fail(RAFFT_ERR_PARAM, "max_branch + 2*max_stack too large for the LDS-resident beam sort");
     const size_t B = (size_t)p.max_stack;
 
@@ -288,7 +288,7 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
     ENS(pos, c.pos * 2); ENS(br, c.br * 4); ENS(db, c.db); ENS(cand, c.cand * 32);
     ENS(looptab, c.looptab * 8);
     ENS(trec, c.trec * 16); ENS(tsid, c.tsid * 4);
-    ENS(work0, c.work * 4); ENS(work1, c.work * 4); ENS(work2, c.work * 4); ENS(mat, c.mat * 4); ENS(newnodes, c.work * 4);
+    ENS(work0, c.work * 4); ENS(work1, c.work * 4); ENS(work2, c.work * 4); ENS(mat, c.mat * 4);
     ENS(counters, sizeof(Counters));
 #undef ENS
 
@@ -322,8 +322,11 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
     d.trec = (int4 *)g.trec.p; d.trec_cap = (uint32_t)c.trec; d.tsid = (int *)g.tsid.p; d.tsid_cap = c.tsid;
     d.work[0] = (int *)g.work0.p; d.work[1] = (int *)g.work1.p; d.work[2] = (int *)g.work2.p; d.work_cap = (uint32_t)c.work;
     d.mat = (int *)g.mat.p; d.mat_cap = (uint32_t)c.mat;
-    d.newnodes = (int *)g.newnodes.p; d.new_cap = (uint32_t)c.work;
     d.c = (Counters *)g.counters.p;
+    d.nd_base = S; d.nd_shard_cap = (c.nd - S) / NSHARD;
+    d.pos_base = sumL; d.pos_shard_cap = (c.pos - sumL) / NSHARD;
+    d.db_base = sumL; d.db_shard_cap = (c.db - sumL) / NSHARD;
+    d.br_shard_cap = c.br / NSHARD; d.cand_shard_cap = c.cand / NSHARD;
     if (seam) d.dbg = seam->dbg;
     if (const char *rp = getenv("RAFFT_REP")) d.rep = atoi(rp);
 
@@ -333,7 +336,7 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
     HIPCHK(hipMemcpyAsync(g.seq_len.p, len.data(), S * 4, hipMemcpyHostToDevice, st));
     Counters hc;
     memset(&hc, 0, sizeof hc);
-    hc.n_struct = S; hc.n_node = S; hc.pos_top = sumL; hc.db_top = sumL; hc.seen_top = S * 1024;
+    hc.n_struct = S; hc.seen_top = S * 1024;
     HIPCHK(hipMemcpyAsync(g.counters.p, &hc, sizeof hc, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(g.seen.p, 0, c.seen * 16, st));
     if (d.memo) HIPCHK(hipMemsetAsync(g.looptab.p, 0, c.looptab * 8, st));
@@ -362,14 +365,15 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
         return 0;
     }
 
-    const size_t bs_lds = (size_t)c.sort_cap * 8 + MAX_PROD * 12 + ((B + 3) & ~(size_t)3) * 4 + 128;
+    const size_t bs_lds = (size_t)c.sort_cap * 8 + MAX_PROD * 12 + B * sizeof(ParentInfo) + ((B + 3) & ~(size_t)3) * 4 + 128;
     static size_t bs_lds_set = 0;
     if (bs_lds > bs_lds_set) {
         HIPCHK(hipFuncSetAttribute((const void *)beam_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds));
         bs_lds_set = bs_lds;
     }
     const size_t cnt_work_off = offsetof(Counters, n_work);
-    const size_t cnt_work_len = offsetof(Counters, overflow) - cnt_work_off;   // n_work[3], n_mat, n_new, next_work[3]
+    const size_t cnt_work_len = offsetof(Counters, overflow) - cnt_work_off;   // n_work[3], n_mat, next_work[3]
+    const size_t hot_len = offsetof(Counters, node);
     int steps = 0;
     for (;;) {
         // ---- expand: the three size classes run concurrently on their own streams
@@ -400,7 +404,7 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
             spans.push_back(sp);
         }
         steps++;
-        HIPCHK(hipMemcpyAsync(&hc, g.counters.p, sizeof hc, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&hc, g.counters.p, hot_len, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if (hc.overflow) { *ovf_bits = hc.overflow; break; }
         if (hc.n_mat == 0) break;
@@ -422,8 +426,13 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
         return RAFFT_ERR_CAPACITY;
     }
     // statistics (SURVEY.md 8d algorithmic bytes; only expansions the kernels really executed)
+    HIPCHK(hipMemcpy(&hc, g.counters.p, sizeof hc, hipMemcpyDeviceToHost));
+    {
+        unsigned long long nn = S;
+        for (int i = 0; i < NSHARD; i++) nn += hc.node[i].v;
+        g.stats.n_nodes_created += (int64_t)nn;
+    }
     g.stats.n_node_expansions += hc.n_expand;
-    g.stats.n_nodes_created += (int64_t)hc.n_node;
     g.stats.n_nodes_aliased += (int64_t)hc.n_alias;
     g.stats.sum_node_len += hc.sum_n;
     g.stats.sum_lags += hc.sum_lags;

@@ -30,17 +30,22 @@ struct alignas(16) Cand {
 };
 static_assert(sizeof(Cand) == 32, "Cand must be 32 bytes");
 
+#define NSHARD 64
+struct ShardCtr { unsigned long long v; unsigned long long pad[7]; };   // one 64-byte line each
+
 struct Counters {
-    unsigned long long n_struct, n_node, pos_top, db_top, cand_top, seen_top, trec_n, tsid_top, br_top;
+    // hot part: read back by the host once per folding step (first 64 bytes)
     unsigned int n_work[3];     // expand work items per size class (filled by dedupe_kernel)
     unsigned int n_mat;         // structures to materialize (filled by beam_step_kernel)
-    unsigned int n_new;         // nodes created by materialize_kernel, input of dedupe_kernel
     unsigned int next_work[3];  // dynamic fetch cursors of the persistent expand kernels
     unsigned int overflow;      // bit mask of which arena overflowed
     unsigned int n_done;
-    unsigned int pad_;
+    unsigned int pad_[7];
+    unsigned long long n_struct, seen_top, trec_n, tsid_top;
     // statistics
     unsigned long long n_expand, sum_n, sum_lags, n_children, sum_struct_len, n_alias, sum_nbr;
+    // sharded bump pointers of the arenas filled by materialize / expand
+    ShardCtr node[NSHARD], pos[NSHARD], br[NSHARD], db[NSHARD], cand[NSHARD];
 };
 
 enum { OVF_STRUCT = 1, OVF_NODE = 2, OVF_POS = 4, OVF_DB = 8, OVF_CAND = 16, OVF_SEEN = 32,
@@ -72,6 +77,7 @@ struct Dev {
     uint64_t *st_h, *st_db, *st_cursor, *st_combo, *st_total;
     // nodes
     uint32_t nd_cap;
+    uint64_t nd_base, nd_shard_cap, pos_base, pos_shard_cap, br_shard_cap, db_base, db_shard_cap, cand_shard_cap;
     int *nd_seq, *nd_pdcal, *nd_n, *nd_ci, *nd_cj, *nd_nbr, *nd_canon, *nd_ncand;
     uint64_t *nd_pos, *nd_br, *nd_cand;
     // loop table: open addressing, word = (hash tag << 32) | (node id + 1)
@@ -87,7 +93,6 @@ struct Dev {
     // work lists
     int *work[3]; uint32_t work_cap;
     int *mat; uint32_t mat_cap;
-    int *newnodes; uint32_t new_cap;
     Counters *c;
     DebugOut dbg;
     int rep;                     // profiling only (RAFFT_REP env): bit k doubles phase k of expand_kernel

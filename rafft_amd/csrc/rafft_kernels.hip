@@ -91,6 +91,8 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         wtab[tid] = (tp == 5 || tp == 6) ? d.au : (tp == 1 || tp == 2) ? d.gc : (tp == 3 || tp == 4) ? d.gu : 0.0;
     }
     const unsigned n_items = d.c->n_work[cls];
+    const int shard = blockIdx.x & (NSHARD - 1);
+    unsigned long long st_items = 0, st_n = 0, st_lags = 0, st_nbr = 0;   // per-block statistics
 
     for (;;) {
         __syncthreads();                       // previous region's LDS use is over
@@ -303,14 +305,12 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
             unsigned long long base = 0;
             misc[2] = 0;
             if (nkept) {
-                base = atomicAdd(&d.c->cand_top, (unsigned long long)nkept);
-                if (base + nkept > d.cand_cap) { atomicOr(&d.c->overflow, OVF_CAND); base = 0; misc[2] = 1; }
+                base = atomicAdd(&d.c->cand[shard].v, (unsigned long long)nkept);
+                if (base + nkept > d.cand_shard_cap) { atomicOr(&d.c->overflow, OVF_CAND); base = 0; misc[2] = 1; }
+                base += (unsigned long long)shard * d.cand_shard_cap;
             }
             *(unsigned long long *)&misc[4] = base;
-            atomicAdd(&d.c->n_expand, 1ULL);
-            atomicAdd(&d.c->sum_n, (unsigned long long)n);
-            atomicAdd(&d.c->sum_lags, (unsigned long long)Kp);
-            atomicAdd(&d.c->sum_nbr, (unsigned long long)nbr);
+            st_items++; st_n += n; st_lags += Kp; st_nbr += nbr;
         }
         __syncthreads();
         const unsigned long long cbase = *(unsigned long long *)&misc[4];
@@ -341,6 +341,12 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
             if (d.dbg.n_ranked) d.dbg.n_ranked[1] = nkept;
         }
     }
+    if (tid == 0 && st_items) {
+        atomicAdd(&d.c->n_expand, st_items);
+        atomicAdd(&d.c->sum_n, st_n);
+        atomicAdd(&d.c->sum_lags, st_lags);
+        atomicAdd(&d.c->sum_nbr, st_nbr);
+    }
 }
 
 // --------------------------------------------------------- beam step kernel
@@ -368,16 +374,29 @@ __device__ inline void seen_insert(uint64_t *tab, uint32_t cap, uint64_t h1, uin
 
 #define BS_NT 256
 
-// LDS: sort keys (dynamic) + product description
+struct ParentInfo {         // filled by the parallel prepass, one entry per beam member
+    unsigned long long total, h1, h2;
+    int dcal0, flag;        // flag: 0 live, 1 nothing to produce
+};
+
+__device__ __forceinline__ unsigned long long sat_mul(unsigned long long a, unsigned long long b)
+{
+    const unsigned long long lim = 1ULL << 62;
+    if (a == 0 || b == 0) return 0;
+    return (a > lim / b) ? lim : a * b;
+}
+
+// LDS: sort keys (dynamic) + product description + per-parent prepass records
 __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
 {
     extern __shared__ __align__(16) unsigned char lds[];
     unsigned long long *skey = (unsigned long long *)lds;                       // [sort_cap]
-    int *prod_cnt = (int *)(lds + 8 * (size_t)sort_cap);                        // [MAX_PROD]
-    unsigned long long *prod_off = (unsigned long long *)(prod_cnt + MAX_PROD); // [MAX_PROD]
-    int *oldbeam = (int *)(prod_off + MAX_PROD);                                // [B]
+    unsigned long long *prod_off = (unsigned long long *)(lds + 8 * (size_t)sort_cap); // [MAX_PROD]
+    int *prod_cnt = (int *)(prod_off + MAX_PROD);                               // [MAX_PROD]
+    ParentInfo *pinfo = (ParentInfo *)(prod_cnt + MAX_PROD);                    // [B]
+    int *oldbeam = (int *)(pinfo + d.B);                                        // [B]
     int *sh = oldbeam + ((d.B + 3) & ~3);                                       // scratch [32]
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int sq = blockIdx.x;
     if (d.done[sq]) return;
     const int nbeam = d.beam_n[sq];
@@ -400,25 +419,112 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
     }
     if (tid == 0) d.nsteps[sq] += 1;
 
+    // ---- prepass, one wavefront per beam member: product size and combo 0 of every parent
+    for (int b = wv; b < nbeam; b += BS_NT / 64) {
+        const int sid = oldbeam[b];
+        const unsigned long long cur0 = d.st_cursor[sid], tot0 = d.st_total[sid];
+        if (tot0 && cur0 >= tot0) { if (lane == 0) pinfo[b].flag = 1; continue; }
+        const int node0 = d.st_node0[sid], nn = d.st_nnodes[sid];
+        unsigned long long tot = 1, h1 = 0, h2 = 0;
+        int dc = 0, np = 0;
+        for (int base = 0; base < nn; base += 64) {
+            int i = base + lane;
+            if (i < nn) {
+                int cn = d.nd_canon[node0 + i];
+                int cnt = d.nd_ncand[cn];
+                if (cnt > 0) {
+                    const Cand *cp = &d.cand[d.nd_cand[cn]];
+                    tot = sat_mul(tot, (unsigned long long)cnt);
+                    dc += cp->ddcal; h1 += cp->h1; h2 += cp->h2; np++;
+                }
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            tot = sat_mul(tot, __shfl_xor(tot, o, 64));
+            h1 += __shfl_xor(h1, o, 64); h2 += __shfl_xor(h2, o, 64);
+            dc += __shfl_xor(dc, o, 64); np += __shfl_xor(np, o, 64);
+        }
+        if (lane == 0) {
+            ParentInfo pi;
+            pi.flag = np == 0 ? 1 : 0;
+            pi.total = tot;
+            pi.h1 = d.st_h[2 * (size_t)sid] + h1; pi.h2 = d.st_h[2 * (size_t)sid + 1] + h2;
+            pi.dcal0 = d.st_dcal[sid] + dc;
+            pinfo[b] = pi;
+            if (np == 0) { d.st_total[sid] = 1; d.st_cursor[sid] = 1; }
+        }
+    }
+    __syncthreads();
+
     uint64_t *stab = d.seen + 2 * d.seen_off[sq];
     uint32_t scap = d.seen_cap[sq], scnt = d.seen_cnt[sq];
     const size_t chb = (size_t)sq * d.ch_cap;
     int nb_branch = 0, nchild = 0;
 
     for (int b = 0; b < nbeam; b++) {
+        if (pinfo[b].flag) continue;
         const int sid = oldbeam[b];
-        const int node0 = d.st_node0[sid], nn = d.st_nnodes[sid];
-        {   // a parent whose product is exhausted, or that may only replay combo 0 which is
-            // already in `seen` (rafft/rafft.py:202-203), cannot produce anything: skip early
-            const unsigned long long cur0 = d.st_cursor[sid], tot0 = d.st_total[sid];
-            if (tot0 && cur0 >= tot0) continue;
-            if (nb_branch >= d.max_branch && cur0 > 0) continue;
+        unsigned long long cur = d.st_cursor[sid];
+        const unsigned long long total = pinfo[b].total;
+        const bool single = nb_branch >= d.max_branch;   // rafft/rafft.py:202-203: one combo, then break
+        if (single && cur > 0) continue;                  // combo 0 is already in `seen`
+        // grow the seen set if the next chunk could push the load factor past 1/2
+        {
+            const unsigned long long left = total - cur;
+            const int chunk = single ? 1 : (left < BS_NT ? (int)left : BS_NT);
+            if ((unsigned long long)(scnt + chunk) * 2 > scap) {
+                uint32_t ncap = scap;
+                while ((unsigned long long)(scnt + BS_NT) * 2 > ncap) ncap <<= 1;
+                if (tid == 0) {
+                    unsigned long long o = atomicAdd(&d.c->seen_top, (unsigned long long)ncap);
+                    if (o + ncap > d.seen_cap_total) { atomicOr(&d.c->overflow, OVF_SEEN); *(unsigned long long *)&sh[8] = ~0ULL; }
+                    else *(unsigned long long *)&sh[8] = o;
+                }
+                __syncthreads();
+                unsigned long long o = *(unsigned long long *)&sh[8];
+                __syncthreads();
+                if (o == ~0ULL) { d.done[sq] = 1; return; }
+                uint64_t *ntab = d.seen + 2 * o;
+                for (uint32_t i = tid; i < scap; i += BS_NT) {
+                    uint64_t k1 = stab[2 * (uint64_t)i];
+                    if (k1) seen_insert(ntab, ncap, k1, stab[2 * (uint64_t)i + 1]);
+                }
+                __syncthreads();
+                stab = ntab; scap = ncap;
+                if (tid == 0) { d.seen_off[sq] = o; d.seen_cap[sq] = ncap; }
+            }
         }
-        // productive nodes in node order (rafft/rafft.py:166-171)
+        if (single) {
+            // exactly combo 0 of this parent (precomputed); accepted if its structure is new
+            if (tid == 0) {
+                uint64_t h1 = pinfo[b].h1, h2 = pinfo[b].h2;
+                if (h1 == 0) h1 = 1;
+                if (h2 == 0) h2 = 1;
+                int isnew = seen_lookup(stab, scap, h1, h2) ? 0 : 1;
+                if (isnew) {
+                    if (nchild < d.ch_cap) {
+                        d.ch_parent[chb + nchild] = (uint16_t)b;
+                        d.ch_combo[chb + nchild] = 0;
+                        d.ch_dcal[chb + nchild] = pinfo[b].dcal0;
+                        d.ch_h[2 * (chb + nchild)] = h1;
+                        d.ch_h[2 * (chb + nchild) + 1] = h2;
+                    } else atomicOr(&d.c->overflow, OVF_SORT);
+                    seen_insert(stab, scap, h1, h2);
+                }
+                sh[20] = isnew;
+                d.st_cursor[sid] = 1; d.st_total[sid] = total;
+            }
+            __syncthreads();
+            const int isnew = sh[20];
+            __syncthreads();
+            nchild += isnew; nb_branch += isnew; scnt += isnew;
+            continue;
+        }
+        // productive regions in node order (rafft/rafft.py:166-171)
+        const int node0 = d.st_node0[sid], nn = d.st_nnodes[sid];
         int mprod = 0;
         for (int base = 0; base < nn; base += BS_NT) {
-            int i = base + tid, cnt = 0;
-            int cn = 0;
+            int i = base + tid, cnt = 0, cn = 0;
             if (i < nn) { cn = d.nd_canon[node0 + i]; cnt = d.nd_ncand[cn]; }
             int tot, ex = block_exscan<BS_NT>(cnt > 0 ? 1 : 0, sh, &tot);
             if (cnt > 0 && mprod + ex < MAX_PROD) {
@@ -429,24 +535,14 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
             __syncthreads();
         }
         if (mprod > MAX_PROD) { if (tid == 0) atomicOr(&d.c->overflow, OVF_PROD); mprod = MAX_PROD; }
-        if (mprod == 0) { if (tid == 0) { d.st_total[sid] = 1; d.st_cursor[sid] = 1; } continue; }
-        unsigned long long total = 1;
-        for (int k = 0; k < mprod; k++) {
-            unsigned long long c = (unsigned long long)prod_cnt[k];
-            total = (total > (1ULL << 62) / c) ? (1ULL << 62) : total * c;
-        }
-        unsigned long long cur = d.st_cursor[sid];
         const int par_dcal = d.st_dcal[sid];
         const uint64_t ph1 = d.st_h[2 * (size_t)sid], ph2 = d.st_h[2 * (size_t)sid + 1];
-        bool single = nb_branch >= d.max_branch;  // rafft/rafft.py:202-203: one combo, then break
-        if (single && cur > 0) continue;           // combo 0 is already in `seen`
         while (cur < total) {
             unsigned long long left = total - cur;
-            int chunk = single ? 1 : (left < BS_NT ? (int)left : BS_NT);
-            // grow the seen set if this chunk could push the load factor past 1/2
-            if ((unsigned long long)(scnt + chunk) * 2 > scap) {
+            int chunk = left < BS_NT ? (int)left : BS_NT;
+            if ((unsigned long long)(scnt + chunk) * 2 > scap) {   // (rare) grow again inside a long product walk
                 uint32_t ncap = scap;
-                while ((unsigned long long)(scnt + chunk) * 2 > ncap) ncap <<= 1;
+                while ((unsigned long long)(scnt + BS_NT) * 2 > ncap) ncap <<= 1;
                 if (tid == 0) {
                     unsigned long long o = atomicAdd(&d.c->seen_top, (unsigned long long)ncap);
                     if (o + ncap > d.seen_cap_total) { atomicOr(&d.c->overflow, OVF_SEEN); *(unsigned long long *)&sh[8] = ~0ULL; }
@@ -495,13 +591,12 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
             // first position where nb_branch reaches max_branch (checked after every combo)
             int incl = ex + isnew;
             int hit = (tid < chunk && nb_branch + incl >= d.max_branch) ? tid : BS_NT;
-            // block min of `hit`
             for (int o = 32; o > 0; o >>= 1) hit = min(hit, __shfl_xor(hit, o, 64));
             __syncthreads();
-            if ((tid & 63) == 0) sh[16 + (tid >> 6)] = hit;
+            if (lane == 0) sh[16 + wv] = hit;
             __syncthreads();
             hit = min(min(sh[16], sh[17]), min(sh[18], sh[19]));
-            int processed = hit < BS_NT ? hit + 1 : chunk;
+            const int processed = hit < BS_NT ? hit + 1 : chunk;
             int accepted_here = 0;
             if (tid < processed && isnew) {
                 int ci2 = nchild + ex;
@@ -515,13 +610,8 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
                 seen_insert(stab, scap, h1, h2);
                 accepted_here = 1;
             }
-            // number accepted = prefix at `processed`
-            int acc_tot;
-            {
-                int t2, e2 = block_exscan<BS_NT>(accepted_here, sh, &t2);
-                (void)e2;
-                acc_tot = t2;
-            }
+            int acc_tot, e2 = block_exscan<BS_NT>(accepted_here, sh, &acc_tot);
+            (void)e2;
             nchild += acc_tot; nb_branch += acc_tot; scnt += acc_tot;
             cur += processed;
             __syncthreads();
@@ -585,6 +675,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
     if (tid == 0) {
         unsigned long long sb = atomicAdd(&d.c->n_struct, (unsigned long long)nsurv_child);
         unsigned int mb = atomicAdd(&d.c->n_mat, (unsigned int)nsurv_child);
+        atomicAdd(&d.c->sum_struct_len, (unsigned long long)nsurv_child * (unsigned long long)d.seq_len[sq]);
         if (sb + nsurv_child > d.st_cap || mb + nsurv_child > d.mat_cap) { atomicOr(&d.c->overflow, OVF_STRUCT); sh[24] = -1; }
         else { sh[24] = (int)sb; sh[25] = (int)mb; }
     }
@@ -693,25 +784,26 @@ __global__ __launch_bounds__(MAT_NT) void materialize_kernel(Dev d)
         tot_nodes += nnod; tot_pos += npos; tot_br += nbrr;
     }
     if (tid == 0) {
-        unsigned long long nb0 = atomicAdd(&d.c->n_node, (unsigned long long)tot_nodes);
-        unsigned long long pb0 = atomicAdd(&d.c->pos_top, (unsigned long long)tot_pos);
-        unsigned long long bb0 = atomicAdd(&d.c->br_top, (unsigned long long)tot_br);
-        unsigned long long tb0 = atomicAdd(&d.c->db_top, (unsigned long long)L);
-        unsigned int nw0 = atomicAdd(&d.c->n_new, (unsigned int)tot_nodes);
+        // bump allocation from one of NSHARD sub-arenas (spreads the same-address atomics)
+        const int shd = blockIdx.x & (NSHARD - 1);
+        unsigned long long nb0 = atomicAdd(&d.c->node[shd].v, (unsigned long long)tot_nodes);
+        unsigned long long pb0 = atomicAdd(&d.c->pos[shd].v, (unsigned long long)tot_pos);
+        unsigned long long bb0 = atomicAdd(&d.c->br[shd].v, (unsigned long long)tot_br);
+        unsigned long long tb0 = atomicAdd(&d.c->db[shd].v, (unsigned long long)L);
         int ok = 1;
-        if (nb0 + tot_nodes > d.nd_cap) { atomicOr(&d.c->overflow, OVF_NODE); ok = 0; }
-        if (pb0 + tot_pos > d.pos_cap) { atomicOr(&d.c->overflow, OVF_POS); ok = 0; }
-        if (bb0 + tot_br > d.br_cap) { atomicOr(&d.c->overflow, OVF_BR); ok = 0; }
-        if (tb0 + L > d.db_cap) { atomicOr(&d.c->overflow, OVF_DB); ok = 0; }
-        if (nw0 + tot_nodes > d.new_cap) { atomicOr(&d.c->overflow, OVF_WORK); ok = 0; }
-        sh64[0] = nb0; sh64[1] = pb0; sh64[2] = tb0; sh64[3] = bb0;
-        shi[0] = ok; shi[1] = (int)nw0;
-        atomicAdd(&d.c->sum_struct_len, (unsigned long long)L);
+        if (nb0 + tot_nodes > d.nd_shard_cap) { atomicOr(&d.c->overflow, OVF_NODE); ok = 0; }
+        if (pb0 + tot_pos > d.pos_shard_cap) { atomicOr(&d.c->overflow, OVF_POS); ok = 0; }
+        if (bb0 + tot_br > d.br_shard_cap) { atomicOr(&d.c->overflow, OVF_BR); ok = 0; }
+        if (tb0 + L > d.db_shard_cap) { atomicOr(&d.c->overflow, OVF_DB); ok = 0; }
+        sh64[0] = d.nd_base + (unsigned long long)shd * d.nd_shard_cap + nb0;
+        sh64[1] = d.pos_base + (unsigned long long)shd * d.pos_shard_cap + pb0;
+        sh64[2] = d.db_base + (unsigned long long)shd * d.db_shard_cap + tb0;
+        sh64[3] = (unsigned long long)shd * d.br_shard_cap + bb0;
+        shi[0] = ok;
     }
     __syncthreads();
     if (!shi[0]) { if (tid == 0) { d.st_nnodes[sid] = 0; d.st_node0[sid] = 0; d.st_db[sid] = 0; } return; }
     const unsigned long long nbase = sh64[0], pbase = sh64[1], tbase = sh64[2], bbase = sh64[3];
-    const int nwbase = shi[1];
 
     // dot-bracket row: parent's row + the stems (rafft/rafft.py:97,127-128)
     const uint8_t *pdb = d.db + d.st_db[par];
@@ -766,7 +858,6 @@ __global__ __launch_bounds__(MAT_NT) void materialize_kernel(Dev d)
                     d.nd_seq[nid] = sq; d.nd_pdcal[nid] = my_dcal; d.nd_pos[nid] = poff; d.nd_n[nid] = len;
                     d.nd_ci[nid] = pp[mi]; d.nd_cj[nid] = pp[mj]; d.nd_br[nid] = boff; d.nd_nbr[nid] = nb_in;
                     d.nd_ncand[nid] = -1; d.nd_cand[nid] = 0; d.nd_canon[nid] = nid;
-                    d.newnodes[nwbase + nidx] = nid;
                 }
                 nidx++; poff += len; boff += nb_in;
             }
@@ -786,7 +877,6 @@ __global__ __launch_bounds__(MAT_NT) void materialize_kernel(Dev d)
                     d.nd_seq[nid] = sq; d.nd_pdcal[nid] = my_dcal; d.nd_pos[nid] = poff; d.nd_n[nid] = len;
                     d.nd_ci[nid] = pci; d.nd_cj[nid] = pcj; d.nd_br[nid] = boff; d.nd_nbr[nid] = nb_out;
                     d.nd_ncand[nid] = -1; d.nd_cand[nid] = 0; d.nd_canon[nid] = nid;
-                    d.newnodes[nwbase + nidx] = nid;
                 }
             }
         }
@@ -810,42 +900,61 @@ __device__ inline bool same_loop(const Dev &d, int a, int b)
     return true;
 }
 
-// One thread per region created in this step.  The first region to claim a loop key
-// becomes canonical and goes to the expand work list; later identical loops alias it.
-__global__ void dedupe_kernel(Dev d)
+// One wavefront per structure materialized in this step, one lane per region.  The first
+// region to claim a loop key becomes canonical and goes to the expand work list; later
+// identical loops alias it.  Work-list appends are aggregated per wavefront.
+__global__ __launch_bounds__(256) void dedupe_kernel(Dev d)
 {
-    const unsigned n_new = d.c->n_new;
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n_new; i += gridDim.x * blockDim.x) {
-        const int nid = d.newnodes[i];
-        int canon = nid;
-        if (d.memo) {
-            const uint32_t *bb = d.br + d.nd_br[nid];
-            const int nbr = d.nd_nbr[nid];
-            uint64_t h = mix64(((uint64_t)(uint32_t)d.nd_seq[nid] << 32) ^ ((uint64_t)(uint32_t)(d.nd_ci[nid] + 1) << 16) ^ (uint32_t)d.nd_cj[nid]);
-            for (int t = 0; t < nbr; t++) h += mix64((uint64_t)bb[t] ^ 0x5bd1e9955bd1e995ULL);
-            const unsigned long long tag = (h >> 32) | 0x80000000ULL;
-            const uint64_t mask = d.looptab_cap - 1;
-            uint64_t sl = h & mask;
-            for (unsigned probe = 0;; probe++) {
-                unsigned long long old = atomicCAS(&d.looptab[sl], 0ULL, (tag << 32) | (unsigned long long)(nid + 1));
-                if (old == 0) break;
-                if ((old >> 32) == tag) {
-                    int other = (int)(old & 0xffffffffULL) - 1;
-                    if (same_loop(d, nid, other)) { canon = other; break; }
+    const unsigned n_mat = d.c->n_mat;
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    unsigned long long aliases = 0;
+    for (unsigned m = wave; m < n_mat; m += n_waves) {
+        const int sid = d.mat[m];
+        const int node0 = d.st_node0[sid], nn = d.st_nnodes[sid];
+        for (int base = 0; base < nn; base += 64) {
+            const int i = base + lane;
+            int cls = -1, nid = 0;
+            if (i < nn) {
+                nid = node0 + i;
+                int canon = nid;
+                if (d.memo) {
+                    const uint32_t *bb = d.br + d.nd_br[nid];
+                    const int nbr = d.nd_nbr[nid];
+                    uint64_t h = mix64(((uint64_t)(uint32_t)d.nd_seq[nid] << 32) ^ ((uint64_t)(uint32_t)(d.nd_ci[nid] + 1) << 16) ^ (uint32_t)d.nd_cj[nid]);
+                    for (int t = 0; t < nbr; t++) h += mix64((uint64_t)bb[t] ^ 0x5bd1e9955bd1e995ULL);
+                    const unsigned long long tag = (h >> 32) | 0x80000000ULL;
+                    const uint64_t mask = d.looptab_cap - 1;
+                    uint64_t sl = h & mask;
+                    for (unsigned probe = 0;; probe++) {
+                        unsigned long long old = atomicCAS(&d.looptab[sl], 0ULL, (tag << 32) | (unsigned long long)(nid + 1));
+                        if (old == 0) break;
+                        if ((old >> 32) == tag) {
+                            int other = (int)(old & 0xffffffffULL) - 1;
+                            if (same_loop(d, nid, other)) { canon = other; break; }
+                        }
+                        sl = (sl + 1) & mask;
+                        if (probe > d.looptab_cap) { atomicOr(&d.c->overflow, OVF_LOOPTAB); break; }
+                    }
                 }
-                sl = (sl + 1) & mask;
-                if (probe > d.looptab_cap) { atomicOr(&d.c->overflow, OVF_LOOPTAB); break; }
+                if (canon == nid) cls = node_class(d.nd_n[nid], d.seq_len[d.nd_seq[nid]], d.nd_nbr[nid]);
+                else { d.nd_canon[nid] = canon; aliases++; }
+            }
+            for (int c = 0; c < 3; c++) {
+                unsigned long long bal = __ballot(cls == c);
+                if (!bal) continue;
+                unsigned int w0 = 0;
+                if (lane == 0) w0 = atomicAdd(&d.c->n_work[c], (unsigned int)__popcll(bal));
+                w0 = __shfl(w0, 0, 64);
+                if (cls == c) {
+                    unsigned int w = w0 + (unsigned int)__popcll(bal & ((1ULL << lane) - 1));
+                    if (w < d.work_cap) d.work[c][w] = nid; else atomicOr(&d.c->overflow, OVF_WORK);
+                }
             }
         }
-        if (canon == nid) {
-            int cls = node_class(d.nd_n[nid], d.seq_len[d.nd_seq[nid]], d.nd_nbr[nid]);
-            unsigned int w = atomicAdd(&d.c->n_work[cls], 1u);
-            if (w < d.work_cap) d.work[cls][w] = nid; else atomicOr(&d.c->overflow, OVF_WORK);
-        } else {
-            d.nd_canon[nid] = canon;
-            atomicAdd(&d.c->n_alias, 1ULL);
-        }
     }
+    for (int o = 32; o > 0; o >>= 1) aliases += __shfl_xor(aliases, o, 64);
+    if (lane == 0 && aliases) atomicAdd(&d.c->n_alias, aliases);
 }
 
 // ------------------------------------------------------------- init kernel
