@@ -380,7 +380,7 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
         HIPCHK(hipEventRecord(g.ev_fork, st));
         Span wall{next_event(), next_event(), 4};
         HIPCHK(hipEventRecord(wall.a, st));
-        for (int cls = 0; cls < 3; cls++) {
+        for (int cls = 2; cls >= 0; cls--) {   // big-LDS classes first: they need whole CUs, the small class fills the rest
             hipStream_t cs = g.cls_stream[cls];
             HIPCHK(hipStreamWaitEvent(cs, g.ev_fork, 0));
             Span sp{next_event(), next_event(), 10 + cls};

@@ -1,0 +1,112 @@
+"""Full-size runs of the BASELINE configs on the GPU, checked through size-independent
+properties (the oracle would take minutes at these sizes) plus sampled oracle parity."""
+import numpy as np
+import pytest
+
+import oracle
+import rafft_amd
+from rafft_amd import rafft as R
+
+pytestmark = pytest.mark.gpu
+
+CANON = {("A", "U"), ("U", "A"), ("G", "C"), ("C", "G"), ("G", "U"), ("U", "G")}
+
+
+def check_structures(seq, beam, max_stack, min_hp=3):
+    assert 1 <= len(beam) <= max_stack
+    dcals = [s.dcal for s in beam]
+    assert dcals == sorted(dcals)                                  # beam sorted by energy (rafft.py:207)
+    assert len({s.str_struct for s in beam}) == len(beam)          # `seen` dedupe (rafft.py:196-200)
+    for s in beam:
+        assert len(s.str_struct) == len(seq)
+        for i, j in s.pair_list:                                   # balanced, canonical, hairpin constraint
+            assert (seq[i], seq[j]) in CANON
+            assert j - i > min_hp
+
+
+def test_gpu_cfg3_benchmark_set_properties(bench_rows):
+    """BASELINE configs[2], all 2296 sequences, n=100 ms=50."""
+    seqs = [r["seq"] for r in bench_rows]
+    res = rafft_amd.fold_batch(seqs, 100, 50, 1000)
+    res2 = rafft_amd.fold_batch(seqs, 100, 50, 1000)
+    flat_s, flat_d, flat_e = [], [], []
+    for s, beam, beam2 in zip(seqs, res, res2):
+        check_structures(s, beam, 50)
+        assert [(x.str_struct, x.dcal) for x in beam] == [(x.str_struct, x.dcal) for x in beam2]   # deterministic
+        for x in beam:
+            flat_s.append(s); flat_d.append(x.str_struct); flat_e.append(x.dcal)
+    # checksum of checksums: the incrementally summed dE of every final structure equals an
+    # independent whole-structure evaluation (different kernel, pair-table walk)
+    got, st = R.eval_structures(flat_s, flat_d)
+    assert not any(st)
+    assert got == flat_e
+    # sampled bit-exact parity with the oracle (every 41st sequence up to 600 nt)
+    for s, beam in list(zip(seqs, res))[::41]:
+        if len(s) <= 600:
+            o = oracle.fold(s, 100, 50, 1000)
+            assert [(x.str_struct, x.dcal) for x in o] == [(x.str_struct, x.dcal) for x in beam]
+    # soft pin: the reference's published lowest-energy structures (unknown ViennaRNA / older rafft.py)
+    hit = sum(1 for r, beam in zip(bench_rows, res) if min(beam, key=lambda x: x.dcal).str_struct == r["best"][0])
+    assert hit >= 0.90 * len(seqs), hit
+    member = sum(1 for r, beam in zip(bench_rows, res) if r["ppv"][0] in {x.str_struct for x in beam})
+    assert member >= 0.80 * len(seqs), member
+
+
+def test_gpu_cfg2_full_1000_random_L200():
+    rng = np.random.default_rng(200)
+    seqs = ["".join(rng.choice(list("ACGU"), 200)) for _ in range(1000)]
+    res = rafft_amd.fold_batch(seqs, 100, 50, 1000)
+    for s, beam in zip(seqs, res):
+        check_structures(s, beam, 50)
+    flat = [(s, x.str_struct, x.dcal) for s, beam in zip(seqs, res) for x in beam]
+    got, st = R.eval_structures([f[0] for f in flat], [f[1] for f in flat])
+    assert got == [f[2] for f in flat]
+
+
+def test_gpu_cfg4_mixed_lengths_ms200_reduced():
+    """BASELINE configs[3] shape (L ~ U[100,3000], ms=200) at 96 sequences on one GPU"""
+    rng = np.random.default_rng(3000)
+    lens = rng.integers(100, 3001, size=96)
+    seqs = ["".join(rng.choice(list("ACGU"), int(n))) for n in lens]
+    res = rafft_amd.fold_batch(seqs, 100, 200, 1000)
+    for s, beam in zip(seqs, res):
+        check_structures(s, beam, 200)
+    flat = [(s, x.str_struct, x.dcal) for s, beam in zip(seqs, res) for x in beam]
+    got, st = R.eval_structures([f[0] for f in flat], [f[1] for f in flat])
+    assert got == [f[2] for f in flat]
+    i = int(np.argmin(lens))
+    o = oracle.fold(seqs[i], 100, 200, 1000)
+    assert [(x.str_struct, x.dcal) for x in o] == [(x.str_struct, x.dcal) for x in res[i]]
+
+
+def test_gpu_cfg5_L400_ms1000_traj_vs_oracle(tmp_path):
+    """BASELINE configs[4]: one 400-nt sequence, beam 1000, full trajectory; the text it writes is
+    what rafft_kin reads (parse_rafft_output round trip)"""
+    rng = np.random.default_rng(400)
+    s = "".join(rng.choice(list("ACGU"), 400))
+    fin, traj = rafft_amd.fold(s, 100, 1000, 1000, traj=True)
+    ofin, otraj = oracle.fold(s, 100, 1000, 1000, traj=True)
+    assert [[(x.str_struct, x.dcal) for x in st] for st in traj] == [[(x.str_struct, x.dcal) for x in st] for st in otraj]
+    p = tmp_path / "traj.out"
+    p.write_text(rafft_amd.format_trajectory(s, traj))
+    steps, seq = rafft_amd.parse_rafft_output(str(p))
+    assert seq == s and [len(x) for x in steps] == [len(x) for x in traj]
+
+
+def test_gpu_min_nrj_nonzero_disables_memoization_and_matches_oracle():
+    rng = np.random.default_rng(11)
+    seqs = ["".join(rng.choice(list("ACGU"), 120)) for _ in range(12)]
+    for mn in (-2.5, -0.7, 1.3):
+        res = rafft_amd.fold_batch(seqs, 100, 20, 1000, min_nrj=mn, traj=True)
+        for s, (fin, traj) in zip(seqs, res):
+            _, o = oracle.fold(s, 100, 20, 1000, min_nrj=mn, traj=True)
+            assert [[(x.str_struct, x.dcal) for x in st] for st in traj] == [[(x.str_struct, x.dcal) for x in st] for st in o]
+
+
+def test_gpu_non_integer_weights_match_oracle():
+    rng = np.random.default_rng(12)
+    seqs = ["".join(rng.choice(list("ACGU"), 100)) for _ in range(8)]
+    res = rafft_amd.fold_batch(seqs, 60, 10, 1000, gc_wei=2.7, au_wei=1.9, gu_wei=0.65, traj=True)
+    for s, (fin, traj) in zip(seqs, res):
+        _, o = oracle.fold(s, 60, 10, 1000, gc_wei=2.7, au_wei=1.9, gu_wei=0.65, traj=True)
+        assert [[(x.str_struct, x.dcal) for x in st] for st in traj] == [[(x.str_struct, x.dcal) for x in st] for st in o]
