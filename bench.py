@@ -147,7 +147,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            k = tj["kernels"].get("void expand_kernel<64>")
+            k = tj["kernels"].get("void expand_kernel<64, false>") or tj["kernels"].get("void expand_kernel<64>")
             if k:
                 traffic, traffic_src = k["hbm_bytes_per_launch"], "profiles/r01_traffic.json: " + tj["correction"]
         launches = max(1, agg["n_expand_launches"])
@@ -168,13 +168,13 @@ def main():
                                    "(L 28..2968), nb_mode n=100, max_stack ms=50, max_branch=1000, 1 GPU per rank",
                        "nb_mode": args.nb_mode, "max_stack": args.max_stack, "max_branch": args.max_branch,
                        "sequences_per_rank": n, "parallelism": f"replica x{world}, no collective"},
-            "roofline": {"bound": "hbm", "kernel": "expand_kernel<64>", "achieved": round(achieved, 3),
+            "roofline": {"bound": "hbm", "kernel": "expand_kernel<64,false> (regions with FFT size <= 512)", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": traffic, "traffic_source": traffic_src,
                          "alg_bytes_per_launch": round(bytes_per_launch, 1),
                          "mean_launch_ms": round(dur_s * 1e3, 4), "launches_per_step": launches / args.steps},
             "kernel_ms_per_step": {k: round(agg[k] / args.steps, 3) for k in
-                                   ("ms_total", "ms_expand", "ms_expand_c1", "ms_expand_c2", "ms_expand_wall", "ms_beam",
+                                   ("ms_total", "ms_expand", "ms_expand_c1", "ms_expand_c2", "ms_expand_c3", "ms_expand_wall", "ms_beam",
                                     "ms_materialize", "ms_output")},
             "memoization": {"regions_created": agg["n_nodes_created"] // args.steps,
                             "regions_expanded": agg["n_node_expansions"] // args.steps},

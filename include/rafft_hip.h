@@ -75,9 +75,11 @@ typedef struct {
  * device (HIP events on the library's own stream). */
 typedef struct {
     double ms_total;          /* wall time of the call, host side */
-    double ms_expand;         /* sum of expand_kernel<64> durations (HIP events on its stream) */
-    double ms_expand_c1;      /* expand_kernel<256> (regions with 512 < P <= 2048), runs concurrently */
-    double ms_expand_c2;      /* expand_kernel<512> (P > 2048), runs concurrently */
+    double ms_expand;         /* sum of expand_kernel<64,false> durations (regions with FFT size P <= 512;
+                                 the dominant kernel; HIP events on its own stream) */
+    double ms_expand_c1;      /* experimental tiny-region class (receives no work) */
+    double ms_expand_c2;      /* expand_kernel<256,false> (512 < P <= 2048), runs concurrently */
+    double ms_expand_c3;      /* expand_kernel<512,false> (P > 2048), runs concurrently */
     double ms_expand_wall;    /* fork->join wall time of the three concurrent expand launches */
     double ms_beam;           /* sum of beam-step kernel durations */
     double ms_materialize;    /* sum of materialize kernel durations */

@@ -27,7 +27,7 @@ class Result(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("ms_total", C.c_double), ("ms_expand", C.c_double), ("ms_expand_c1", C.c_double),
-                ("ms_expand_c2", C.c_double), ("ms_expand_wall", C.c_double), ("ms_beam", C.c_double),
+                ("ms_expand_c2", C.c_double), ("ms_expand_c3", C.c_double), ("ms_expand_wall", C.c_double), ("ms_beam", C.c_double),
                 ("ms_materialize", C.c_double), ("ms_output", C.c_double),
                 ("n_expand_launches", C.c_int64), ("n_steps", C.c_int64), ("n_node_expansions", C.c_int64),
                 ("n_nodes_created", C.c_int64), ("n_nodes_aliased", C.c_int64),

@@ -43,13 +43,14 @@ struct Buf {
     void *p = nullptr;
     size_t cap = 0;
 };
+struct PinBuf { void *p = nullptr; size_t cap = 0; };
 
 struct Ctx {
     bool ready = false;
     int device = -1;
     hipStream_t stream = nullptr;
-    hipStream_t cls_stream[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    hipStream_t cls_stream[NCLS] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[NCLS] = {};
     int n_cu = 256;
     EnergyTables *T = nullptr;
     float2 *tw = nullptr;
@@ -59,8 +60,9 @@ struct Ctx {
     Buf codes, seq_off, seq_len, beam, beam_n, done, nsteps, ch_parent, ch_combo, ch_dcal, ch_h, seen, seen_off,
         seen_cap, seen_cnt, st_seq, st_dcal, st_node0, st_nnodes, st_parent, st_h, st_db, st_cursor, st_combo, st_total, nd_seq, nd_pdcal,
         nd_n, nd_ci, nd_cj, nd_nbr, nd_canon, nd_ncand, nd_pos, nd_br, nd_cand, pos, br, db, cand, looptab, trec, tsid,
-        work0, work1, work2, mat, counters,
+        work0, work1, work2, work3, mat, counters,
         row_sid, row_off, out_db, out_dcal, dbg;
+    std::vector<PinBuf> pin_free;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     rafft_stats stats{};
@@ -107,7 +109,7 @@ int init_ctx(int device)
     HIPCHK(hipGetDeviceProperties(&prop, device));
     g.hbm_total = prop.totalGlobalMem;
     HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-    for (int c = 0; c < 3; c++) {
+    for (int c = 0; c < NCLS; c++) {
         HIPCHK(hipStreamCreateWithFlags(&g.cls_stream[c], hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&g.ev_join[c], hipEventDisableTiming));
     }
@@ -116,28 +118,28 @@ int init_ctx(int device)
     // energy tables
     EnergyTables *h = new EnergyTables();
     memset(h, 0, sizeof *h);
-    memcpy(h->stack, t04_stack, sizeof h->stack);
-    memcpy(h->mmH, t04_mismatch_hairpin, sizeof h->mmH);
-    memcpy(h->mmI, t04_mismatch_interior, sizeof h->mmI);
-    memcpy(h->mm1n, t04_mismatch_interior_1n, sizeof h->mm1n);
-    memcpy(h->mm23, t04_mismatch_interior_23, sizeof h->mm23);
-    memcpy(h->mmM, t04_mismatch_multi, sizeof h->mmM);
-    memcpy(h->mmE, t04_mismatch_exterior, sizeof h->mmE);
-    memcpy(h->d5, t04_dangle5, sizeof h->d5);
-    memcpy(h->d3, t04_dangle3, sizeof h->d3);
-    memcpy(h->int11, t04_int11, sizeof h->int11);
-    memcpy(h->int21, t04_int21, sizeof h->int21);
-    memcpy(h->int22, t04_int22, sizeof h->int22);
-    memcpy(h->hairpin, t04_hairpin, sizeof h->hairpin);
-    memcpy(h->bulge, t04_bulge, sizeof h->bulge);
-    memcpy(h->interior, t04_interior, sizeof h->interior);
-    h->ml_base = T04_ML_BASE; h->ml_closing = T04_ML_CLOSING; h->ml_intern = T04_ML_INTERN;
-    h->ninio = T04_NINIO; h->max_ninio = T04_MAX_NINIO; h->term_au = T04_TERMINAL_AU;
-    h->n_tri = T04_N_TRILOOPS; h->n_tetra = T04_N_TETRALOOPS; h->n_hexa = T04_N_HEXALOOPS;
-    for (int i = 0; i < T04_N_TRILOOPS; i++) { h->tri_key[i] = key_of(t04_triloops_seq[i], 5); h->tri_e[i] = t04_triloops_e[i]; }
-    for (int i = 0; i < T04_N_TETRALOOPS; i++) { h->tetra_key[i] = key_of(t04_tetraloops_seq[i], 6); h->tetra_e[i] = t04_tetraloops_e[i]; }
-    for (int i = 0; i < T04_N_HEXALOOPS; i++) { h->hexa_key[i] = key_of(t04_hexaloops_seq[i], 8); h->hexa_e[i] = t04_hexaloops_e[i]; }
-    for (int sz = 31; sz <= RAFFT_MAX_LEN + 1; sz++) h->logext[sz] = (int)(T04_LXC * log(sz / 30.));
+    memcpy(h->s.stack, t04_stack, sizeof h->s.stack);
+    memcpy(h->s.mmH, t04_mismatch_hairpin, sizeof h->s.mmH);
+    memcpy(h->s.mmI, t04_mismatch_interior, sizeof h->s.mmI);
+    memcpy(h->s.mm1n, t04_mismatch_interior_1n, sizeof h->s.mm1n);
+    memcpy(h->s.mm23, t04_mismatch_interior_23, sizeof h->s.mm23);
+    memcpy(h->s.mmM, t04_mismatch_multi, sizeof h->s.mmM);
+    memcpy(h->s.mmE, t04_mismatch_exterior, sizeof h->s.mmE);
+    memcpy(h->s.d5, t04_dangle5, sizeof h->s.d5);
+    memcpy(h->s.d3, t04_dangle3, sizeof h->s.d3);
+    memcpy(h->b.int11, t04_int11, sizeof h->b.int11);
+    memcpy(h->b.int21, t04_int21, sizeof h->b.int21);
+    memcpy(h->b.int22, t04_int22, sizeof h->b.int22);
+    memcpy(h->s.hairpin, t04_hairpin, sizeof h->s.hairpin);
+    memcpy(h->s.bulge, t04_bulge, sizeof h->s.bulge);
+    memcpy(h->s.interior, t04_interior, sizeof h->s.interior);
+    h->s.ml_base = T04_ML_BASE; h->s.ml_closing = T04_ML_CLOSING; h->s.ml_intern = T04_ML_INTERN;
+    h->s.ninio = T04_NINIO; h->s.max_ninio = T04_MAX_NINIO; h->s.term_au = T04_TERMINAL_AU;
+    h->s.n_tri = T04_N_TRILOOPS; h->s.n_tetra = T04_N_TETRALOOPS; h->s.n_hexa = T04_N_HEXALOOPS;
+    for (int i = 0; i < T04_N_TRILOOPS; i++) { h->s.tri_key[i] = key_of(t04_triloops_seq[i], 5); h->s.tri_e[i] = t04_triloops_e[i]; }
+    for (int i = 0; i < T04_N_TETRALOOPS; i++) { h->s.tetra_key[i] = key_of(t04_tetraloops_seq[i], 6); h->s.tetra_e[i] = t04_tetraloops_e[i]; }
+    for (int i = 0; i < T04_N_HEXALOOPS; i++) { h->s.hexa_key[i] = key_of(t04_hexaloops_seq[i], 8); h->s.hexa_e[i] = t04_hexaloops_e[i]; }
+    for (int sz = 31; sz <= RAFFT_MAX_LEN + 1; sz++) h->b.logext[sz] = (int)(T04_LXC * log(sz / 30.));
     HIPCHK(hipMalloc((void **)&g.T, sizeof(EnergyTables)));
     HIPCHK(hipMemcpy(g.T, h, sizeof(EnergyTables), hipMemcpyHostToDevice));
     delete h;
@@ -153,42 +155,46 @@ int init_ctx(int device)
     return 0;
 }
 
-struct ClsCfg { int nt, Pmax, Lmax, nmax, brmax, Kmax, lds, grid; };
+struct ClsCfg { int nt, Pmax, Lmax, nmax, brmax, Kmax, lds, grid; bool tab; };
 
-int class_cfg(int K, ClsCfg out[3])
+int class_cfg(int K, ClsCfg out[NCLS])
 {
-    const int P[3] = {CLS0_P, CLS1_P, MAX_P}, LM[3] = {CLS0_L, RAFFT_MAX_LEN, RAFFT_MAX_LEN}, NT[3] = {64, 256, 512};
-    const int BR[3] = {CLS0_BR, MAX_BR, MAX_BR};
-    for (int c = 0; c < 3; c++) {
+    const int P[NCLS] = {CLS0_P, CLS1_P, CLS2_P, MAX_P}, LM[NCLS] = {CLS01_L, CLS01_L, RAFFT_MAX_LEN, RAFFT_MAX_LEN};
+    const int NT[NCLS] = {64, 64, 256, 512}, BR[NCLS] = {CLS0_BR, CLS1_BR, MAX_BR, MAX_BR};
+    // LDS-resident energy tables cost occupancy and measured slower on MI355X; class 0 (tiny regions in
+    // their own kernel) is kept compiled for experiments but receives no work (see node_class)
+    const bool TAB[NCLS] = {true, getenv("RAFFT_TAB1") ? atoi(getenv("RAFFT_TAB1")) != 0 : false, false, false};
+    for (int c = 0; c < NCLS; c++) {
         int nmax = P[c] / 2;
         int Kmax = std::max(1, std::min(K, P[c] - 1));
-        ExpandLds l = expand_lds(P[c], LM[c], nmax, BR[c], Kmax);
+        ExpandLds l = expand_lds(P[c], LM[c], nmax, BR[c], Kmax, TAB[c]);
         int per_cu = std::max(1, std::min(32 / (NT[c] / 64), (160 * 1024) / l.total));
-        out[c] = {NT[c], P[c], LM[c], nmax, BR[c], Kmax, l.total, g.n_cu * per_cu};
+        out[c] = {NT[c], P[c], LM[c], nmax, BR[c], Kmax, l.total, g.n_cu * per_cu, TAB[c]};
         if (l.total > 160 * 1024)
             return fail(RAFFT_ERR_PARAM, "nb_mode too large for the LDS-resident expand kernel");
     }
     return 0;
 }
 
-template <int NT>
+template <int NT, bool TAB>
 int launch_expand(const Dev &d, int cls, const ClsCfg &cf, unsigned n_blocks, hipStream_t st)
 {
     static int lds_set = 0;
     if (cf.lds > lds_set) {
-        HIPCHK(hipFuncSetAttribute((const void *)expand_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, cf.lds));
+        HIPCHK(hipFuncSetAttribute((const void *)expand_kernel<NT, TAB>, hipFuncAttributeMaxDynamicSharedMemorySize, cf.lds));
         lds_set = cf.lds;
     }
-    hipLaunchKernelGGL(expand_kernel<NT>, dim3(n_blocks), dim3(NT), cf.lds, st, d, cls, cf.Pmax, cf.Lmax, cf.nmax, cf.brmax, cf.Kmax);
+    hipLaunchKernelGGL((expand_kernel<NT, TAB>), dim3(n_blocks), dim3(NT), cf.lds, st, d, cls, cf.Pmax, cf.Lmax, cf.nmax, cf.brmax, cf.Kmax);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
-int launch_expand_cls(const Dev &d, int cls, const ClsCfg cf[3], unsigned n_blocks, hipStream_t st)
+int launch_expand_cls(const Dev &d, int cls, const ClsCfg cf[NCLS], unsigned n_blocks, hipStream_t st)
 {
-    if (cls == 0) return launch_expand<64>(d, 0, cf[0], n_blocks, st);
-    if (cls == 1) return launch_expand<256>(d, 1, cf[1], n_blocks, st);
-    return launch_expand<512>(d, 2, cf[2], n_blocks, st);
+    if (cls == 0) return launch_expand<64, true>(d, 0, cf[0], n_blocks, st);
+    if (cls == 1) return cf[1].tab ? launch_expand<64, true>(d, 1, cf[1], n_blocks, st) : launch_expand<64, false>(d, 1, cf[1], n_blocks, st);
+    if (cls == 2) return launch_expand<256, false>(d, 2, cf[2], n_blocks, st);
+    return launch_expand<512, false>(d, 3, cf[3], n_blocks, st);
 }
 
 hipEvent_t next_event()
@@ -241,10 +247,32 @@ struct SeqIn { const char *s; int len; int idx; };
 
 struct HostOut {   // owner of a rafft_result
     std::vector<rafft_seq_result> seq;
-    std::vector<std::vector<int>> step_size, step_off, dcal;
-    std::vector<std::vector<char>> db;
+    std::vector<std::vector<int>> step_size, step_off;
+    std::vector<const char *> db_ptr;       // rows live in pinned chunks (one per wave): the D2H copy lands
+    std::vector<const int *> dcal_ptr;      // directly in the memory the caller reads
+    std::vector<PinBuf> chunks;
     rafft_result res;
 };
+
+// small pool of pinned host buffers, recycled across calls (hipHostMalloc is slow)
+PinBuf pin_acquire(size_t bytes)
+{
+    int best = -1;
+    for (size_t i = 0; i < g.pin_free.size(); i++)
+        if (g.pin_free[i].cap >= bytes && (best < 0 || g.pin_free[i].cap < g.pin_free[best].cap)) best = (int)i;
+    if (best >= 0) { PinBuf b = g.pin_free[best]; g.pin_free.erase(g.pin_free.begin() + best); return b; }
+    PinBuf b;
+    size_t want = bytes + bytes / 4 + 4096;
+    if (hipHostMalloc(&b.p, want, hipHostMallocDefault) != hipSuccess) { b.p = nullptr; return b; }
+    b.cap = want;
+    return b;
+}
+void pin_release(PinBuf b)
+{
+    if (!b.p) return;
+    if (g.pin_free.size() < 8) g.pin_free.push_back(b);
+    else { hipError_t e = hipHostFree(b.p); (void)e; }
+}
 
 struct SeamIn {     // rafft_expand_node: one region of one given structure
     DebugOut dbg;
@@ -259,6 +287,8 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
 {
     const size_t S = seqs.size();
     *ovf_bits = 0;
+    auto tw0 = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     std::vector<int> off(S), len(S);
     size_t sumL = 0;
     for (size_t i = 0; i < S; i++) { off[i] = (int)sumL; len[i] = seqs[i].len; sumL += seqs[i].len; }
@@ -268,7 +298,7 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
             char ch = seqs[i].s[x];
             codes[off[i] + x] = ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : ch == 'U' ? 4 : 0;
         }
-    ClsCfg cf[3];
+    ClsCfg cf[NCLS];
     if (int rc = class_cfg(p.nb_mode, cf)) return rc;
     Caps c = plan_caps(S, sumL, p, est);
     if ((size_t)c.sort_cap * 8 + MAX_PROD * 12 + (size_t)(p.max_stack + 4) * 36 + 256 > 150 * 1024)
@@ -288,7 +318,7 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
     ENS(pos, c.pos * 2); ENS(br, c.br * 4); ENS(db, c.db); ENS(cand, c.cand * 32);
     ENS(looptab, c.looptab * 8);
     ENS(trec, c.trec * 16); ENS(tsid, c.tsid * 4);
-    ENS(work0, c.work * 4); ENS(work1, c.work * 4); ENS(work2, c.work * 4); ENS(mat, c.mat * 4);
+    ENS(work0, c.work * 4); ENS(work1, c.work * 4); ENS(work2, c.work * 4); ENS(work3, c.work * 4); ENS(mat, c.mat * 4);
     ENS(counters, sizeof(Counters));
 #undef ENS
 
@@ -320,7 +350,7 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
     d.db = (uint8_t *)g.db.p; d.db_cap = c.db;
     d.cand = (Cand *)g.cand.p; d.cand_cap = c.cand;
     d.trec = (int4 *)g.trec.p; d.trec_cap = (uint32_t)c.trec; d.tsid = (int *)g.tsid.p; d.tsid_cap = c.tsid;
-    d.work[0] = (int *)g.work0.p; d.work[1] = (int *)g.work1.p; d.work[2] = (int *)g.work2.p; d.work_cap = (uint32_t)c.work;
+    d.work[0] = (int *)g.work0.p; d.work[1] = (int *)g.work1.p; d.work[2] = (int *)g.work2.p; d.work[3] = (int *)g.work3.p; d.work_cap = (uint32_t)c.work;
     d.mat = (int *)g.mat.p; d.mat_cap = (uint32_t)c.mat;
     d.c = (Counters *)g.counters.p;
     d.nd_base = S; d.nd_shard_cap = (c.nd - S) / NSHARD;
@@ -329,6 +359,15 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
     d.br_shard_cap = c.br / NSHARD; d.cand_shard_cap = c.cand / NSHARD;
     if (seam) d.dbg = seam->dbg;
     if (const char *rp = getenv("RAFFT_REP")) d.rep = atoi(rp);
+    static unsigned long long *prof_buf = nullptr;
+    if (getenv("RAFFT_TRACE") && atoi(getenv("RAFFT_TRACE")) >= 3) {
+        if (!prof_buf) HIPCHK(hipMalloc((void **)&prof_buf, 64));
+        HIPCHK(hipMemset(prof_buf, 0, 64));
+        d.prof = prof_buf;
+        int best = 0;
+        for (size_t i = 0; i < S; i++) if (len[i] > len[best]) best = (int)i;
+        d.prof_seq = best;
+    }
 
     hipStream_t st = g.stream;
     HIPCHK(hipMemcpyAsync(g.codes.p, codes.data(), sumL + 16, hipMemcpyHostToDevice, st));
@@ -371,6 +410,9 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
         HIPCHK(hipFuncSetAttribute((const void *)beam_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds));
         bs_lds_set = bs_lds;
     }
+    HIPCHK(hipStreamSynchronize(st));
+    const double ms_setup = since(tw0);
+    auto tw1 = std::chrono::steady_clock::now();
     const size_t cnt_work_off = offsetof(Counters, n_work);
     const size_t cnt_work_len = offsetof(Counters, overflow) - cnt_work_off;   // n_work[3], n_mat, next_work[3]
     const size_t hot_len = offsetof(Counters, node);
@@ -380,16 +422,19 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
         HIPCHK(hipEventRecord(g.ev_fork, st));
         Span wall{next_event(), next_event(), 4};
         HIPCHK(hipEventRecord(wall.a, st));
-        for (int cls = 2; cls >= 0; cls--) {   // big-LDS classes first: they need whole CUs, the small class fills the rest
-            hipStream_t cs = g.cls_stream[cls];
-            HIPCHK(hipStreamWaitEvent(cs, g.ev_fork, 0));
+        for (int cls = NCLS - 1; cls >= 1; cls--) {   // big-LDS classes first; class 0 is unused (node_class)
+            static const bool serial = getenv("RAFFT_SERIAL") && atoi(getenv("RAFFT_SERIAL"));
+            hipStream_t cs = serial ? st : g.cls_stream[cls];
+            if (!serial) HIPCHK(hipStreamWaitEvent(cs, g.ev_fork, 0));
             Span sp{next_event(), next_event(), 10 + cls};
             HIPCHK(hipEventRecord(sp.a, cs));
             if (int rc = launch_expand_cls(d, cls, cf, (unsigned)cf[cls].grid, cs)) return rc;
             HIPCHK(hipEventRecord(sp.b, cs));
             spans.push_back(sp);
-            HIPCHK(hipEventRecord(g.ev_join[cls], cs));
-            HIPCHK(hipStreamWaitEvent(st, g.ev_join[cls], 0));
+            if (!serial) {
+                HIPCHK(hipEventRecord(g.ev_join[cls], cs));
+                HIPCHK(hipStreamWaitEvent(st, g.ev_join[cls], 0));
+            }
         }
         HIPCHK(hipEventRecord(wall.b, st));
         spans.push_back(wall);
@@ -418,7 +463,15 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
             HIPCHK(hipEventRecord(sp.b, st));
             spans.push_back(sp);
         }
+        if (const char *tr = getenv("RAFFT_TRACE")) if (atoi(tr) >= 2) {
+            Counters h2;
+            HIPCHK(hipMemcpyAsync(&h2, g.counters.p, hot_len, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            fprintf(stderr, "[rafft] step %d: n_mat %u -> work %u %u %u %u\n", steps, hc.n_mat, h2.n_work[0], h2.n_work[1], h2.n_work[2], h2.n_work[3]);
+        }
     }
+    const double ms_loop = since(tw1);
+    auto tw2 = std::chrono::steady_clock::now();
     g.stats.n_steps = std::max<int64_t>(g.stats.n_steps, steps);
     if (*ovf_bits) {
         if (*ovf_bits & (OVF_PROD | OVF_SORT))
@@ -468,8 +521,12 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
             }
     }
     const size_t nrows = row_sid.size();
-    std::vector<char> all_db(tot_bytes + 1);
-    std::vector<int> all_dcal(nrows + 1);
+    const size_t dcal_off = ((size_t)tot_bytes + 63) & ~(size_t)63;
+    PinBuf chunk = pin_acquire(dcal_off + nrows * 4 + 64);
+    if (!chunk.p) return fail(RAFFT_ERR_HIP, "hipHostMalloc failed for the result buffer");
+    out.chunks.push_back(chunk);
+    char *all_db = (char *)chunk.p;
+    int *all_dcal = (int *)((char *)chunk.p + dcal_off);
     if (nrows) {
         if (int rc = ensure(g.row_sid, nrows * 4)) return rc;
         if (int rc = ensure(g.row_off, nrows * 8)) return rc;
@@ -485,8 +542,8 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(sp.b, st));
         spans.push_back(sp);
-        HIPCHK(hipMemcpyAsync(all_db.data(), g.out_db.p, (size_t)tot_bytes, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(all_dcal.data(), g.out_dcal.p, nrows * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(all_db, g.out_db.p, (size_t)tot_bytes, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(all_dcal, g.out_dcal.p, nrows * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
     }
     size_t row = 0;
@@ -498,12 +555,19 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
         out.step_size[gi].clear(); out.step_off[gi].clear();
         int o = 0;
         for (auto &r : v) { out.step_size[gi].push_back(r.z); out.step_off[gi].push_back(o); o += r.z; }
-        out.dcal[gi].assign(all_dcal.begin() + row, all_dcal.begin() + row + nst);
-        out.db[gi].assign(all_db.begin() + seq_db_off[i], all_db.begin() + seq_db_off[i] + (long long)nst * (len[i] + 1));
+        out.dcal_ptr[gi] = all_dcal + row;
+        out.db_ptr[gi] = all_db + seq_db_off[i];
         rafft_seq_result &sr = out.seq[gi];
         sr.status = RAFFT_OK; sr.length = len[i]; sr.n_steps = (int)v.size(); sr.n_structs = nst;
         row += nst;
     }
+    if (d.prof) {
+        unsigned long long pv[8];
+        HIPCHK(hipMemcpy(pv, d.prof, 64, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[rafft] beam_step stamps of the longest sequence (cycles): prepass %llu, product loop %llu, single phase %llu, sort %llu, survivors %llu over %llu steps\n",
+                pv[0], pv[1], pv[2], pv[3], pv[4], pv[5]);
+    }
+    if (getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] wave S=%zu setup %.2f ms, loop %.2f ms (%d steps), tail %.2f ms\n", S, ms_setup, ms_loop, steps, since(tw2));
     return 0;
 }
 
@@ -529,7 +593,11 @@ int fold_range(const rafft_params &p, std::vector<SeqIn> seqs, double est, HostO
     return rc;
 }
 
-void free_out(HostOut *o) { delete o; }
+void free_out(HostOut *o)
+{
+    for (auto &c : o->chunks) pin_release(c);
+    delete o;
+}
 
 } // namespace
 
@@ -558,7 +626,8 @@ int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs, 
     memset(&g.stats, 0, sizeof g.stats);
     g.ev_used = 0;
     HostOut *ho = new HostOut();
-    ho->seq.resize(n_seq); ho->step_size.resize(n_seq); ho->step_off.resize(n_seq); ho->dcal.resize(n_seq); ho->db.resize(n_seq);
+    ho->seq.resize(n_seq); ho->step_size.resize(n_seq); ho->step_off.resize(n_seq);
+    ho->dcal_ptr.assign(n_seq, nullptr); ho->db_ptr.assign(n_seq, nullptr);
     std::vector<SeqIn> good;
     for (int i = 0; i < n_seq; i++) {
         int L = lens ? lens[i] : (int)strlen(seqs[i]);
@@ -581,9 +650,10 @@ int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs, 
     for (auto &sp : spans) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
-            if (sp.kind == 10) g.stats.ms_expand += ms;
-            else if (sp.kind == 11) g.stats.ms_expand_c1 += ms;
+            if (sp.kind == 10) g.stats.ms_expand_c1 += ms;   /* class 0: unused */
+            else if (sp.kind == 11) g.stats.ms_expand += ms;   /* dominant kernel: regions with P <= 512 */
             else if (sp.kind == 12) g.stats.ms_expand_c2 += ms;
+            else if (sp.kind == 13) g.stats.ms_expand_c3 += ms;
             else if (sp.kind == 4) g.stats.ms_expand_wall += ms;
             else if (sp.kind == 1) g.stats.ms_beam += ms;
             else if (sp.kind == 2) g.stats.ms_materialize += ms;
@@ -593,7 +663,7 @@ int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs, 
     for (int i = 0; i < n_seq; i++) {
         rafft_seq_result &sr = ho->seq[i];
         sr.step_size = ho->step_size[i].data(); sr.step_off = ho->step_off[i].data();
-        sr.db = ho->db[i].data(); sr.dcal = ho->dcal[i].data();
+        sr.db = ho->db_ptr[i]; sr.dcal = ho->dcal_ptr[i];
     }
     ho->res.n_seq = n_seq; ho->res.seq = ho->seq.data(); ho->res._owner = ho;
     *out_ = &ho->res;
@@ -603,7 +673,10 @@ int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs, 
 
 void rafft_free_result(rafft_result *r)
 {
-    if (r && r->_owner) free_out((HostOut *)r->_owner);
+    if (r && r->_owner) {
+        std::lock_guard<std::mutex> lk(g.mu);
+        free_out((HostOut *)r->_owner);
+    }
 }
 
 int rafft_get_stats(rafft_stats *o)
@@ -731,7 +804,7 @@ int rafft_expand_node(const rafft_params *p, const char *seq, const char *db, co
     dbg.corval = (double *)b; b += 8 * K; dbg.score = (double *)b;
     std::vector<SeqIn> one{{seq, L, 0}};
     HostOut ho;
-    ho.seq.resize(1); ho.step_size.resize(1); ho.step_off.resize(1); ho.dcal.resize(1); ho.db.resize(1);
+    ho.seq.resize(1); ho.step_size.resize(1); ho.step_off.resize(1); ho.dcal_ptr.assign(1, nullptr); ho.db_ptr.assign(1, nullptr);
     unsigned ovf = 0;
     std::vector<Span> spans;
     g.ev_used = 0;

@@ -11,20 +11,28 @@
 
 #define RAFFT_MAX_LEN 4096
 
-struct EnergyTables {
+// Small, hot tables (3.4 KB): copied into LDS by the expand kernel of the smallest size class.
+struct SmallT {
     int16_t stack[7][7];
     int16_t mmH[7][5][5], mmI[7][5][5], mm1n[7][5][5], mm23[7][5][5], mmM[7][5][5], mmE[7][5][5];
     int16_t d5[7][5], d3[7][5];
-    int16_t int11[7][7][5][5];
-    int16_t int21[7][7][5][5][5];
-    int16_t int22[7][7][5][5][5][5];
     int32_t hairpin[31], bulge[31], interior[31];
     int32_t ml_base, ml_closing, ml_intern, ninio, max_ninio, term_au;
     int32_t n_tri, n_tetra, n_hexa;
     uint32_t tri_key[4];   int32_t tri_e[4];
     uint32_t tetra_key[32]; int32_t tetra_e[32];
     uint32_t hexa_key[8];  int32_t hexa_e[8];
+};
+// Big, rarely hit tables stay in HBM/L2.
+struct BigT {
+    int16_t int11[7][7][5][5];
+    int16_t int21[7][7][5][5][5];
+    int16_t int22[7][7][5][5][5][5];
     int32_t logext[RAFFT_MAX_LEN + 2];   // (int)(lxc*log(size/30.)), host libm, size > 30
+};
+struct EnergyTables {
+    SmallT s;
+    BigT b;
 };
 
 __device__ __constant__ static const int8_t kPairType[5][5] = {
@@ -41,9 +49,9 @@ __device__ __forceinline__ uint32_t loop_key(const uint8_t *S, int i, int m)
     return k;
 }
 
-__device__ inline int e_hairpin(const EnergyTables *T, int size, int type, const uint8_t *S, int ci, int cj)
+__device__ inline int e_hairpin(const SmallT *T, const BigT *B, int size, int type, const uint8_t *S, int ci, int cj)
 {
-    int e = (size <= 30) ? T->hairpin[size] : T->hairpin[30] + T->logext[size];
+    int e = (size <= 30) ? T->hairpin[size] : T->hairpin[30] + B->logext[size];
     if (size < 3) return e;
     if (size == 4) {
         uint32_t k = loop_key(S, ci, 6);
@@ -62,13 +70,13 @@ __device__ inline int e_hairpin(const EnergyTables *T, int size, int type, const
     return e + T->mmH[type][S[ci + 1]][S[cj - 1]];
 }
 
-__device__ inline int e_intloop(const EnergyTables *T, int n1, int n2, int type, int type2,
+__device__ inline int e_intloop(const SmallT *T, const BigT *B, int n1, int n2, int type, int type2,
                                 int si1, int sj1, int sp1, int sq1)
 {
     int nl = n1 > n2 ? n1 : n2, ns = n1 > n2 ? n2 : n1, e, u;
     if (nl == 0) return T->stack[type][type2];
     if (ns == 0) {
-        e = (nl <= 30) ? T->bulge[nl] : T->bulge[30] + T->logext[nl];
+        e = (nl <= 30) ? T->bulge[nl] : T->bulge[30] + B->logext[nl];
         if (nl == 1) e += T->stack[type][type2];
         else {
             if (type > 2) e += T->term_au;
@@ -77,19 +85,19 @@ __device__ inline int e_intloop(const EnergyTables *T, int n1, int n2, int type,
         return e;
     }
     if (ns == 1) {
-        if (nl == 1) return T->int11[type][type2][si1][sj1];
+        if (nl == 1) return B->int11[type][type2][si1][sj1];
         if (nl == 2) {
-            if (n1 == 1) return T->int21[type][type2][si1][sq1][sj1];
-            return T->int21[type2][type][sq1][si1][sp1];
+            if (n1 == 1) return B->int21[type][type2][si1][sq1][sj1];
+            return B->int21[type2][type][sq1][si1][sp1];
         }
         u = nl + 1;
-        e = (u <= 30) ? T->interior[u] : T->interior[30] + T->logext[u];
+        e = (u <= 30) ? T->interior[u] : T->interior[30] + B->logext[u];
         e += min(T->max_ninio, (nl - ns) * T->ninio);
         e += T->mm1n[type][si1][sj1] + T->mm1n[type2][sq1][sp1];
         return e;
     }
     if (ns == 2) {
-        if (nl == 2) return T->int22[type][type2][si1][sp1][sq1][sj1];
+        if (nl == 2) return B->int22[type][type2][si1][sp1][sq1][sj1];
         if (nl == 3) {
             e = T->interior[5] + T->ninio;
             e += T->mm23[type][si1][sj1] + T->mm23[type2][sq1][sp1];
@@ -97,14 +105,14 @@ __device__ inline int e_intloop(const EnergyTables *T, int n1, int n2, int type,
         }
     }
     u = nl + ns;
-    e = (u <= 30) ? T->interior[u] : T->interior[30] + T->logext[u];
+    e = (u <= 30) ? T->interior[u] : T->interior[30] + B->logext[u];
     e += min(T->max_ninio, (nl - ns) * T->ninio);
     e += T->mmI[type][si1][sj1] + T->mmI[type2][sq1][sp1];
     return e;
 }
 
 // si1/sj1 < 0: neighbour does not exist (sequence end)
-__device__ inline int e_stem(const EnergyTables *T, int type, int si1, int sj1, bool ext)
+__device__ inline int e_stem(const SmallT *T, int type, int si1, int sj1, bool ext)
 {
     int e = 0;
     if (si1 >= 0 && sj1 >= 0) e += ext ? T->mmE[type][si1][sj1] : T->mmM[type][si1][sj1];
@@ -120,7 +128,7 @@ __device__ inline int e_stem(const EnergyTables *T, int type, int si1, int sj1, 
 // in the same coordinates (S may be a pointer shifted by a window base).
 // `bad` is set when a non-canonical pair is met (cannot happen inside the fold).
 template <class PV>
-__device__ inline int loop_energy(const EnergyTables *T, const uint8_t *S, int L, const PV &pv, int ci, int cj, int *bad)
+__device__ inline int loop_energy(const SmallT *T, const BigT *B, const uint8_t *S, int L, const PV &pv, int ci, int cj, int *bad)
 {
     if (ci < 0) {
         int e = 0;
@@ -144,11 +152,11 @@ __device__ inline int loop_energy(const EnergyTables *T, const uint8_t *S, int L
         nbr++;
         p = q + 1;
     }
-    if (nbr == 0) return e_hairpin(T, cj - ci - 1, type, S, ci, cj);
+    if (nbr == 0) return e_hairpin(T, B, cj - ci - 1, type, S, ci, cj);
     if (nbr == 1) {
         int t2 = pair_type(S[p1], S[q1]);
         if (!t2) { *bad = 1; return 0; }
-        return e_intloop(T, p1 - ci - 1, cj - q1 - 1, type, kRtype[t2], S[ci + 1], S[cj - 1], S[p1 - 1], S[q1 + 1]);
+        return e_intloop(T, B, p1 - ci - 1, cj - q1 - 1, type, kRtype[t2], S[ci + 1], S[cj - 1], S[p1 - 1], S[q1 + 1]);
     }
     int e = 0, u = cj - ci - 1;
     for (int p = ci + 1; p < cj;) {
@@ -203,7 +211,7 @@ struct BrList {
     }
 };
 
-__device__ inline int loop_energy_br(const EnergyTables *T, const uint8_t *S, int L, int ci, int cj, const BrList &bl)
+__device__ inline int loop_energy_br(const SmallT *T, const BigT *B, const uint8_t *S, int L, int ci, int cj, const BrList &bl)
 {
     const int k = bl.count();
     if (ci < 0) {
@@ -216,11 +224,11 @@ __device__ inline int loop_energy_br(const EnergyTables *T, const uint8_t *S, in
         return e;
     }
     const int type = pair_type(S[ci], S[cj]);
-    if (k == 0) return e_hairpin(T, cj - ci - 1, type, S, ci, cj);
+    if (k == 0) return e_hairpin(T, B, cj - ci - 1, type, S, ci, cj);
     if (k == 1) {
         int p, q;
         bl.get(0, p, q);
-        return e_intloop(T, p - ci - 1, cj - q - 1, type, kRtype[pair_type(S[p], S[q])], S[ci + 1], S[cj - 1], S[p - 1], S[q + 1]);
+        return e_intloop(T, B, p - ci - 1, cj - q - 1, type, kRtype[pair_type(S[p], S[q])], S[ci + 1], S[cj - 1], S[p - 1], S[q + 1]);
     }
     int e = 0, u = cj - ci - 1;
     for (int i = 0; i < k; i++) {

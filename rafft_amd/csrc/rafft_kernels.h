@@ -31,16 +31,17 @@ struct alignas(16) Cand {
 static_assert(sizeof(Cand) == 32, "Cand must be 32 bytes");
 
 #define NSHARD 64
+#define NCLS 4
 struct ShardCtr { unsigned long long v; unsigned long long pad[7]; };   // one 64-byte line each
 
 struct Counters {
     // hot part: read back by the host once per folding step (first 64 bytes)
-    unsigned int n_work[3];     // expand work items per size class (filled by dedupe_kernel)
-    unsigned int n_mat;         // structures to materialize (filled by beam_step_kernel)
-    unsigned int next_work[3];  // dynamic fetch cursors of the persistent expand kernels
-    unsigned int overflow;      // bit mask of which arena overflowed
+    unsigned int n_work[NCLS];     // expand work items per size class (filled by dedupe_kernel)
+    unsigned int n_mat;            // structures to materialize (filled by beam_step_kernel)
+    unsigned int next_work[NCLS];  // dynamic fetch cursors of the persistent expand kernels
+    unsigned int overflow;         // bit mask of which arena overflowed
     unsigned int n_done;
-    unsigned int pad_[7];
+    unsigned int pad_[5];
     unsigned long long n_struct, seen_top, trec_n, tsid_top;
     // statistics
     unsigned long long n_expand, sum_n, sum_lags, n_children, sum_struct_len, n_alias, sum_nbr;
@@ -91,18 +92,22 @@ struct Dev {
     int4 *trec; uint32_t trec_cap;
     int *tsid; uint64_t tsid_cap;
     // work lists
-    int *work[3]; uint32_t work_cap;
+    int *work[NCLS]; uint32_t work_cap;
     int *mat; uint32_t mat_cap;
     Counters *c;
     DebugOut dbg;
+    unsigned long long *prof; int prof_seq;   // diagnostic stamps of beam_step_kernel (RAFFT_TRACE=3)
     int rep;                     // profiling only (RAFFT_REP env): bit k doubles phase k of expand_kernel
 };
 
-// expand-kernel size classes
-#define CLS0_P 512
-#define CLS0_L 1280
-#define CLS0_BR 256
-#define CLS1_P 2048
+// expand-kernel size classes: 0 tiny (one wavefront, energy tables + twiddles in LDS),
+// 1 small (one wavefront), 2 medium (256 threads), 3 large (512 threads, one workgroup per CU)
+#define CLS0_P 128
+#define CLS0_BR 64
+#define CLS1_P 512
+#define CLS01_L 1280
+#define CLS1_BR 256
+#define CLS2_P 2048
 #define MAX_P 8192
 #define MAX_BR 1024
 #define MAX_PROD 512
@@ -111,17 +116,20 @@ __host__ __device__ inline int next_pow2_ge(int x) { int p = 2; while (p < x) p 
 __host__ __device__ inline int node_class(int n, int L, int nbr)
 {
     int P = next_pow2_ge(2 * n - 1);
-    if (P <= CLS0_P && L <= CLS0_L && nbr <= CLS0_BR) return 0;
-    if (P <= CLS1_P) return 1;
-    return 2;
+    // class 0 is kept empty: measured on MI355X, running the tiny regions (P <= 128) in their own
+    // persistent kernel beside class 1 oversubscribes the wave slots and is slower than one kernel
+    if (L <= CLS01_L && P <= CLS1_P && nbr <= CLS1_BR) return 1;
+    if (P <= CLS2_P) return 2;
+    return 3;
 }
 
 // LDS layout of the expand kernel (bytes).  Region A is time-shared between the FFT
 // buffers and the sort keys; region B holds the loop itself.
 struct ExpandLds {
-    int offA, szA, off_pos, off_code, off_S, off_br, off_rk, off_nb, off_mi, off_mj, off_dd, off_keep, off_w, off_misc, total;
+    int offA, szA, off_pos, off_code, off_S, off_br, off_rk, off_nb, off_mi, off_mj, off_dd, off_keep, off_w, off_misc,
+        off_tab, off_tw, total;
 };
-__host__ __device__ inline ExpandLds expand_lds(int Pmax, int Lmax, int nmax, int brmax, int Kmax)
+__host__ __device__ inline ExpandLds expand_lds(int Pmax, int Lmax, int nmax, int brmax, int Kmax, bool tab_lds)
 {
     ExpandLds l;
     auto al = [](int x) { return (x + 15) & ~15; };
@@ -139,7 +147,9 @@ __host__ __device__ inline ExpandLds expand_lds(int Pmax, int Lmax, int nmax, in
     l.off_dd = o; o += al(4 * Kmax);
     l.off_keep = o; o += al(2 * Kmax);
     l.off_w = o; o += al(25 * 8);
-    l.off_misc = o; o += 64;
+    l.off_misc = o; o += 128;
+    l.off_tab = o; if (tab_lds) o += al((int)sizeof(SmallT));
+    l.off_tw = o; if (tab_lds) o += al(8 * (Pmax / 2));
     l.total = o;
     return l;
 }

@@ -65,13 +65,26 @@ struct PlainView {
 
 // ------------------------------------------------------------ expand kernel
 
-template <int NT>
+template <int NT, bool TAB_LDS>
 __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, int Lmax, int nmax, int brmax, int Kmax)
 {
     extern __shared__ __align__(16) unsigned char lds[];
-    const ExpandLds lay = expand_lds(Pmax, Lmax, nmax, brmax, Kmax);
+    const ExpandLds lay = expand_lds(Pmax, Lmax, nmax, brmax, Kmax, TAB_LDS);
     const int tid = threadIdx.x;
-    const EnergyTables *T = d.T;
+    const SmallT *T = &d.T->s;
+    const BigT *B = &d.T->b;
+    const float2 *tw = d.tw;
+    int twN = MAX_P;          // the twiddle table holds exp(-2 pi i m / twN), m < twN/2
+    if (TAB_LDS) {            // persistent workgroup: hot energy tables and twiddles live in LDS
+        int *dst = (int *)(lds + lay.off_tab);
+        const int *src = (const int *)&d.T->s;
+        for (int i = tid; i < (int)(sizeof(SmallT) / 4); i += NT) dst[i] = src[i];
+        float2 *twl = (float2 *)(lds + lay.off_tw);
+        for (int m = tid; m < Pmax / 2; m += NT) twl[m] = d.tw[m * (MAX_P / Pmax)];
+        T = (const SmallT *)dst;
+        tw = twl;
+        twN = Pmax;
+    }
     uint16_t *pos = (uint16_t *)(lds + lay.off_pos);
     uint8_t *code = lds + lay.off_code;
     uint8_t *Sl = lds + lay.off_S;
@@ -132,11 +145,11 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
             }
             __syncthreads();
             for (int s = P >> 1; s >= 1; s >>= 1) {       // DIF, natural in -> bit-reversed out
-                const int tws = (MAX_P / 2) / s;
+                const int tws = (twN / 2) / s;
                 for (int b = tid; b < (P >> 1); b += NT) {
                     int off = b & (s - 1);
                     int j = ((b - off) << 1) + off;
-                    float2 w = d.tw[off * tws];
+                    float2 w = tw[off * tws];
                     float2 a = z1[j], bb = z1[j + s];
                     z1[j] = make_float2(a.x + bb.x, a.y + bb.y);
                     z1[j + s] = cmul(make_float2(a.x - bb.x, a.y - bb.y), w);
@@ -165,11 +178,11 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
             }
             __syncthreads();
             for (int s = 1; s < P; s <<= 1) {             // DIT inverse, bit-reversed in -> natural out
-                const int tws = (MAX_P / 2) / s;
+                const int tws = (twN / 2) / s;
                 for (int b = tid; b < (P >> 1); b += NT) {
                     int off = b & (s - 1);
                     int j = ((b - off) << 1) + off;
-                    float2 w = d.tw[off * tws];
+                    float2 w = tw[off * tws];
                     float2 a = z1[j], bb = cmulc(z1[j + s], w);
                     z1[j] = make_float2(a.x + bb.x, a.y + bb.y);
                     z1[j + s] = make_float2(a.x - bb.x, a.y - bb.y);
@@ -204,6 +217,10 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
             for (int k = tid; k < P; k += NT) lagk[k] = (uint16_t)k;
             __syncthreads();
         }
+        // When every lag is searched anyway (2n-1 <= nb_mode) the ranking only breaks dE ties
+        // later on, so the sort is skipped and ties are resolved from (value, lag) directly.
+        const bool sorted = (m > Kp) || d.dbg.lag != nullptr;
+        if (sorted)
         for (int rep_ = 0; rep_ < 1 + ((d.rep >> 1) & 1); rep_++)
             for (int k2 = 2; k2 <= P; k2 <<= 1) {
                 for (int j = k2 >> 1; j > 0; j >>= 1) {
@@ -224,7 +241,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                 }
             }
         for (int r = tid; r < Kp; r += NT) {
-            rk[r] = lagk[r];
+            rk[r] = sorted ? lagk[r] : (uint16_t)r;
             if (d.dbg.lag) { d.dbg.lag[r] = lagk[r]; d.dbg.corval[r] = keyv[r]; }
         }
         if (tid == 0 && d.dbg.n_ranked) *d.dbg.n_ranked = Kp;
@@ -268,13 +285,13 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                     const int mi = wmi[r], mj = wmj[r];
                     const int a0 = pos[mi], b0 = pos[mj], ao = pos[mi - nb + 1], bo = pos[mj + nb - 1];
                     BrList all{brl, 0, nbr, 0, 0, 0, 0, 0};
-                    const int e_old = loop_energy_br(T, Sl, L, ci, cj, all);
+                    const int e_old = loop_energy_br(T, B, Sl, L, ci, cj, all);
                     int lo = br_lower(brl, nbr, a0), hi = br_lower(brl, nbr, b0);
                     const int lo_o = br_lower(brl, nbr, ao), hi_o = br_lower(brl, nbr, bo);
                     BrList outer{brl, 0, lo_o, hi_o, nbr, 1, ao, bo};
-                    int e_new = loop_energy_br(T, Sl, L, ci, cj, outer);
+                    int e_new = loop_energy_br(T, B, Sl, L, ci, cj, outer);
                     BrList inner{brl, lo, hi, 0, 0, 0, 0, 0};
-                    e_new += loop_energy_br(T, Sl, L, a0, b0, inner);
+                    e_new += loop_energy_br(T, B, Sl, L, a0, b0, inner);
                     int pa = a0, pb = b0;
                     for (int t = 1; t < nb; t++) {
                         const int a = pos[mi - t], b = pos[mj + t];
@@ -283,7 +300,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                         else {
                             const int lo2 = br_lower(brl, nbr, a), hi2 = br_lower(brl, nbr, b);
                             BrList mid{brl, lo2, lo, hi, hi2, 1, pa, pb};
-                            e_new += loop_energy_br(T, Sl, L, a, b, mid);
+                            e_new += loop_energy_br(T, B, Sl, L, a, b, mid);
                             lo = lo2; hi = hi2;
                         }
                         pa = a; pb = b;
@@ -299,8 +316,32 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         __syncthreads();
 
         // ---- stable sort of the kept candidates by dE (ties keep lag-rank order), emit
+        // compact the kept lags (keep[] becomes the list of their indices)
         int nkept = 0;
-        for (int r = 0; r < Kp; r++) nkept += keep[r];   // LDS broadcast reads
+        {
+            int *wave_tot = misc + 16;
+            const int lane = tid & 63, wv = tid >> 6;
+            for (int base = 0; base < Kp; base += NT) {
+                const int r = base + tid;
+                const int f = (r < Kp) ? keep[r] : 0;
+                __syncthreads();                      // everyone has read keep[] of this slab
+                const unsigned long long bal = __ballot(f != 0);
+                int pre = __popcll(bal & ((1ULL << lane) - 1));
+                if (NT > 64) {
+                    if (lane == 0) wave_tot[wv] = __popcll(bal);
+                    __syncthreads();
+                    int tot = 0;
+                    for (int w = 0; w < NT / 64; w++) { if (w < wv) pre += wave_tot[w]; tot += wave_tot[w]; }
+                    if (f) keep[nkept + pre] = (uint16_t)r;   // nkept + pre <= r: never clobbers an unread flag
+                    nkept += tot;
+                    __syncthreads();
+                } else {
+                    if (f) keep[nkept + pre] = (uint16_t)r;
+                    nkept += __popcll(bal);
+                }
+            }
+            __syncthreads();
+        }
         if (tid == 0) {
             unsigned long long base = 0;
             misc[2] = 0;
@@ -316,11 +357,20 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         const unsigned long long cbase = *(unsigned long long *)&misc[4];
         const bool ovf = misc[2] != 0;
         if (!ovf) {
-            for (int r = tid; r < Kp; r += NT) {
-                if (!keep[r]) continue;
-                int my = dd[r], rank = 0;
-                for (int q = 0; q < Kp; q++)
-                    if (keep[q] && (dd[q] < my || (dd[q] == my && q < r))) rank++;
+            for (int x = tid; x < nkept; x += NT) {
+                const int r = keep[x];
+                const int my = dd[r];
+                const double myv = keyv[r];
+                int rank = 0;
+                for (int y = 0; y < nkept; y++) {
+                    const int q = keep[y];
+                    const int oq = dd[q];
+                    bool before;
+                    if (oq != my) before = oq < my;
+                    else if (sorted) before = q < r;
+                    else { const double qv = keyv[q]; before = (qv > myv) || (qv == myv && q > r); }
+                    rank += (q != r && before) ? 1 : 0;
+                }
                 int mi = wmi[r], mj = wmj[r], nb = wnb[r];
                 uint64_t h1 = 0, h2 = 0;
                 for (int t = 0; t < nb; t++) {
@@ -399,6 +449,9 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int sq = blockIdx.x;
     if (d.done[sq]) return;
+    const bool prof = d.prof && sq == d.prof_seq && tid == 0;   // diagnostic stamps (RAFFT_TRACE=3)
+    unsigned long long tprev = prof ? clock64() : 0;
+#define STAMP(k) do { if (prof) { unsigned long long tn_ = clock64(); d.prof[k] += tn_ - tprev; tprev = tn_; } } while (0)
     const int nbeam = d.beam_n[sq];
     int *beam = d.beam + (size_t)sq * d.B;
     for (int i = tid; i < nbeam; i += BS_NT) oldbeam[i] = beam[i];
@@ -424,6 +477,11 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
         const int sid = oldbeam[b];
         const unsigned long long cur0 = d.st_cursor[sid], tot0 = d.st_total[sid];
         if (tot0 && cur0 >= tot0) { if (lane == 0) pinfo[b].flag = 1; continue; }
+        const int curbit = cur0 > 0 ? 2 : 0;
+        if (tot0 && cur0 > 0) {      // expanded in an earlier step: only the cursor/total matter now
+            if (lane == 0) { ParentInfo pi; pi.flag = curbit; pi.total = tot0; pi.h1 = pi.h2 = 0; pi.dcal0 = 0; pinfo[b] = pi; }
+            continue;
+        }
         const int node0 = d.st_node0[sid], nn = d.st_nnodes[sid];
         unsigned long long tot = 1, h1 = 0, h2 = 0;
         int dc = 0, np = 0;
@@ -446,7 +504,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
         }
         if (lane == 0) {
             ParentInfo pi;
-            pi.flag = np == 0 ? 1 : 0;
+            pi.flag = (np == 0 ? 1 : 0) | curbit;
             pi.total = tot;
             pi.h1 = d.st_h[2 * (size_t)sid] + h1; pi.h2 = d.st_h[2 * (size_t)sid + 1] + h2;
             pi.dcal0 = d.st_dcal[sid] + dc;
@@ -456,70 +514,21 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
     }
     __syncthreads();
 
+    STAMP(0);
     uint64_t *stab = d.seen + 2 * d.seen_off[sq];
     uint32_t scap = d.seen_cap[sq], scnt = d.seen_cnt[sq];
     const size_t chb = (size_t)sq * d.ch_cap;
     int nb_branch = 0, nchild = 0;
 
+    int single_from = nbeam;
     for (int b = 0; b < nbeam; b++) {
-        if (pinfo[b].flag) continue;
+        // once nb_branch >= max_branch every later parent only replays its combo 0
+        // (rafft/rafft.py:202-203): those are handled together, in parallel, after this loop
+        if (nb_branch >= d.max_branch) { single_from = b; break; }
+        if (pinfo[b].flag & 1) continue;
         const int sid = oldbeam[b];
         unsigned long long cur = d.st_cursor[sid];
         const unsigned long long total = pinfo[b].total;
-        const bool single = nb_branch >= d.max_branch;   // rafft/rafft.py:202-203: one combo, then break
-        if (single && cur > 0) continue;                  // combo 0 is already in `seen`
-        // grow the seen set if the next chunk could push the load factor past 1/2
-        {
-            const unsigned long long left = total - cur;
-            const int chunk = single ? 1 : (left < BS_NT ? (int)left : BS_NT);
-            if ((unsigned long long)(scnt + chunk) * 2 > scap) {
-                uint32_t ncap = scap;
-                while ((unsigned long long)(scnt + BS_NT) * 2 > ncap) ncap <<= 1;
-                if (tid == 0) {
-                    unsigned long long o = atomicAdd(&d.c->seen_top, (unsigned long long)ncap);
-                    if (o + ncap > d.seen_cap_total) { atomicOr(&d.c->overflow, OVF_SEEN); *(unsigned long long *)&sh[8] = ~0ULL; }
-                    else *(unsigned long long *)&sh[8] = o;
-                }
-                __syncthreads();
-                unsigned long long o = *(unsigned long long *)&sh[8];
-                __syncthreads();
-                if (o == ~0ULL) { d.done[sq] = 1; return; }
-                uint64_t *ntab = d.seen + 2 * o;
-                for (uint32_t i = tid; i < scap; i += BS_NT) {
-                    uint64_t k1 = stab[2 * (uint64_t)i];
-                    if (k1) seen_insert(ntab, ncap, k1, stab[2 * (uint64_t)i + 1]);
-                }
-                __syncthreads();
-                stab = ntab; scap = ncap;
-                if (tid == 0) { d.seen_off[sq] = o; d.seen_cap[sq] = ncap; }
-            }
-        }
-        if (single) {
-            // exactly combo 0 of this parent (precomputed); accepted if its structure is new
-            if (tid == 0) {
-                uint64_t h1 = pinfo[b].h1, h2 = pinfo[b].h2;
-                if (h1 == 0) h1 = 1;
-                if (h2 == 0) h2 = 1;
-                int isnew = seen_lookup(stab, scap, h1, h2) ? 0 : 1;
-                if (isnew) {
-                    if (nchild < d.ch_cap) {
-                        d.ch_parent[chb + nchild] = (uint16_t)b;
-                        d.ch_combo[chb + nchild] = 0;
-                        d.ch_dcal[chb + nchild] = pinfo[b].dcal0;
-                        d.ch_h[2 * (chb + nchild)] = h1;
-                        d.ch_h[2 * (chb + nchild) + 1] = h2;
-                    } else atomicOr(&d.c->overflow, OVF_SORT);
-                    seen_insert(stab, scap, h1, h2);
-                }
-                sh[20] = isnew;
-                d.st_cursor[sid] = 1; d.st_total[sid] = total;
-            }
-            __syncthreads();
-            const int isnew = sh[20];
-            __syncthreads();
-            nchild += isnew; nb_branch += isnew; scnt += isnew;
-            continue;
-        }
         // productive regions in node order (rafft/rafft.py:166-171)
         const int node0 = d.st_node0[sid], nn = d.st_nnodes[sid];
         int mprod = 0;
@@ -537,6 +546,8 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
         if (mprod > MAX_PROD) { if (tid == 0) atomicOr(&d.c->overflow, OVF_PROD); mprod = MAX_PROD; }
         const int par_dcal = d.st_dcal[sid];
         const uint64_t ph1 = d.st_h[2 * (size_t)sid], ph2 = d.st_h[2 * (size_t)sid + 1];
+        int *digit = (int *)skey;              // [mprod] digits of the chunk's first combo (sort keys not live yet)
+        unsigned long long *bsum = (unsigned long long *)(digit + MAX_PROD);   // [3] sums over the base digits
         while (cur < total) {
             unsigned long long left = total - cur;
             int chunk = left < BS_NT ? (int)left : BS_NT;
@@ -562,25 +573,47 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
                 if (tid == 0) { d.seen_off[sq] = o; d.seen_cap[sq] = ncap; }
             }
             // decode combo `cur + tid` (itertools.product: last list fastest, rafft.py:180)
+            // mixed-radix digits of `cur` once per chunk (thread 0), sums over them by the whole block;
+            // thread t then adds t with carry: only the last few digits differ from the base
+            if (tid == 0) {
+                unsigned long long idx = cur;
+                for (int k = mprod - 1; k >= 0; k--) {
+                    unsigned long long c = (unsigned long long)prod_cnt[k], q = idx / c;
+                    digit[k] = (int)(idx - q * c);
+                    idx = q;
+                }
+            }
+            __syncthreads();
+            {
+                unsigned long long a1 = 0, a2 = 0; long long ad = 0;
+                for (int k = tid; k < mprod; k += BS_NT) {
+                    const Cand *cp = &d.cand[prod_off[k] + digit[k]];
+                    a1 += cp->h1; a2 += cp->h2; ad += cp->ddcal;
+                }
+                for (int o = 32; o > 0; o >>= 1) {
+                    a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); ad += __shfl_xor(ad, o, 64);
+                }
+                if (lane == 0) { bsum[4 + 3 * wv] = a1; bsum[5 + 3 * wv] = a2; bsum[6 + 3 * wv] = (unsigned long long)ad; }
+                __syncthreads();
+                if (tid == 0) {
+                    unsigned long long t1 = 0, t2 = 0, td = 0;
+                    for (int w = 0; w < BS_NT / 64; w++) { t1 += bsum[4 + 3 * w]; t2 += bsum[5 + 3 * w]; td += bsum[6 + 3 * w]; }
+                    bsum[0] = t1; bsum[1] = t2; bsum[2] = td;
+                }
+                __syncthreads();
+            }
             int isnew = 0, cd_dcal = 0;
             uint64_t h1 = 0, h2 = 0;
             if (tid < chunk) {
-                unsigned long long idx = cur + tid;
-                h1 = ph1; h2 = ph2; cd_dcal = par_dcal;
-                if (total <= 0xffffffffULL) {
-                    uint32_t ix = (uint32_t)idx;
-                    for (int k = mprod - 1; k >= 0; k--) {
-                        uint32_t c = (uint32_t)prod_cnt[k], q = ix / c, r = ix - q * c;
-                        ix = q;
-                        const Cand *cp = &d.cand[prod_off[k] + r];
-                        cd_dcal += cp->ddcal; h1 += cp->h1; h2 += cp->h2;
-                    }
-                } else {
-                    for (int k = mprod - 1; k >= 0; k--) {
-                        unsigned long long c = (unsigned long long)prod_cnt[k], q = idx / c, r = idx - q * c;
-                        idx = q;
-                        const Cand *cp = &d.cand[prod_off[k] + r];
-                        cd_dcal += cp->ddcal; h1 += cp->h1; h2 += cp->h2;
+                h1 = ph1 + bsum[0]; h2 = ph2 + bsum[1]; cd_dcal = par_dcal + (int)(long long)bsum[2];
+                unsigned int carry = (unsigned int)tid;
+                for (int k = mprod - 1; k >= 0 && carry; k--) {
+                    const unsigned int c = (unsigned int)prod_cnt[k], v = (unsigned int)digit[k] + carry;
+                    const unsigned int nd = v % c;
+                    carry = v / c;
+                    if ((int)nd != digit[k]) {
+                        const Cand *cn = &d.cand[prod_off[k] + nd], *co = &d.cand[prod_off[k] + digit[k]];
+                        cd_dcal += cn->ddcal - co->ddcal; h1 += cn->h1 - co->h1; h2 += cn->h2 - co->h2;
                     }
                 }
                 if (h1 == 0) h1 = 1;
@@ -619,6 +652,68 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
         }
         if (tid == 0) { d.st_cursor[sid] = cur; d.st_total[sid] = total; }
     }
+    STAMP(1);
+    if (single_from < nbeam) {
+        // ---- parents in "one combo then break" mode: combo 0 of each (from the prepass), accepted in
+        // beam order if its structure is new; a parent whose cursor already moved replays a known combo
+        const int nrest = nbeam - single_from;
+        if ((unsigned long long)(scnt + nrest) * 2 > scap) {
+            uint32_t ncap = scap;
+            while ((unsigned long long)(scnt + nrest + BS_NT) * 2 > ncap) ncap <<= 1;
+            if (tid == 0) {
+                unsigned long long o = atomicAdd(&d.c->seen_top, (unsigned long long)ncap);
+                if (o + ncap > d.seen_cap_total) { atomicOr(&d.c->overflow, OVF_SEEN); *(unsigned long long *)&sh[8] = ~0ULL; }
+                else *(unsigned long long *)&sh[8] = o;
+            }
+            __syncthreads();
+            unsigned long long o = *(unsigned long long *)&sh[8];
+            __syncthreads();
+            if (o == ~0ULL) { d.done[sq] = 1; return; }
+            uint64_t *ntab = d.seen + 2 * o;
+            for (uint32_t i = tid; i < scap; i += BS_NT) {
+                uint64_t k1 = stab[2 * (uint64_t)i];
+                if (k1) seen_insert(ntab, ncap, k1, stab[2 * (uint64_t)i + 1]);
+            }
+            __syncthreads();
+            stab = ntab; scap = ncap;
+            if (tid == 0) { d.seen_off[sq] = o; d.seen_cap[sq] = ncap; }
+        }
+        for (int base = single_from; base < nbeam; base += BS_NT) {
+            const int b = base + tid;
+            int isnew = 0;
+            uint64_t h1 = 0, h2 = 0;
+            if (b < nbeam && pinfo[b].flag == 0) {       // live and cursor == 0
+                h1 = pinfo[b].h1; h2 = pinfo[b].h2;
+                if (h1 == 0) h1 = 1;
+                if (h2 == 0) h2 = 1;
+                isnew = seen_lookup(stab, scap, h1, h2) ? 0 : 1;
+                // an earlier parent of this phase producing the same structure wins (`seen` order)
+                for (int e = single_from; isnew && e < b; e++)
+                    if (pinfo[e].flag == 0) {
+                        uint64_t g1 = pinfo[e].h1, g2 = pinfo[e].h2;
+                        if (g1 == 0) g1 = 1;
+                        if (g2 == 0) g2 = 1;
+                        if (g1 == h1 && g2 == h2) isnew = 0;
+                    }
+            }
+            int tot, ex = block_exscan<BS_NT>(isnew, sh, &tot);
+            if (isnew) {
+                const int ci2 = nchild + ex;
+                if (ci2 < d.ch_cap) {
+                    d.ch_parent[chb + ci2] = (uint16_t)b;
+                    d.ch_combo[chb + ci2] = 0;
+                    d.ch_dcal[chb + ci2] = pinfo[b].dcal0;
+                    d.ch_h[2 * (chb + ci2)] = h1;
+                    d.ch_h[2 * (chb + ci2) + 1] = h2;
+                } else atomicOr(&d.c->overflow, OVF_SORT);
+                seen_insert(stab, scap, h1, h2);
+            }
+            if (b < nbeam && pinfo[b].flag == 0) { d.st_cursor[oldbeam[b]] = 1; d.st_total[oldbeam[b]] = pinfo[b].total; }
+            nchild += tot; nb_branch += tot; scnt += tot;
+            __syncthreads();
+        }
+    }
+    STAMP(2);
     if (tid == 0) { d.seen_cnt[sq] = scnt; atomicAdd(&d.c->n_children, (unsigned long long)nchild); }
     if (nchild > d.ch_cap) nchild = d.ch_cap;
 
@@ -645,6 +740,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
             }
             __syncthreads();
         }
+    STAMP(3);
     const int nnew = N < d.B ? N : d.B;
     // children among the survivors
     int nsurv_child = 0;
@@ -711,6 +807,9 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
         __syncthreads();
     }
     if (tid == 0) d.beam_n[sq] = nnew;
+    STAMP(4);
+    if (prof) d.prof[5] += 1;
+#undef STAMP
 }
 
 // ------------------------------------------------------- materialize kernel
@@ -940,7 +1039,7 @@ __global__ __launch_bounds__(256) void dedupe_kernel(Dev d)
                 if (canon == nid) cls = node_class(d.nd_n[nid], d.seq_len[d.nd_seq[nid]], d.nd_nbr[nid]);
                 else { d.nd_canon[nid] = canon; aliases++; }
             }
-            for (int c = 0; c < 3; c++) {
+            for (int c = 0; c < NCLS; c++) {
                 unsigned long long bal = __ballot(cls == c);
                 if (!bal) continue;
                 unsigned int w0 = 0;
@@ -1001,7 +1100,7 @@ __global__ void output_kernel(Dev d, int nrows, const int *row_sid, const long l
 // ------------------------------------------------------------- eval kernel
 
 // one wavefront per structure: sum of loop energies (rafft/utils.py:135-138)
-__global__ __launch_bounds__(64) void eval_kernel(const EnergyTables *T, int n, const uint8_t *codes, const int16_t *pts,
+__global__ __launch_bounds__(64) void eval_kernel(const EnergyTables *ET, int n, const uint8_t *codes, const int16_t *pts,
                                                   const long long *off, const int *len, int *out, int *status)
 {
     const int s = blockIdx.x, lane = threadIdx.x;
@@ -1009,11 +1108,13 @@ __global__ __launch_bounds__(64) void eval_kernel(const EnergyTables *T, int n, 
     const int L = len[s];
     const uint8_t *S = codes + off[s];
     PlainView pv{pts + off[s]};
+    const SmallT *T = &ET->s;
+    const BigT *B = &ET->b;
     int e = 0, bad = 0;
-    if (lane == 0) e += loop_energy(T, S, L, pv, -1, L, &bad);
+    if (lane == 0) e += loop_energy(T, B, S, L, pv, -1, L, &bad);
     for (int i = lane; i < L; i += 64) {
         int j = pv(i);
-        if (j > i) e += loop_energy(T, S, L, pv, i, j, &bad);
+        if (j > i) e += loop_energy(T, B, S, L, pv, i, j, &bad);
     }
     for (int o = 32; o > 0; o >>= 1) { e += __shfl_xor(e, o, 64); bad |= __shfl_xor(bad, o, 64); }
     if (lane == 0) { out[s] = e; status[s] = bad ? 8 : 0; }
