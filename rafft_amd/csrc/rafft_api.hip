@@ -227,13 +227,21 @@ Caps plan_caps(size_t S, size_t sumL, const rafft_params &p, double est)
     c.pos = (size_t)((double)sumL + (double)(c.st - S) * avgL) + 4096;
     c.br = c.pos / 2 + 4096;
     c.db = c.pos;
-    c.cand = c.nd * (size_t)std::min(std::max(p.nb_mode, 1), 12) + 4096;
-    double per_seq_seen = std::min(std::max(8.0 * est * ((double)B + (double)p.max_branch / 8.0), 4096.0), 4194304.0);
+    c.cand = std::max<size_t>(c.nd * (size_t)std::min(std::max(p.nb_mode, 1), 12) + 4096, (size_t)NSHARD * 8192);
+    // accepted children per sequence ~ steps * min(max_branch, ...); regions double and old ones are dropped
+    double per_seq_seen = std::min(std::max(24.0 * est * ((double)B + (double)p.max_branch / 4.0), 16384.0), 16777216.0);
     c.seen = S * 1024 + (size_t)((double)S * per_seq_seen);
     c.trec = p.traj ? S * (size_t)(est * 3 + 16) : S + 16;
     c.tsid = c.trec * B + 16;
     c.work = c.nd;
     c.mat = S * B + 16;
+    // every arena is split into NSHARD sub-arenas: keep a floor per shard so that small batches,
+    // whose few structures land on few shards, do not overflow a starved shard
+    c.nd = std::max<size_t>(c.nd, S + (size_t)NSHARD * 2048);
+    c.pos = std::max<size_t>(c.pos, sumL + (size_t)NSHARD * (16 * (size_t)avgL + 4096));
+    c.db = std::max<size_t>(c.db, sumL + (size_t)NSHARD * (16 * (size_t)avgL + 4096));
+    c.br = std::max<size_t>(c.br, (size_t)NSHARD * 8192);
+    c.work = c.nd;
     c.looptab = 1024; while (c.looptab < 2 * c.nd) c.looptab <<= 1;
     c.ch_cap = p.max_branch + p.max_stack + 8;
     int need = p.max_branch + 2 * p.max_stack + 8;
@@ -377,7 +385,6 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
     memset(&hc, 0, sizeof hc);
     hc.n_struct = S; hc.seen_top = S * 1024;
     HIPCHK(hipMemcpyAsync(g.counters.p, &hc, sizeof hc, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(g.seen.p, 0, c.seen * 16, st));
     if (d.memo) HIPCHK(hipMemsetAsync(g.looptab.p, 0, c.looptab * 8, st));
     hipLaunchKernelGGL(init_roots_kernel, dim3((unsigned)S), dim3(64), 0, st, d);
     HIPCHK(hipGetLastError());
@@ -587,8 +594,8 @@ int fold_range(const rafft_params &p, std::vector<SeqIn> seqs, double est, HostO
     unsigned ovf = 0;
     int rc = run_wave(p, seqs, est, out, &ovf, spans);
     if (rc == RAFFT_ERR_CAPACITY) {
-        if (depth >= 8) return fail(RAFFT_ERR_CAPACITY, "HBM arena overflow after 8 regrowths (bits " + std::to_string(ovf) + ")");
-        return fold_range(p, seqs, est * 2.0, out, spans, depth + 1);
+        if (depth >= 12) return fail(RAFFT_ERR_CAPACITY, "HBM arena overflow after 12 regrowths (bits " + std::to_string(ovf) + ")");
+        return fold_range(p, seqs, est * (depth >= 2 ? 4.0 : 2.0), out, spans, depth + 1);
     }
     return rc;
 }
@@ -645,7 +652,9 @@ int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs, 
         good.push_back({seqs[i], L, i});
     }
     std::vector<Span> spans;
-    int rc = fold_range(*p, good, 12.0, *ho, spans, 0);
+    double est0 = 12.0;                       // expected survivors per beam slot; arenas regrow x2 on overflow
+    if (const char *e = getenv("RAFFT_EST")) if (atof(e) > 0) est0 = atof(e);
+    int rc = fold_range(*p, good, est0, *ho, spans, 0);
     if (rc) { free_out(ho); return rc; }
     for (auto &sp : spans) {
         float ms = 0;

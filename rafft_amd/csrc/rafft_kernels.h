@@ -46,7 +46,7 @@ struct Counters {
     // statistics
     unsigned long long n_expand, sum_n, sum_lags, n_children, sum_struct_len, n_alias, sum_nbr;
     // sharded bump pointers of the arenas filled by materialize / expand
-    ShardCtr node[NSHARD], pos[NSHARD], br[NSHARD], db[NSHARD], cand[NSHARD];
+    ShardCtr node[NSHARD], pos[NSHARD], br[NSHARD], db[NSHARD], cand[NSHARD], node_prev[NSHARD];
 };
 
 enum { OVF_STRUCT = 1, OVF_NODE = 2, OVF_POS = 4, OVF_DB = 8, OVF_CAND = 16, OVF_SEEN = 32,

@@ -107,11 +107,22 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
     const int shard = blockIdx.x & (NSHARD - 1);
     unsigned long long st_items = 0, st_n = 0, st_lags = 0, st_nbr = 0;   // per-block statistics
 
+    // Work items are fetched FETCH at a time and candidate slots are reserved in slabs, so that the
+    // two atomics with a returned value (a full L2 round trip each) are paid once per several regions.
+    const unsigned FETCH = (NT == 64) ? 4u : 1u;
+    unsigned fetch_base = 0, fetch_left = 0;                 // uniform across the workgroup
+    unsigned long long slab_base = 0; unsigned slab_left = 0;   // thread 0 only
+
     for (;;) {
         __syncthreads();                       // previous region's LDS use is over
-        if (tid == 0) misc[8] = (int)atomicAdd(&d.c->next_work[cls], 1u);
-        __syncthreads();
-        const unsigned item = (unsigned)misc[8];
+        if (fetch_left == 0) {
+            if (tid == 0) misc[8] = (int)atomicAdd(&d.c->next_work[cls], FETCH);
+            __syncthreads();
+            fetch_base = (unsigned)misc[8];
+            fetch_left = FETCH;
+        }
+        const unsigned item = fetch_base;
+        fetch_base++; fetch_left--;
         if (item >= n_items) break;
         const int nid = d.work[cls][item];
         const int sq = d.nd_seq[nid];
@@ -346,9 +357,14 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
             unsigned long long base = 0;
             misc[2] = 0;
             if (nkept) {
-                base = atomicAdd(&d.c->cand[shard].v, (unsigned long long)nkept);
-                if (base + nkept > d.cand_shard_cap) { atomicOr(&d.c->overflow, OVF_CAND); base = 0; misc[2] = 1; }
-                base += (unsigned long long)shard * d.cand_shard_cap;
+                if ((unsigned)nkept > slab_left) {      // reserve a new slab of candidate slots (the rest of the old one is dropped)
+                    const unsigned slab = d.cand_shard_cap >= 4096 ? 256u : 16u;
+                    const unsigned want = (unsigned)nkept > slab ? (unsigned)nkept : slab;
+                    unsigned long long b0 = atomicAdd(&d.c->cand[shard].v, (unsigned long long)want);
+                    if (b0 + want > d.cand_shard_cap) { atomicOr(&d.c->overflow, OVF_CAND); misc[2] = 1; slab_left = 0; }
+                    else { slab_base = (unsigned long long)shard * d.cand_shard_cap + b0; slab_left = want; }
+                }
+                if (!misc[2]) { base = slab_base; slab_base += nkept; slab_left -= nkept; }
             }
             *(unsigned long long *)&misc[4] = base;
             st_items++; st_n += n; st_lags += Kp; st_nbr += nbr;
@@ -448,6 +464,8 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
     int *sh = oldbeam + ((d.B + 3) & ~3);                                       // scratch [32]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int sq = blockIdx.x;
+    // snapshot of the region allocators: whatever materialize adds after this kernel is "new"
+    if (sq == 0 && tid < NSHARD) d.c->node_prev[tid].v = d.c->node[tid].v;
     if (d.done[sq]) return;
     const bool prof = d.prof && sq == d.prof_seq && tid == 0;   // diagnostic stamps (RAFFT_TRACE=3)
     unsigned long long tprev = prof ? clock64() : 0;
@@ -564,6 +582,8 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
                 __syncthreads();
                 if (o == ~0ULL) { d.done[sq] = 1; return; }
                 uint64_t *ntab = d.seen + 2 * o;
+                for (uint32_t i = tid; i < 2 * ncap; i += BS_NT) ntab[i] = 0;   // arena is not pre-zeroed
+                __syncthreads();
                 for (uint32_t i = tid; i < scap; i += BS_NT) {
                     uint64_t k1 = stab[2 * (uint64_t)i];
                     if (k1) seen_insert(ntab, ncap, k1, stab[2 * (uint64_t)i + 1]);
@@ -670,6 +690,8 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
             __syncthreads();
             if (o == ~0ULL) { d.done[sq] = 1; return; }
             uint64_t *ntab = d.seen + 2 * o;
+            for (uint32_t i = tid; i < 2 * ncap; i += BS_NT) ntab[i] = 0;       // arena is not pre-zeroed
+            __syncthreads();
             for (uint32_t i = tid; i < scap; i += BS_NT) {
                 uint64_t k1 = stab[2 * (uint64_t)i];
                 if (k1) seen_insert(ntab, ncap, k1, stab[2 * (uint64_t)i + 1]);
@@ -999,56 +1021,68 @@ __device__ inline bool same_loop(const Dev &d, int a, int b)
     return true;
 }
 
-// One wavefront per structure materialized in this step, one lane per region.  The first
+// One thread per region created in this step (the new node ids are the ranges the
+// materialize kernel bumped in each allocation shard since the last snapshot).  The first
 // region to claim a loop key becomes canonical and goes to the expand work list; later
 // identical loops alias it.  Work-list appends are aggregated per wavefront.
 __global__ __launch_bounds__(256) void dedupe_kernel(Dev d)
 {
-    const unsigned n_mat = d.c->n_mat;
-    const int lane = threadIdx.x & 63;
-    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    __shared__ unsigned int pre[NSHARD + 1];
+    __shared__ unsigned int prev[NSHARD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    // an arena overflowed while materializing: some region records of this step were never written.
+    // Nothing may be read from them; the host sees the flag at its next read-back and regrows.
+    if (d.c->overflow) return;
+    if (tid < NSHARD) {
+        prev[tid] = (unsigned int)d.c->node_prev[tid].v;
+        pre[tid + 1] = (unsigned int)(d.c->node[tid].v - d.c->node_prev[tid].v);
+    }
+    if (tid == 0) pre[0] = 0;
+    __syncthreads();
+    if (tid == 0) for (int i = 1; i <= NSHARD; i++) pre[i] += pre[i - 1];
+    __syncthreads();
+    const unsigned int total = pre[NSHARD];
     unsigned long long aliases = 0;
-    for (unsigned m = wave; m < n_mat; m += n_waves) {
-        const int sid = d.mat[m];
-        const int node0 = d.st_node0[sid], nn = d.st_nnodes[sid];
-        for (int base = 0; base < nn; base += 64) {
-            const int i = base + lane;
-            int cls = -1, nid = 0;
-            if (i < nn) {
-                nid = node0 + i;
-                int canon = nid;
-                if (d.memo) {
-                    const uint32_t *bb = d.br + d.nd_br[nid];
-                    const int nbr = d.nd_nbr[nid];
-                    uint64_t h = mix64(((uint64_t)(uint32_t)d.nd_seq[nid] << 32) ^ ((uint64_t)(uint32_t)(d.nd_ci[nid] + 1) << 16) ^ (uint32_t)d.nd_cj[nid]);
-                    for (int t = 0; t < nbr; t++) h += mix64((uint64_t)bb[t] ^ 0x5bd1e9955bd1e995ULL);
-                    const unsigned long long tag = (h >> 32) | 0x80000000ULL;
-                    const uint64_t mask = d.looptab_cap - 1;
-                    uint64_t sl = h & mask;
-                    for (unsigned probe = 0;; probe++) {
-                        unsigned long long old = atomicCAS(&d.looptab[sl], 0ULL, (tag << 32) | (unsigned long long)(nid + 1));
-                        if (old == 0) break;
-                        if ((old >> 32) == tag) {
-                            int other = (int)(old & 0xffffffffULL) - 1;
-                            if (same_loop(d, nid, other)) { canon = other; break; }
-                        }
-                        sl = (sl + 1) & mask;
-                        if (probe > d.looptab_cap) { atomicOr(&d.c->overflow, OVF_LOOPTAB); break; }
+    const unsigned int stride = gridDim.x * blockDim.x;
+    for (unsigned int f0 = blockIdx.x * blockDim.x; f0 < total; f0 += stride) {
+        const unsigned int f = f0 + tid;
+        int cls = -1, nid = 0;
+        if (f < total) {
+            int lo = 0, hi = NSHARD;             // shard with pre[lo] <= f < pre[lo+1]
+            while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (pre[mid] <= f) lo = mid; else hi = mid; }
+            nid = (int)(d.nd_base + (unsigned long long)lo * d.nd_shard_cap + prev[lo] + (f - pre[lo]));
+            int canon = nid;
+            if (d.memo) {
+                const uint32_t *bb = d.br + d.nd_br[nid];
+                const int nbr = d.nd_nbr[nid];
+                uint64_t h = mix64(((uint64_t)(uint32_t)d.nd_seq[nid] << 32) ^ ((uint64_t)(uint32_t)(d.nd_ci[nid] + 1) << 16) ^ (uint32_t)d.nd_cj[nid]);
+                for (int t = 0; t < nbr; t++) h += mix64((uint64_t)bb[t] ^ 0x5bd1e9955bd1e995ULL);
+                const unsigned long long tag = (h >> 32) | 0x80000000ULL;
+                const uint64_t mask = d.looptab_cap - 1;
+                uint64_t sl = h & mask;
+                for (unsigned probe = 0;; probe++) {
+                    unsigned long long old = atomicCAS(&d.looptab[sl], 0ULL, (tag << 32) | (unsigned long long)(nid + 1));
+                    if (old == 0) break;
+                    if ((old >> 32) == tag) {
+                        int other = (int)(old & 0xffffffffULL) - 1;
+                        if (same_loop(d, nid, other)) { canon = other; break; }
                     }
+                    sl = (sl + 1) & mask;
+                    if (probe > d.looptab_cap) { atomicOr(&d.c->overflow, OVF_LOOPTAB); break; }
                 }
-                if (canon == nid) cls = node_class(d.nd_n[nid], d.seq_len[d.nd_seq[nid]], d.nd_nbr[nid]);
-                else { d.nd_canon[nid] = canon; aliases++; }
             }
-            for (int c = 0; c < NCLS; c++) {
-                unsigned long long bal = __ballot(cls == c);
-                if (!bal) continue;
-                unsigned int w0 = 0;
-                if (lane == 0) w0 = atomicAdd(&d.c->n_work[c], (unsigned int)__popcll(bal));
-                w0 = __shfl(w0, 0, 64);
-                if (cls == c) {
-                    unsigned int w = w0 + (unsigned int)__popcll(bal & ((1ULL << lane) - 1));
-                    if (w < d.work_cap) d.work[c][w] = nid; else atomicOr(&d.c->overflow, OVF_WORK);
-                }
+            if (canon == nid) cls = node_class(d.nd_n[nid], d.seq_len[d.nd_seq[nid]], d.nd_nbr[nid]);
+            else { d.nd_canon[nid] = canon; aliases++; }
+        }
+        for (int c = 0; c < NCLS; c++) {
+            unsigned long long bal = __ballot(cls == c);
+            if (!bal) continue;
+            unsigned int w0 = 0;
+            if (lane == 0) w0 = atomicAdd(&d.c->n_work[c], (unsigned int)__popcll(bal));
+            w0 = __shfl(w0, 0, 64);
+            if (cls == c) {
+                unsigned int w = w0 + (unsigned int)__popcll(bal & ((1ULL << lane) - 1));
+                if (w < d.work_cap) d.work[c][w] = nid; else atomicOr(&d.c->overflow, OVF_WORK);
             }
         }
     }
@@ -1065,6 +1099,7 @@ __global__ void init_roots_kernel(Dev d)
     // structure sq / node sq are the unfolded structure and its single region (rafft.py:224-231)
     const unsigned long long off = (unsigned long long)d.seq_off[sq];
     for (int x = tid; x < L; x += blockDim.x) { d.db[off + x] = '.'; d.pos[off + x] = (uint16_t)x; }
+    for (int x = tid; x < 2048; x += blockDim.x) d.seen[2 * (size_t)sq * 1024 + x] = 0;   // first seen region
     if (tid == 0) {
         d.st_seq[sq] = sq; d.st_dcal[sq] = 0; d.st_h[2 * (size_t)sq] = 0; d.st_h[2 * (size_t)sq + 1] = 0;
         d.st_db[sq] = off; d.st_node0[sq] = sq; d.st_nnodes[sq] = L > 0 ? 1 : 0; d.st_cursor[sq] = 0; d.st_total[sq] = 0;

@@ -105,3 +105,16 @@ def test_gpu_error_behaviour():
     assert res[1] is None and res[2] is None and res[0][0].str_struct == oracle.fold("GGGAAACCC", max_stack=3)[0].str_struct
     with pytest.raises(Exception):
         rafft_amd.fold("GGGAAACCC", temp=25.0)
+
+
+def test_gpu_arena_overflow_regrows_and_stays_exact(monkeypatch):
+    """start with starved HBM arenas (on memory still holding an earlier batch): the overflow flags
+    must stop the step cleanly, the wave is re-run with doubled arenas and results are unchanged"""
+    rng = np.random.default_rng(21)
+    seqs = ["".join(rng.choice(list("ACGU"), int(n))) for n in rng.integers(60, 400, size=40)]
+    want = rafft_amd.fold_batch(seqs, 100, 20, 1000, traj=True)
+    monkeypatch.setenv("RAFFT_EST", "0.05")
+    got = rafft_amd.fold_batch(seqs, 100, 20, 1000, traj=True)
+    monkeypatch.delenv("RAFFT_EST")
+    for (f1, t1), (f2, t2) in zip(want, got):
+        assert as_lists(t1) == as_lists(t2)
