@@ -58,7 +58,7 @@ struct Ctx {
     std::vector<Buf *> bufs;
     // named workspace buffers (grow-only)
     Buf codes, seq_off, seq_len, beam, beam_n, done, nsteps, ch_parent, ch_combo, ch_dcal, ch_h, seen, seen_off,
-        seen_cap, seen_cnt, st_seq, st_dcal, st_node0, st_nnodes, st_parent, st_h, st_db, st_cursor, st_combo, st_total, nd_seq, nd_pdcal,
+        seen_cap, seen_cnt, st_seq, st_dcal, st_node0, st_nnodes, st_parent, st_h, st_db, st_cursor, st_combo, st_total, st_prod, st_nprod, prod, nd_seq, nd_pdcal,
         nd_n, nd_ci, nd_cj, nd_nbr, nd_canon, nd_ncand, nd_pos, nd_br, nd_cand, pos, br, db, cand, looptab, trec, tsid,
         work0, work1, work2, work3, mat, counters,
         row_sid, row_off, out_db, out_dcal, dbg;
@@ -230,7 +230,7 @@ Caps plan_caps(size_t S, size_t sumL, const rafft_params &p, double est)
     c.cand = std::max<size_t>(c.nd * (size_t)std::min(std::max(p.nb_mode, 1), 12) + 4096, (size_t)NSHARD * 8192);
     // accepted children per sequence ~ steps * min(max_branch, ...); regions double and old ones are dropped
     double per_seq_seen = std::min(std::max(24.0 * est * ((double)B + (double)p.max_branch / 4.0), 16384.0), 16777216.0);
-    c.seen = S * 1024 + (size_t)((double)S * per_seq_seen);
+    c.seen = S * (size_t)SEEN0 + (size_t)((double)S * per_seq_seen);
     c.trec = p.traj ? S * (size_t)(est * 3 + 16) : S + 16;
     c.tsid = c.trec * B + 16;
     c.work = c.nd;
@@ -246,7 +246,7 @@ Caps plan_caps(size_t S, size_t sumL, const rafft_params &p, double est)
     c.ch_cap = p.max_branch + p.max_stack + 8;
     int need = p.max_branch + 2 * p.max_stack + 8;
     c.sort_cap = 2; while (c.sort_cap < need) c.sort_cap <<= 1;
-    c.bytes = c.st * (4 * 5 + 8 * 5) + c.nd * (4 * 8 + 8 * 3 + 4 * 4) + c.pos * 2 + c.br * 4 + c.db + c.cand * 32 + c.seen * 16 +
+    c.bytes = c.st * (4 * 6 + 8 * 6) + c.nd * (4 * 8 + 8 * 3 + 4 * 4 + 16) + c.pos * 2 + c.br * 4 + c.db + c.cand * 32 + c.seen * 16 +
               c.looptab * 8 + c.trec * 16 + c.tsid * 4 + c.mat * 4 + S * (size_t)c.ch_cap * 32 + S * B * 4;
     return c;
 }
@@ -319,7 +319,7 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
     ENS(ch_parent, S * c.ch_cap * 2); ENS(ch_combo, S * c.ch_cap * 8); ENS(ch_dcal, S * c.ch_cap * 4); ENS(ch_h, S * c.ch_cap * 16);
     ENS(seen, c.seen * 16); ENS(seen_off, S * 8); ENS(seen_cap, S * 4); ENS(seen_cnt, S * 4);
     ENS(st_seq, c.st * 4); ENS(st_dcal, c.st * 4); ENS(st_node0, c.st * 4); ENS(st_nnodes, c.st * 4); ENS(st_parent, c.st * 4);
-    ENS(st_h, c.st * 16); ENS(st_db, c.st * 8); ENS(st_cursor, c.st * 8); ENS(st_combo, c.st * 8); ENS(st_total, c.st * 8);
+    ENS(st_h, c.st * 16); ENS(st_db, c.st * 8); ENS(st_cursor, c.st * 8); ENS(st_combo, c.st * 8); ENS(st_total, c.st * 8); ENS(st_prod, c.st * 8); ENS(st_nprod, c.st * 4); ENS(prod, c.nd * 16);
     ENS(nd_seq, c.nd * 4); ENS(nd_pdcal, c.nd * 4); ENS(nd_n, c.nd * 4); ENS(nd_ci, c.nd * 4); ENS(nd_cj, c.nd * 4);
     ENS(nd_nbr, c.nd * 4); ENS(nd_canon, c.nd * 4); ENS(nd_ncand, c.nd * 4);
     ENS(nd_pos, c.nd * 8); ENS(nd_br, c.nd * 8); ENS(nd_cand, c.nd * 8);
@@ -348,7 +348,8 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
     d.st_cap = (uint32_t)c.st;
     d.st_seq = (int *)g.st_seq.p; d.st_dcal = (int *)g.st_dcal.p; d.st_node0 = (int *)g.st_node0.p; d.st_nnodes = (int *)g.st_nnodes.p;
     d.st_parent = (int *)g.st_parent.p; d.st_h = (uint64_t *)g.st_h.p; d.st_db = (uint64_t *)g.st_db.p;
-    d.st_cursor = (uint64_t *)g.st_cursor.p; d.st_combo = (uint64_t *)g.st_combo.p; d.st_total = (uint64_t *)g.st_total.p;
+    d.st_cursor = (uint64_t *)g.st_cursor.p; d.st_combo = (uint64_t *)g.st_combo.p; d.st_total = (uint64_t *)g.st_total.p; d.st_prod = (uint64_t *)g.st_prod.p; d.st_nprod = (int *)g.st_nprod.p;
+    d.prod = (ProdEnt *)g.prod.p; d.prod_shard_cap = c.nd / NSHARD;
     d.nd_cap = (uint32_t)c.nd;
     d.nd_seq = (int *)g.nd_seq.p; d.nd_pdcal = (int *)g.nd_pdcal.p; d.nd_n = (int *)g.nd_n.p; d.nd_ci = (int *)g.nd_ci.p;
     d.nd_cj = (int *)g.nd_cj.p; d.nd_nbr = (int *)g.nd_nbr.p; d.nd_canon = (int *)g.nd_canon.p; d.nd_ncand = (int *)g.nd_ncand.p;
@@ -369,8 +370,8 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
     if (const char *rp = getenv("RAFFT_REP")) d.rep = atoi(rp);
     static unsigned long long *prof_buf = nullptr;
     if (getenv("RAFFT_TRACE") && atoi(getenv("RAFFT_TRACE")) >= 3) {
-        if (!prof_buf) HIPCHK(hipMalloc((void **)&prof_buf, 64));
-        HIPCHK(hipMemset(prof_buf, 0, 64));
+        if (!prof_buf) HIPCHK(hipMalloc((void **)&prof_buf, 128));
+        HIPCHK(hipMemset(prof_buf, 0, 128));
         d.prof = prof_buf;
         int best = 0;
         for (size_t i = 0; i < S; i++) if (len[i] > len[best]) best = (int)i;
@@ -383,9 +384,10 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
     HIPCHK(hipMemcpyAsync(g.seq_len.p, len.data(), S * 4, hipMemcpyHostToDevice, st));
     Counters hc;
     memset(&hc, 0, sizeof hc);
-    hc.n_struct = S; hc.seen_top = S * 1024;
+    hc.n_struct = S; hc.seen_top = S * (size_t)SEEN0;
     HIPCHK(hipMemcpyAsync(g.counters.p, &hc, sizeof hc, hipMemcpyHostToDevice, st));
     if (d.memo) HIPCHK(hipMemsetAsync(g.looptab.p, 0, c.looptab * 8, st));
+    HIPCHK(hipMemsetAsync(g.seen.p, 0, S * (size_t)SEEN0 * 16, st));   // first region of every sequence; later regions are zeroed on allocation
     hipLaunchKernelGGL(init_roots_kernel, dim3((unsigned)S), dim3(64), 0, st, d);
     HIPCHK(hipGetLastError());
 
@@ -569,8 +571,10 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
         row += nst;
     }
     if (d.prof) {
-        unsigned long long pv[8];
-        HIPCHK(hipMemcpy(pv, d.prof, 64, hipMemcpyDeviceToHost));
+        unsigned long long pv[16];
+        HIPCHK(hipMemcpy(pv, d.prof, 128, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[rafft]   product loop detail: head %llu, digits+base %llu, decode+lookup %llu, scans %llu, write+insert %llu\n",
+                pv[6], pv[7], pv[8], pv[9], pv[10]);
         fprintf(stderr, "[rafft] beam_step stamps of the longest sequence (cycles): prepass %llu, product loop %llu, single phase %llu, sort %llu, survivors %llu over %llu steps\n",
                 pv[0], pv[1], pv[2], pv[3], pv[4], pv[5]);
     }

@@ -31,8 +31,11 @@ struct alignas(16) Cand {
 static_assert(sizeof(Cand) == 32, "Cand must be 32 bytes");
 
 #define NSHARD 64
+#define SEEN0 8192      // initial slots of a sequence's `seen` set (grows x2 by rehash)
 #define NCLS 4
 struct ShardCtr { unsigned long long v; unsigned long long pad[7]; };   // one 64-byte line each
+
+struct ProdEnt { uint32_t cnt; int32_t node; uint64_t off; };   // one productive region of a structure
 
 struct Counters {
     // hot part: read back by the host once per folding step (first 64 bytes)
@@ -46,11 +49,11 @@ struct Counters {
     // statistics
     unsigned long long n_expand, sum_n, sum_lags, n_children, sum_struct_len, n_alias, sum_nbr;
     // sharded bump pointers of the arenas filled by materialize / expand
-    ShardCtr node[NSHARD], pos[NSHARD], br[NSHARD], db[NSHARD], cand[NSHARD], node_prev[NSHARD];
+    ShardCtr node[NSHARD], pos[NSHARD], br[NSHARD], db[NSHARD], cand[NSHARD], node_prev[NSHARD], prod[NSHARD];
 };
 
 enum { OVF_STRUCT = 1, OVF_NODE = 2, OVF_POS = 4, OVF_DB = 8, OVF_CAND = 16, OVF_SEEN = 32,
-       OVF_TRAJ = 64, OVF_WORK = 128, OVF_PROD = 256, OVF_SORT = 512, OVF_BR = 1024, OVF_LOOPTAB = 2048 };
+       OVF_TRAJ = 64, OVF_WORK = 128, OVF_PROD = 256, OVF_SORT = 512, OVF_BR = 1024, OVF_LOOPTAB = 2048, OVF_PRODLIST = 4096 };
 
 struct DebugOut {       // kernel-level seam (rafft_expand_node); null in production
     int *n_ranked, *lag, *nb, *mi, *mj, *ddcal, *kept;
@@ -75,7 +78,9 @@ struct Dev {
     // structures
     uint32_t st_cap;
     int *st_seq, *st_dcal, *st_node0, *st_nnodes, *st_parent;
-    uint64_t *st_h, *st_db, *st_cursor, *st_combo, *st_total;
+    uint64_t *st_h, *st_db, *st_cursor, *st_combo, *st_total, *st_prod;
+    int *st_nprod;
+    ProdEnt *prod; uint64_t prod_shard_cap;
     // nodes
     uint32_t nd_cap;
     uint64_t nd_base, nd_shard_cap, pos_base, pos_shard_cap, br_shard_cap, db_base, db_shard_cap, cand_shard_cap;

@@ -58,6 +58,53 @@ __device__ inline int block_exscan(int v, int *scratch, int *tot)
     return base + x - v;
 }
 
+// Exact top-K selection for a workgroup: moves the K smallest of the N DISTINCT 64-bit keys in LDS to
+// keys[0..K) (unordered).  Byte-wise radix select from the most significant byte: 8 passes over the
+// keys with a 256-bin LDS histogram instead of sorting all N.  `hist` needs 256 ints, `sh` 32 ints.
+template <int NT>
+__device__ inline void select_smallest_inplace(unsigned long long *keys, int N, int K, int *hist, int *sh)
+{
+    const int tid = threadIdx.x;
+    if (K >= N) return;
+    unsigned long long prefix = 0;
+    int kk = K;
+    for (int pass = 7; pass >= 0; pass--) {
+        for (int i = tid; i < 256; i += NT) hist[i] = 0;
+        __syncthreads();
+        const int sh_hi = 8 * (pass + 1);
+        for (int i = tid; i < N; i += NT) {
+            const unsigned long long key = keys[i];
+            if (pass == 7 || (key >> sh_hi) == (prefix >> sh_hi)) atomicAdd(&hist[(int)((key >> (8 * pass)) & 255ULL)], 1);
+        }
+        __syncthreads();
+        // bucket holding the kk-th smallest key of the current group
+        int run = 0;
+        for (int base = 0; base < 256; base += NT) {
+            const int b = base + tid;
+            const int h = b < 256 ? hist[b] : 0;
+            int tot, ex = block_exscan<NT>(h, sh, &tot);
+            if (b < 256 && run + ex < kk && kk <= run + ex + h) { sh[28] = b; sh[29] = kk - (run + ex); }
+            run += tot;
+            __syncthreads();
+        }
+        prefix |= (unsigned long long)(unsigned)sh[28] << (8 * pass);
+        kk = sh[29];
+        __syncthreads();
+    }
+    // `prefix` is now the K-th smallest key: keep every key <= prefix (exactly K, keys are distinct)
+    int outn = 0;
+    for (int base = 0; base < N; base += NT) {
+        const int i = base + tid;
+        unsigned long long key = 0;
+        int f = 0;
+        if (i < N) { key = keys[i]; f = key <= prefix ? 1 : 0; }
+        int tot, ex = block_exscan<NT>(f, sh, &tot);     // (barriers inside: all reads of this slab are done)
+        if (f) keys[outn + ex] = key;                     // outn + ex <= i: never clobbers an unread key
+        outn += tot;
+        __syncthreads();
+    }
+}
+
 struct PlainView {
     const int16_t *pt;
     __device__ __forceinline__ int operator()(int x) const { return pt[x]; }
@@ -503,18 +550,38 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
         const int node0 = d.st_node0[sid], nn = d.st_nnodes[sid];
         unsigned long long tot = 1, h1 = 0, h2 = 0;
         int dc = 0, np = 0;
+        // first visit of this structure: its productive regions (node order, rafft/rafft.py:166-171) are
+        // written once as a compact list that the product walk and materialize_kernel read back
+        unsigned long long pbase = 0;
+        if (lane == 0) {
+            const int shd = sq & (NSHARD - 1);
+            pbase = atomicAdd(&d.c->prod[shd].v, (unsigned long long)nn);
+            if (pbase + nn > d.prod_shard_cap) { atomicOr(&d.c->overflow, OVF_PRODLIST); pbase = ~0ULL; }
+            else pbase += (unsigned long long)shd * d.prod_shard_cap;
+        }
+        pbase = __shfl(pbase, 0, 64);
+        int wpos = 0;
         for (int base = 0; base < nn; base += 64) {
-            int i = base + lane;
+            int i = base + lane, cnt = 0, cn = 0;
+            unsigned long long coff = 0;
             if (i < nn) {
-                int cn = d.nd_canon[node0 + i];
-                int cnt = d.nd_ncand[cn];
+                cn = d.nd_canon[node0 + i];
+                cnt = d.nd_ncand[cn];
                 if (cnt > 0) {
-                    const Cand *cp = &d.cand[d.nd_cand[cn]];
+                    coff = d.nd_cand[cn];
+                    const Cand *cp = &d.cand[coff];
                     tot = sat_mul(tot, (unsigned long long)cnt);
                     dc += cp->ddcal; h1 += cp->h1; h2 += cp->h2; np++;
                 }
             }
+            const unsigned long long bal = __ballot(cnt > 0);
+            if (cnt > 0 && pbase != ~0ULL) {
+                ProdEnt pe; pe.cnt = (uint32_t)cnt; pe.node = cn; pe.off = coff;
+                d.prod[pbase + wpos + __popcll(bal & ((1ULL << lane) - 1))] = pe;
+            }
+            wpos += __popcll(bal);
         }
+        if (lane == 0) { d.st_prod[sid] = pbase == ~0ULL ? 0 : pbase; d.st_nprod[sid] = pbase == ~0ULL ? 0 : wpos; }
         for (int o = 32; o > 0; o >>= 1) {
             tot = sat_mul(tot, __shfl_xor(tot, o, 64));
             h1 += __shfl_xor(h1, o, 64); h2 += __shfl_xor(h2, o, 64);
@@ -547,31 +614,36 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
         const int sid = oldbeam[b];
         unsigned long long cur = d.st_cursor[sid];
         const unsigned long long total = pinfo[b].total;
-        // productive regions in node order (rafft/rafft.py:166-171)
-        const int node0 = d.st_node0[sid], nn = d.st_nnodes[sid];
-        int mprod = 0;
-        for (int base = 0; base < nn; base += BS_NT) {
-            int i = base + tid, cnt = 0, cn = 0;
-            if (i < nn) { cn = d.nd_canon[node0 + i]; cnt = d.nd_ncand[cn]; }
-            int tot, ex = block_exscan<BS_NT>(cnt > 0 ? 1 : 0, sh, &tot);
-            if (cnt > 0 && mprod + ex < MAX_PROD) {
-                prod_cnt[mprod + ex] = cnt;
-                prod_off[mprod + ex] = d.nd_cand[cn];
-            }
-            mprod += tot;
+        // productive regions of this parent (compact list written at its first visit)
+        int mprod = d.st_nprod[sid];
+        if (mprod > MAX_PROD) { if (tid == 0) atomicOr(&d.c->overflow, OVF_PROD); mprod = MAX_PROD; }
+        {
+            const ProdEnt *pl = d.prod + d.st_prod[sid];
+            for (int k = tid; k < mprod; k += BS_NT) { prod_cnt[k] = (int)pl[k].cnt; prod_off[k] = pl[k].off; }
             __syncthreads();
         }
-        if (mprod > MAX_PROD) { if (tid == 0) atomicOr(&d.c->overflow, OVF_PROD); mprod = MAX_PROD; }
         const int par_dcal = d.st_dcal[sid];
         const uint64_t ph1 = d.st_h[2 * (size_t)sid], ph2 = d.st_h[2 * (size_t)sid + 1];
-        int *digit = (int *)skey;              // [mprod] digits of the chunk's first combo (sort keys not live yet)
-        unsigned long long *bsum = (unsigned long long *)(digit + MAX_PROD);   // [3] sums over the base digits
+        int *digit = (int *)skey;              // [mprod] mixed-radix digits of combo `cur` (sort keys not live yet)
+        unsigned long long *bsum = (unsigned long long *)(digit + MAX_PROD);   // sums over the base digits
+        constexpr int R = 1;                   // combos per thread and chunk (R=4 measured slower: register pressure)
+        // digits of the first combo: zero for a fresh parent, one long division when resuming
+        if (cur == 0) { for (int k = tid; k < mprod; k += BS_NT) digit[k] = 0; }
+        else if (tid == 0) {
+            unsigned long long idx = cur;
+            for (int k = mprod - 1; k >= 0; k--) {
+                unsigned long long c = (unsigned long long)prod_cnt[k], q = idx / c;
+                digit[k] = (int)(idx - q * c);
+                idx = q;
+            }
+        }
+        __syncthreads();
         while (cur < total) {
-            unsigned long long left = total - cur;
-            int chunk = left < BS_NT ? (int)left : BS_NT;
-            if ((unsigned long long)(scnt + chunk) * 2 > scap) {   // (rare) grow again inside a long product walk
+            const unsigned long long left = total - cur;
+            const int chunk = left < (unsigned long long)(BS_NT * R) ? (int)left : BS_NT * R;
+            if ((unsigned long long)(scnt + chunk) * 2 > scap) {   // grow the seen set (rehash into a zeroed region)
                 uint32_t ncap = scap;
-                while ((unsigned long long)(scnt + BS_NT) * 2 > ncap) ncap <<= 1;
+                while ((unsigned long long)(scnt + BS_NT * R) * 2 > ncap) ncap <<= 1;
                 if (tid == 0) {
                     unsigned long long o = atomicAdd(&d.c->seen_top, (unsigned long long)ncap);
                     if (o + ncap > d.seen_cap_total) { atomicOr(&d.c->overflow, OVF_SEEN); *(unsigned long long *)&sh[8] = ~0ULL; }
@@ -592,18 +664,9 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
                 stab = ntab; scap = ncap;
                 if (tid == 0) { d.seen_off[sq] = o; d.seen_cap[sq] = ncap; }
             }
-            // decode combo `cur + tid` (itertools.product: last list fastest, rafft.py:180)
-            // mixed-radix digits of `cur` once per chunk (thread 0), sums over them by the whole block;
-            // thread t then adds t with carry: only the last few digits differ from the base
-            if (tid == 0) {
-                unsigned long long idx = cur;
-                for (int k = mprod - 1; k >= 0; k--) {
-                    unsigned long long c = (unsigned long long)prod_cnt[k], q = idx / c;
-                    digit[k] = (int)(idx - q * c);
-                    idx = q;
-                }
-            }
-            __syncthreads();
+            STAMP(6);   // loop head / seen growth
+            // sums over the base digits by the whole block; thread t then adds its offsets with carry:
+            // only the last few digits differ from the base (itertools.product order, rafft.py:180)
             {
                 unsigned long long a1 = 0, a2 = 0; long long ad = 0;
                 for (int k = tid; k < mprod; k += BS_NT) {
@@ -622,53 +685,87 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
                 }
                 __syncthreads();
             }
-            int isnew = 0, cd_dcal = 0;
-            uint64_t h1 = 0, h2 = 0;
-            if (tid < chunk) {
-                h1 = ph1 + bsum[0]; h2 = ph2 + bsum[1]; cd_dcal = par_dcal + (int)(long long)bsum[2];
-                unsigned int carry = (unsigned int)tid;
-                for (int k = mprod - 1; k >= 0 && carry; k--) {
-                    const unsigned int c = (unsigned int)prod_cnt[k], v = (unsigned int)digit[k] + carry;
-                    const unsigned int nd = v % c;
-                    carry = v / c;
-                    if ((int)nd != digit[k]) {
-                        const Cand *cn = &d.cand[prod_off[k] + nd], *co = &d.cand[prod_off[k] + digit[k]];
-                        cd_dcal += cn->ddcal - co->ddcal; h1 += cn->h1 - co->h1; h2 += cn->h2 - co->h2;
+            STAMP(7);   // base sums
+            int isnew[R], cdd[R];
+            uint64_t hh1[R], hh2[R];
+            int cnt_new = 0;
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                const int pos = tid * R + j;
+                isnew[j] = 0; cdd[j] = 0; hh1[j] = 0; hh2[j] = 0;
+                if (pos < chunk) {
+                    uint64_t h1 = ph1 + bsum[0], h2 = ph2 + bsum[1];
+                    int cd = par_dcal + (int)(long long)bsum[2];
+                    unsigned int carry = (unsigned int)pos;
+                    for (int k = mprod - 1; k >= 0 && carry; k--) {
+                        const unsigned int c = (unsigned int)prod_cnt[k], v = (unsigned int)digit[k] + carry;
+                        const unsigned int nd = v % c;
+                        carry = v / c;
+                        if ((int)nd != digit[k]) {
+                            const Cand *cn = &d.cand[prod_off[k] + nd], *co = &d.cand[prod_off[k] + digit[k]];
+                            cd += cn->ddcal - co->ddcal; h1 += cn->h1 - co->h1; h2 += cn->h2 - co->h2;
+                        }
                     }
+                    if (h1 == 0) h1 = 1;
+                    if (h2 == 0) h2 = 1;
+                    hh1[j] = h1; hh2[j] = h2; cdd[j] = cd;
                 }
-                if (h1 == 0) h1 = 1;
-                if (h2 == 0) h2 = 1;
-                isnew = seen_lookup(stab, scap, h1, h2) ? 0 : 1;
             }
-            int tot, ex = block_exscan<BS_NT>(isnew, sh, &tot);
-            // first position where nb_branch reaches max_branch (checked after every combo)
-            int incl = ex + isnew;
-            int hit = (tid < chunk && nb_branch + incl >= d.max_branch) ? tid : BS_NT;
+#pragma unroll
+            for (int j = 0; j < R; j++)
+                if (tid * R + j < chunk) { isnew[j] = seen_lookup(stab, scap, hh1[j], hh2[j]) ? 0 : 1; cnt_new += isnew[j]; }
+            STAMP(8);   // carry decode + seen lookups (thread 0's share)
+            int tot, ex = block_exscan<BS_NT>(cnt_new, sh, &tot);
+            // first position where nb_branch reaches max_branch (the reference checks after every combo)
+            int hit = BS_NT * R;
+            {
+                int incl = ex;
+#pragma unroll
+                for (int j = 0; j < R; j++) {
+                    incl += isnew[j];
+                    if (tid * R + j < chunk && nb_branch + incl >= d.max_branch && hit == BS_NT * R) hit = tid * R + j;
+                }
+            }
             for (int o = 32; o > 0; o >>= 1) hit = min(hit, __shfl_xor(hit, o, 64));
             __syncthreads();
             if (lane == 0) sh[16 + wv] = hit;
             __syncthreads();
             hit = min(min(sh[16], sh[17]), min(sh[18], sh[19]));
-            const int processed = hit < BS_NT ? hit + 1 : chunk;
-            int accepted_here = 0;
-            if (tid < processed && isnew) {
+            const int processed = hit < BS_NT * R ? hit + 1 : chunk;
+            const int acc_tot = hit < BS_NT * R ? d.max_branch - nb_branch : tot;
+            STAMP(9);   // scans
+            {
                 int ci2 = nchild + ex;
-                if (ci2 < d.ch_cap) {
-                    d.ch_parent[chb + ci2] = (uint16_t)b;
-                    d.ch_combo[chb + ci2] = cur + tid;
-                    d.ch_dcal[chb + ci2] = cd_dcal;
-                    d.ch_h[2 * (chb + ci2)] = h1;
-                    d.ch_h[2 * (chb + ci2) + 1] = h2;
-                } else atomicOr(&d.c->overflow, OVF_SORT);
-                seen_insert(stab, scap, h1, h2);
-                accepted_here = 1;
+#pragma unroll
+                for (int j = 0; j < R; j++) {
+                    const int pos = tid * R + j;
+                    if (pos < processed && isnew[j]) {
+                        if (ci2 < d.ch_cap) {
+                            d.ch_parent[chb + ci2] = (uint16_t)b;
+                            d.ch_combo[chb + ci2] = cur + pos;
+                            d.ch_dcal[chb + ci2] = cdd[j];
+                            d.ch_h[2 * (chb + ci2)] = hh1[j];
+                            d.ch_h[2 * (chb + ci2) + 1] = hh2[j];
+                        } else atomicOr(&d.c->overflow, OVF_SORT);
+                        seen_insert(stab, scap, hh1[j], hh2[j]);
+                        ci2++;
+                    }
+                }
             }
-            int acc_tot, e2 = block_exscan<BS_NT>(accepted_here, sh, &acc_tot);
-            (void)e2;
             nchild += acc_tot; nb_branch += acc_tot; scnt += acc_tot;
             cur += processed;
             __syncthreads();
-            if (nb_branch >= d.max_branch) break;
+            STAMP(10);  // child records + seen insert
+            if (nb_branch >= d.max_branch || cur >= total) break;
+            if (tid == 0) {                    // advance the base digits by `processed`
+                unsigned int carry = (unsigned int)processed;
+                for (int k = mprod - 1; k >= 0 && carry; k--) {
+                    const unsigned int c = (unsigned int)prod_cnt[k], v = (unsigned int)digit[k] + carry;
+                    digit[k] = (int)(v % c);
+                    carry = v / c;
+                }
+            }
+            __syncthreads();
         }
         if (tid == 0) { d.st_cursor[sid] = cur; d.st_total[sid] = total; }
     }
@@ -741,27 +838,34 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
 
     // ---- new = children + beam, stable sort by energy, cut (rafft/rafft.py:206-210)
     const int N = nchild + nbeam;
-    int M = 2; while (M < N) M <<= 1;
-    if (M > sort_cap) { if (tid == 0) atomicOr(&d.c->overflow, OVF_SORT); d.done[sq] = 1; return; }
-    for (int i = tid; i < M; i += BS_NT) {
-        unsigned long long key = ~0ULL;
+    if (N > sort_cap) { if (tid == 0) atomicOr(&d.c->overflow, OVF_SORT); d.done[sq] = 1; return; }
+    for (int i = tid; i < N; i += BS_NT) {
+        unsigned long long key;
         if (i < nchild) key = ((unsigned long long)(uint32_t)(d.ch_dcal[chb + i] + 0x40000000) << 32) | (uint32_t)i;
-        else if (i < N) key = ((unsigned long long)(uint32_t)(d.st_dcal[oldbeam[i - nchild]] + 0x40000000) << 32) | (uint32_t)i;
+        else key = ((unsigned long long)(uint32_t)(d.st_dcal[oldbeam[i - nchild]] + 0x40000000) << 32) | (uint32_t)i;
         skey[i] = key;
     }
     __syncthreads();
-    for (int k2 = 2; k2 <= M; k2 <<= 1)
-        for (int j = k2 >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < M; i += BS_NT) {
-                int ixj = i ^ j;
-                if (ixj > i) {
-                    unsigned long long a = skey[i], bb = skey[ixj];
-                    bool up = (i & k2) == 0;
-                    if (up ? a > bb : a < bb) { skey[i] = bb; skey[ixj] = a; }
+    {
+        // only the max_stack best survive: select them exactly (radix select), then sort just those
+        const int K = N < d.B ? N : d.B;
+        select_smallest_inplace<BS_NT>(skey, N, K, prod_cnt, sh);
+        int M = 2; while (M < K) M <<= 1;
+        for (int i = K + tid; i < M; i += BS_NT) skey[i] = ~0ULL;
+        __syncthreads();
+        for (int k2 = 2; k2 <= M; k2 <<= 1)
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < M; i += BS_NT) {
+                    int ixj = i ^ j;
+                    if (ixj > i) {
+                        unsigned long long a = skey[i], bb = skey[ixj];
+                        bool up = (i & k2) == 0;
+                        if (up ? a > bb : a < bb) { skey[i] = bb; skey[ixj] = a; }
+                    }
                 }
+                __syncthreads();
             }
-            __syncthreads();
-        }
+    }
     STAMP(3);
     const int nnew = N < d.B ? N : d.B;
     // children among the survivors
@@ -858,16 +962,12 @@ __global__ __launch_bounds__(MAT_NT) void materialize_kernel(Dev d)
     const int L = d.seq_len[sq];
     const int my_dcal = d.st_dcal[sid];
     const int node0 = d.st_node0[par], nn = d.st_nnodes[par];
-    int mprod = 0;
-    for (int base = 0; base < nn; base += MAT_NT) {
-        int i = base + tid, cnt = 0, cn = 0;
-        if (i < nn) { cn = d.nd_canon[node0 + i]; cnt = d.nd_ncand[cn]; }
-        unsigned long long bal = __ballot(cnt > 0);
-        int ex = __popcll(bal & ((1ULL << tid) - 1));
-        if (cnt > 0 && mprod + ex < MAX_PROD) { prod_node[mprod + ex] = cn; prod_cnt[mprod + ex] = cnt; }
-        mprod += __popcll(bal);
-    }
+    int mprod = d.st_nprod[par];
     if (mprod > MAX_PROD) mprod = MAX_PROD;
+    {
+        const ProdEnt *pl = d.prod + d.st_prod[par];      // the parent's productive regions (beam_step prepass)
+        for (int k = tid; k < mprod; k += MAT_NT) { prod_node[k] = pl[k].node; prod_cnt[k] = (int)pl[k].cnt; }
+    }
     __syncthreads();
     if (tid == 0) {
         unsigned long long idx = d.st_combo[sid];
@@ -1099,7 +1199,7 @@ __global__ void init_roots_kernel(Dev d)
     // structure sq / node sq are the unfolded structure and its single region (rafft.py:224-231)
     const unsigned long long off = (unsigned long long)d.seq_off[sq];
     for (int x = tid; x < L; x += blockDim.x) { d.db[off + x] = '.'; d.pos[off + x] = (uint16_t)x; }
-    for (int x = tid; x < 2048; x += blockDim.x) d.seen[2 * (size_t)sq * 1024 + x] = 0;   // first seen region
+
     if (tid == 0) {
         d.st_seq[sq] = sq; d.st_dcal[sq] = 0; d.st_h[2 * (size_t)sq] = 0; d.st_h[2 * (size_t)sq + 1] = 0;
         d.st_db[sq] = off; d.st_node0[sq] = sq; d.st_nnodes[sq] = L > 0 ? 1 : 0; d.st_cursor[sq] = 0; d.st_total[sq] = 0;
@@ -1109,7 +1209,7 @@ __global__ void init_roots_kernel(Dev d)
         d.nd_ncand[sq] = -1; d.nd_cand[sq] = 0;
         d.beam[(size_t)sq * d.B] = sq; d.beam_n[sq] = 1; d.nsteps[sq] = 0;
         d.done[sq] = L > 0 ? 0 : 1;
-        d.seen_off[sq] = (uint64_t)sq * 1024; d.seen_cap[sq] = 1024; d.seen_cnt[sq] = 0;
+        d.seen_off[sq] = (uint64_t)sq * SEEN0; d.seen_cap[sq] = SEEN0; d.seen_cnt[sq] = 0;   // zeroed by the host memset
         if (L > 0) {
             int cls = node_class(L, L, 0);
             unsigned int w = atomicAdd(&d.c->n_work[cls], 1u);
