@@ -145,7 +145,7 @@ __host__ __device__ inline ExpandLds expand_lds(int Pmax, int Lmax, int nmax, in
     l.off_code = o; o += al(nmax);
     l.off_S = o; o += al(Lmax + 8);
     l.off_br = o; o += al(4 * brmax);
-    l.off_rk = o; o += al(2 * Kmax);
+    l.off_rk = o; o += al(2 * next_pow2_ge(Kmax));
     l.off_nb = o; o += al(2 * Kmax);
     l.off_mi = o; o += al(2 * Kmax);
     l.off_mj = o; o += al(2 * Kmax);

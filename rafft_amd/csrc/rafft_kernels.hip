@@ -278,6 +278,81 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         // When every lag is searched anyway (2n-1 <= nb_mode) the ranking only breaks dE ties
         // later on, so the sort is skipped and ties are resolved from (value, lag) directly.
         const bool sorted = (m > Kp) || d.dbg.lag != nullptr;
+        // Big regions (P >= 1024): the nb_mode best lags are SELECTED exactly with a byte-wise radix select
+        // on the order-preserving bit pattern of the fp64 value (ties: larger lag first) and only those
+        // are sorted; keyv stays indexed by lag.  Small regions sort all P keys (cheaper there).
+        const bool selected = sorted && NT > 64 && P >= 1024 && Kp < m;
+        if (selected) {
+            int *hist = (int *)(lds + lay.offA + 10 * P);          // 256 bins in the slack of region A
+            int *shs = hist + 256;                                   // scan scratch [32]
+            for (int rep_ = 0; rep_ < 1 + ((d.rep >> 1) & 1); rep_++) {
+            auto ukey = [&](int i) -> unsigned long long {
+                unsigned long long u = (unsigned long long)__double_as_longlong(keyv[i]);
+                return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
+            };
+            unsigned long long prefix = 0;
+            int kk = Kp;
+            for (int pass = 7; pass >= 0; pass--) {
+                for (int i = tid; i < 256; i += NT) hist[i] = 0;
+                __syncthreads();
+                const int sh_hi = 8 * (pass + 1);
+                for (int i = tid; i < m; i += NT) {
+                    const unsigned long long u = ukey(i);
+                    if (pass == 7 || (u >> sh_hi) == (prefix >> sh_hi)) atomicAdd(&hist[(int)((u >> (8 * pass)) & 255ULL)], 1);
+                }
+                __syncthreads();
+                // largest byte b with count(bytes > b) < kk <= count(bytes >= b): suffix scan over the bins
+                {
+                    const int b = 255 - tid;
+                    const int h = tid < 256 ? hist[b] : 0;
+                    int tot, ex = block_exscan<NT>(h, shs, &tot);
+                    if (tid < 256 && ex < kk && kk <= ex + h) { shs[28] = b; shs[29] = kk - ex; }
+                    __syncthreads();
+                }
+                prefix |= (unsigned long long)(unsigned)shs[28] << (8 * pass);
+                kk = shs[29];
+                __syncthreads();
+            }
+            // take every lag with key > prefix and the kk largest lags among key == prefix (sweep from the top)
+            int outn = 0, tie_run = 0;
+            for (int base = 0; base < P; base += NT) {
+                const int i = P - 1 - (base + tid);
+                unsigned long long u = 0;
+                int tie = 0;
+                if (i >= 0 && i < m) { u = ukey(i); tie = (u == prefix) ? 1 : 0; }
+                int ttot, tex = block_exscan<NT>(tie, shs, &ttot);
+                const int g = (i >= 0 && i < m) && (u > prefix || (tie && tie_run + tex < kk)) ? 1 : 0;
+                int gtot, gex = block_exscan<NT>(g, shs, &gtot);
+                if (g) rk[outn + gex] = (uint16_t)i;
+                outn += gtot; tie_run += ttot;
+                __syncthreads();
+            }
+            // sort the selected lags by (value desc, lag desc)
+            int M2 = 2; while (M2 < Kp) M2 <<= 1;
+            for (int i = Kp + tid; i < M2; i += NT) rk[i] = 0xFFFF;
+            __syncthreads();
+            for (int k2 = 2; k2 <= M2; k2 <<= 1)
+                for (int j = k2 >> 1; j > 0; j >>= 1) {
+                    for (int i = tid; i < M2; i += NT) {
+                        int ixj = i ^ j;
+                        if (ixj > i) {
+                            const uint16_t la = rk[i], lb = rk[ixj];
+                            bool a_first;
+                            if (la == 0xFFFF) a_first = false;
+                            else if (lb == 0xFFFF) a_first = true;
+                            else { const double va = keyv[la], vb = keyv[lb]; a_first = (va > vb) || (va == vb && la > lb); }
+                            const bool up = (i & k2) == 0;
+                            if (up ? !a_first : a_first) { rk[i] = lb; rk[ixj] = la; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            for (int r = tid; r < Kp; r += NT)
+                if (d.dbg.lag) { d.dbg.lag[r] = rk[r]; d.dbg.corval[r] = keyv[rk[r]]; }
+            if (tid == 0 && d.dbg.n_ranked) *d.dbg.n_ranked = Kp;
+            __syncthreads();
+        } else {
         if (sorted)
         for (int rep_ = 0; rep_ < 1 + ((d.rep >> 1) & 1); rep_++)
             for (int k2 = 2; k2 <= P; k2 <<= 1) {
@@ -304,31 +379,61 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         }
         if (tid == 0 && d.dbg.n_ranked) *d.dbg.n_ranked = Kp;
         __syncthreads();
+        }
 
-        // ---- window_slide, one lane per ranked lag (rafft/rafft.py:36-83)
-        for (int rep_ = 0; rep_ < 1 + ((d.rep >> 2) & 1); rep_++)
-            for (int r = tid; r < Kp; r += NT) {
+        // ---- window_slide (rafft/rafft.py:36-83).  Small regions: one lane per ranked lag.  Big regions:
+        // each diagonal is cut into C chunks handled by different lanes; a lane first walks back to the last
+        // zero cell before its chunk and replays the recurrence from there (same fp64 operation order, so
+        // values are bit-identical), then the chunk results are merged with the reference's `>=` rule.
+        // (chunking only for regions ranked by selection: their region A no longer holds anything live)
+        const int C = (NT >= 256 && selected) ? max(1, min(8, NT / max(Kp, 1))) : 1;
+        struct WsPart { double score; int nb, mi, mj, any; };
+        WsPart *parts = (WsPart *)(lds + lay.offA);       // big regions only: region A is free by now
+        for (int rep_ = 0; rep_ < 1 + ((d.rep >> 2) & 1); rep_++) {
+            for (int q = tid; q < Kp * C; q += NT) {
+                const int r = q / C, c = q - r * C;
                 const int lagp = rk[r];
                 const int len = lagp < n ? lagp + 1 : 2 * n - lagp - 1;
                 const int len2 = (len >> 1) + (len & 1);
+                const int a = (int)((long long)len2 * c / C), e = (int)((long long)len2 * (c + 1) / C);
+                const int ip0 = lagp < n ? 0 : lagp - n + 1, jp0 = lagp < n ? lagp : n - 1;   // cell i: (ip0+i, jp0-i)
+                int z = a;                                  // replay start: just after the last zero cell before `a`
+                while (z > 0 && wtab[code[ip0 + z - 1] * 5 + code[jp0 - (z - 1)]] != 0.0) z--;
                 double prev = 0.0, mx_s = 0.0;
-                int tmp = 0, mx_nb = 0, mx_i = 0, mx_j = 0;
-                for (int i = 0; i < len2; i++) {
-                    int ip, jp;
-                    if (lagp < n) { ip = i; jp = lagp - i; }
-                    else { ip = lagp - n + 1 + i; jp = n - i - 1; }
+                int tmp = 0, mx_nb = 0, mx_i = 0, mx_j = 0, any = 0;
+                for (int i = z; i < e; i++) {
+                    const int ip = ip0 + i, jp = jp0 - i;
                     double t = wtab[code[ip] * 5 + code[jp]];
                     if (i > 0 && (int)pos[ip] - (int)pos[ip - 1] == 1 && (int)pos[jp + 1] - (int)pos[jp] == 1)
                         t = (prev + t) * t;
                     tmp = (t == 0.0) ? 0 : tmp + 1;
-                    if (t >= mx_s && (int)pos[jp] - (int)pos[ip] > d.min_hp) {
-                        mx_s = t; mx_nb = tmp; mx_i = ip; mx_j = jp;
+                    if (i >= a && t >= mx_s && (int)pos[jp] - (int)pos[ip] > d.min_hp) {
+                        mx_s = t; mx_nb = tmp; mx_i = ip; mx_j = jp; any = 1;
                     }
                     prev = t;
                 }
-                wnb[r] = (uint16_t)mx_nb; wmi[r] = (uint16_t)mx_i; wmj[r] = (uint16_t)mx_j;
-                if (d.dbg.nb) { d.dbg.nb[r] = mx_nb; d.dbg.mi[r] = mx_i; d.dbg.mj[r] = mx_j; d.dbg.score[r] = mx_s; }
+                if (C == 1) {
+                    wnb[r] = (uint16_t)mx_nb; wmi[r] = (uint16_t)mx_i; wmj[r] = (uint16_t)mx_j;
+                    if (d.dbg.nb) { d.dbg.nb[r] = mx_nb; d.dbg.mi[r] = mx_i; d.dbg.mj[r] = mx_j; d.dbg.score[r] = mx_s; }
+                } else {
+                    WsPart w; w.score = mx_s; w.nb = mx_nb; w.mi = mx_i; w.mj = mx_j; w.any = any;
+                    parts[q] = w;
+                }
             }
+            if (C > 1) {
+                __syncthreads();
+                for (int r = tid; r < Kp; r += NT) {
+                    double mx_s = 0.0;
+                    int mx_nb = 0, mx_i = 0, mx_j = 0;
+                    for (int c = 0; c < C; c++) {
+                        const WsPart w = parts[r * C + c];
+                        if (w.any && w.score >= mx_s) { mx_s = w.score; mx_nb = w.nb; mx_i = w.mi; mx_j = w.mj; }
+                    }
+                    wnb[r] = (uint16_t)mx_nb; wmi[r] = (uint16_t)mx_i; wmj[r] = (uint16_t)mx_j;
+                    if (d.dbg.nb) { d.dbg.nb[r] = mx_nb; d.dbg.mi[r] = mx_i; d.dbg.mj[r] = mx_j; d.dbg.score[r] = mx_s; }
+                }
+            }
+        }
         __syncthreads();
 
         // ---- dE of every candidate stem: only the loops it changes, from the branch list
