@@ -192,9 +192,15 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         for (int t = tid; t < nbr; t += NT) brl[t] = brg[t];
         __syncthreads();
 
-        // ---- correlation: conv(A,U), conv(G,C), conv(G,U) through two packed complex FFTs
+        // ---- correlation: conv(A,U), conv(G,C), conv(G,U).
+        // Regions of <= 64 positions (one wavefront holds the whole strand in 64-bit masks) use the exact
+        // direct form: popcount(mask & shifted reversed mask) per lag - the analogue of scipy's own
+        // method="auto" picking direct convolution for short inputs (rafft/utils.py:121).  Longer regions
+        // go through two packed complex FFTs in LDS.  Both give the same exact integer pair counts.
+        const bool direct = (NT == 64) && n <= 64 && !d.force_fft;
         float2 *z1 = (float2 *)(lds + lay.offA);
         float2 *z2 = z1 + P;
+        if (!direct)
         for (int rep_ = 0; rep_ < 1 + (d.rep & 1); rep_++) {   // d.rep: profiling-only phase doubling
             for (int t = tid; t < P; t += NT) {
                 int c = t < n ? code[t] : 0;
@@ -255,7 +261,30 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         // ---- lag values (exact integer pair counts, IEEE fp64 divide) and ranking
         double *keyv = (double *)(lds + lay.offA);
         uint16_t *lagk = (uint16_t *)(lds + lay.offA + 8 * P);
-        {
+        if (direct) {
+            const int c = tid < n ? code[tid] : 0;
+            const unsigned long long mA = __ballot(c == 1), mC = __ballot(c == 2), mG = __ballot(c == 3), mU = __ballot(c == 4);
+            const unsigned long long rU = __brevll(mU) >> (64 - n), rC = __brevll(mC) >> (64 - n);   // strand reversed
+            for (int rep_ = 0; rep_ < 1 + (d.rep & 1); rep_++)
+            for (int k = tid; k < P; k += NT) {
+                double v = -INFINITY;
+                if (k < m) {
+                    const int sft = n - 1 - k;                     // bit i of x* = base at position k - i
+                    const unsigned long long xU = sft >= 0 ? (rU >> sft) : (rU << -sft);
+                    const unsigned long long xC = sft >= 0 ? (rC >> sft) : (rC << -sft);
+                    double nAU = 2.0 * (double)__popcll(mA & xU);
+                    double nGC = 2.0 * (double)__popcll(mG & xC);
+                    double nGU = 2.0 * (double)__popcll(mG & xU);
+                    double raw = nAU * d.au + nGC * d.gc + nGU * d.gu;
+                    int nk = k < m - 1 - k ? k : m - 1 - k;
+                    v = raw / ((double)nk + 1.0);
+                }
+                keyv[k] = v;
+            }
+            __syncthreads();
+            for (int k = tid; k < P; k += NT) lagk[k] = (uint16_t)k;
+            __syncthreads();
+        } else {
             // keyv[k] aliases z1[k] byte for byte and is written by the thread that read it;
             // lagk aliases the head of z2, so it is filled only after every read of z2.
             const float invP = 1.0f / (float)P;

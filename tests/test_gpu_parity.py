@@ -118,3 +118,19 @@ def test_gpu_arena_overflow_regrows_and_stays_exact(monkeypatch):
     monkeypatch.delenv("RAFFT_EST")
     for (f1, t1), (f2, t2) in zip(want, got):
         assert as_lists(t1) == as_lists(t2)
+
+
+def test_gpu_fft_and_direct_correlation_agree(monkeypatch, node_records):
+    """short regions use the popcount form, long ones the LDS FFT; forcing the FFT everywhere must not
+    change a single lag value, rank or trajectory"""
+    rng = np.random.default_rng(31)
+    seqs = ["".join(rng.choice(list("ACGU"), int(n))) for n in rng.integers(20, 140, size=24)]
+    a = rafft_amd.fold_batch(seqs, 100, 10, 1000, traj=True)
+    monkeypatch.setenv("RAFFT_FORCE_FFT", "1")
+    b = rafft_amd.fold_batch(seqs, 100, 10, 1000, traj=True)
+    for r in node_records[:60]:
+        g = R.expand_node(r["seq"], r["db"], r["pos"], r["nb_mode"], r["min_hp"], r["min_nrj"], r["gc"], r["au"], r["gu"])
+        assert g["lag"] == r["lags"] and g["cor"] == [r["cor"][k] for k in r["lags"]]
+    monkeypatch.delenv("RAFFT_FORCE_FFT")
+    for (f1, t1), (f2, t2) in zip(a, b):
+        assert as_lists(t1) == as_lists(t2)
