@@ -217,23 +217,27 @@ struct Caps {
 
 Caps plan_caps(size_t S, size_t sumL, const rafft_params &p, double est)
 {
+    // Arena sizes from measured usage on the BASELINE workloads (benchmark set, L 28..2968, ms 50;
+    // random L 100..3000, ms 200): per surviving structure about 2 + L/100 regions, 0.6 L region
+    // positions, one branch per region, ~5 candidates per region, L dot-bracket bytes (structures of
+    // long sequences are over-represented: they fold for more steps).  Factors below carry ~1.5x slack;
+    // an overflow is detected on the device and the wave is re-run with doubled arenas.
     Caps c;
     const size_t B = (size_t)p.max_stack;
     double avgL = S ? (double)sumL / (double)S : 1.0;
     double nstruct = (double)S * (1.0 + (double)B * est);
     c.st = (size_t)std::min(nstruct, 2.0e9) + 64;
-    double nodes_per = avgL / 16.0 + 3.0;
+    double nodes_per = avgL / 60.0 + 4.0;
     c.nd = (size_t)std::min((double)c.st * nodes_per, 2.0e9) + 64;
-    c.pos = (size_t)((double)sumL + (double)(c.st - S) * avgL) + 4096;
-    c.br = c.pos / 2 + 4096;
-    c.db = c.pos;
-    c.cand = std::max<size_t>(c.nd * (size_t)std::min(std::max(p.nb_mode, 1), 12) + 4096, (size_t)NSHARD * 8192);
+    c.pos = (size_t)((double)sumL + (double)(c.st - S) * avgL * 0.9) + 4096;
+    c.br = c.nd * 3 + 4096;
+    c.db = (size_t)((double)sumL + (double)(c.st - S) * avgL * 1.5) + 4096;
+    c.cand = std::max<size_t>(c.nd * (size_t)std::min(std::max(p.nb_mode, 1), 8) + 4096, (size_t)NSHARD * 16384);
     // accepted children per sequence ~ steps * min(max_branch, ...); regions double and old ones are dropped
     double per_seq_seen = std::min(std::max(24.0 * est * ((double)B + (double)p.max_branch / 4.0), 16384.0), 16777216.0);
     c.seen = S * (size_t)SEEN0 + (size_t)((double)S * per_seq_seen);
     c.trec = p.traj ? S * (size_t)(est * 3 + 16) : S + 16;
     c.tsid = c.trec * B + 16;
-    c.work = c.nd;
     c.mat = S * B + 16;
     // every arena is split into NSHARD sub-arenas: keep a floor per shard so that small batches,
     // whose few structures land on few shards, do not overflow a starved shard
@@ -483,6 +487,7 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
     const double ms_loop = since(tw1);
     auto tw2 = std::chrono::steady_clock::now();
     g.stats.n_steps = std::max<int64_t>(g.stats.n_steps, steps);
+    if (*ovf_bits && getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] wave S=%zu est %.1f overflowed (bits %u) after %d steps, %.1f ms\n", S, est, *ovf_bits, steps, since(tw0));
     if (*ovf_bits) {
         if (*ovf_bits & (OVF_PROD | OVF_SORT))
             return fail(RAFFT_ERR_PARAM, "structure with more than 512 productive regions or sort capacity exceeded");
@@ -579,6 +584,14 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
         fprintf(stderr, "[rafft] beam_step stamps of the longest sequence (cycles): prepass %llu, product loop %llu, single phase %llu, sort %llu, survivors %llu over %llu steps\n",
                 pv[0], pv[1], pv[2], pv[3], pv[4], pv[5]);
     }
+    if (getenv("RAFFT_TRACE")) {
+        auto mx = [&](const ShardCtr *sc) { unsigned long long m = 0, t = 0; for (int i = 0; i < NSHARD; i++) { m = std::max(m, sc[i].v); t += sc[i].v; } return std::make_pair(m, t); };
+        auto nd = mx(hc.node), po = mx(hc.pos), br = mx(hc.br), db = mx(hc.db), ca = mx(hc.cand), pr = mx(hc.prod);
+        fprintf(stderr, "[rafft] arenas used/cap (max shard | total): st %llu/%zu  nd %llu/%llu|%llu  pos %llu/%llu|%llu  br %llu/%llu|%llu  db %llu/%llu  cand %llu/%llu|%llu  prod %llu/%llu  seen %llu/%zu  est %.1f\n",
+                hc.n_struct, c.st, nd.first, (unsigned long long)d.nd_shard_cap, nd.second, po.first, (unsigned long long)d.pos_shard_cap, po.second,
+                br.first, (unsigned long long)d.br_shard_cap, br.second, db.first, (unsigned long long)d.db_shard_cap,
+                ca.first, (unsigned long long)d.cand_shard_cap, ca.second, pr.first, (unsigned long long)d.prod_shard_cap, hc.seen_top, c.seen, est);
+    }
     if (getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] wave S=%zu setup %.2f ms, loop %.2f ms (%d steps), tail %.2f ms\n", S, ms_setup, ms_loop, steps, since(tw2));
     return 0;
 }
@@ -657,7 +670,10 @@ int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs, 
         good.push_back({seqs[i], L, i});
     }
     std::vector<Span> spans;
-    double est0 = 12.0;                       // expected survivors per beam slot; arenas regrow x2 on overflow
+    // expected survivors per beam slot (~ folding steps in which a slot is renewed): grows with length
+    size_t sumL0 = 0;
+    for (auto &sq : good) sumL0 += sq.len;
+    double est0 = 6.0 + (good.empty() ? 0.0 : (double)sumL0 / (double)good.size()) / 100.0;
     if (const char *e = getenv("RAFFT_EST")) if (atof(e) > 0) est0 = atof(e);
     int rc = fold_range(*p, good, est0, *ho, spans, 0);
     if (rc) { free_out(ho); return rc; }

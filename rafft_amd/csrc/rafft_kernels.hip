@@ -539,7 +539,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
             misc[2] = 0;
             if (nkept) {
                 if ((unsigned)nkept > slab_left) {      // reserve a new slab of candidate slots (the rest of the old one is dropped)
-                    const unsigned slab = d.cand_shard_cap >= 4096 ? 256u : 16u;
+                    const unsigned slab = d.cand_shard_cap >= 4096 ? 64u : 16u;
                     const unsigned want = (unsigned)nkept > slab ? (unsigned)nkept : slab;
                     unsigned long long b0 = atomicAdd(&d.c->cand[shard].v, (unsigned long long)want);
                     if (b0 + want > d.cand_shard_cap) { atomicOr(&d.c->overflow, OVF_CAND); misc[2] = 1; slab_left = 0; }
