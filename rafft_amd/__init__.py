@@ -6,4 +6,5 @@
 The compute path is libraffthip.so (hand-written HIP for gfx950); there is no CPU
 fallback - importing works anywhere, calling needs the built library and a GPU."""
 from .rafft import fold, fold_batch, eval_structures, last_stats  # noqa: F401
+from .rafft_kin import kinetics  # noqa: F401
 from .utils import Structure, parse_rafft_output, paired_positions, dot_bracket, read_fasta, format_trajectory  # noqa: F401

@@ -136,3 +136,26 @@ def test_world_size_2_gloo_sharded_fold(tmp_path):
     got = json.loads(outfile.read_text())
     want = [[(x.str_struct, x.dcal) for x in oracle.fold(s, 100, 5, 1000)] for s in seqs]
     assert [[tuple(x) for x in r] for r in got] == want
+
+
+def test_kinetics_matches_reference_python():
+    """rafft_amd.rafft_kin.kinetics == the reference's kinetics on its example fast-folding graphs"""
+    from conftest import load_json_gz
+    from rafft_amd import rafft_kin
+    gold = load_json_gz("kinetics.json.gz")
+    for name, g in gold.items():
+        fp, seq = utils.parse_rafft_output(os.path.join(GOLD, name))
+        traj, times, sl, eq = rafft_kin.kinetics(fp, g["max_time"], g["n_steps"])
+        assert [s.str_struct for s in sl] == g["struct_list"]
+        np.testing.assert_allclose(np.array(times, dtype=float), np.array(g["times"]), rtol=1e-14)
+        np.testing.assert_allclose(np.array([np.asarray(r, dtype=float) for r in traj]), np.array(g["trajectory"]), rtol=1e-9, atol=1e-12)
+        assert [(e[0], e[3]) for e in eq] == [(e[0], e[3]) for e in g["equi"]]
+
+
+def test_rafft_kin_cli_table(capsys):
+    from rafft_amd import rafft_kin
+    rafft_kin.main([os.path.join(GOLD, "example_rafft_20.out"), "-mt", "40"])
+    lines = capsys.readouterr().out.strip().splitlines()
+    assert len(lines) == 68
+    top = lines[-1].split()
+    assert top[0].startswith("(((((.(((") and abs(float(top[1]) - 0.519) < 1e-3 and top[3] == "59"

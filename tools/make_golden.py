@@ -151,3 +151,24 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def kinetics_golden():
+    """tests/golden/kinetics.json.gz: the reference's rafft_kin.kinetics on its own example outputs."""
+    import matplotlib
+    matplotlib.use("Agg")
+    from rafft.rafft_kin import kinetics
+    out = {}
+    for name, mt, ns in (("example_rafft_20.out", 40, 100), ("example_rafft.out", 30, 50)):
+        fp, seq = U.parse_rafft_output(os.path.join(GOLD, name))
+        traj, times, sl, eq = kinetics(fp, mt, ns)
+        out[name] = dict(max_time=mt, n_steps=ns, times=[float(t) for t in times],
+                         trajectory=[[float(x) for x in row] for row in traj],
+                         struct_list=[s.str_struct for s in sl],
+                         equi=[[e[0], float(e[1]), float(e[2]), int(e[3])] for e in eq])
+    with gzip.GzipFile(os.path.join(GOLD, "kinetics.json.gz"), "wb", mtime=0) as fh:
+        fh.write(json.dumps(out, separators=(",", ":")).encode())
+
+
+if __name__ == "__main__" and "--kinetics" in sys.argv:
+    kinetics_golden()
