@@ -160,7 +160,7 @@ struct ClsCfg { int nt, Pmax, Lmax, nmax, brmax, Kmax, lds, grid; bool tab; };
 int class_cfg(int K, ClsCfg out[NCLS])
 {
     const int P[NCLS] = {CLS0_P, CLS1_P, CLS2_P, MAX_P}, LM[NCLS] = {CLS01_L, CLS01_L, RAFFT_MAX_LEN, RAFFT_MAX_LEN};
-    const int NT[NCLS] = {64, 64, 256, 512}, BR[NCLS] = {CLS0_BR, CLS1_BR, MAX_BR, MAX_BR};
+    const int NT[NCLS] = {64, 64, getenv("RAFFT_NT2") ? atoi(getenv("RAFFT_NT2")) : 256, 512}, BR[NCLS] = {CLS0_BR, CLS1_BR, MAX_BR, MAX_BR};
     // LDS-resident energy tables cost occupancy and measured slower on MI355X; class 0 (tiny regions in
     // their own kernel) is kept compiled for experiments but receives no work (see node_class)
     const bool TAB[NCLS] = {true, getenv("RAFFT_TAB1") ? atoi(getenv("RAFFT_TAB1")) != 0 : false, false, false};
@@ -193,7 +193,7 @@ int launch_expand_cls(const Dev &d, int cls, const ClsCfg cf[NCLS], unsigned n_b
 {
     if (cls == 0) return launch_expand<64, true>(d, 0, cf[0], n_blocks, st);
     if (cls == 1) return cf[1].tab ? launch_expand<64, true>(d, 1, cf[1], n_blocks, st) : launch_expand<64, false>(d, 1, cf[1], n_blocks, st);
-    if (cls == 2) return launch_expand<256, false>(d, 2, cf[2], n_blocks, st);
+    if (cls == 2) return cf[2].nt == 512 ? launch_expand<512, false>(d, 2, cf[2], n_blocks, st) : launch_expand<256, false>(d, 2, cf[2], n_blocks, st);
     return launch_expand<512, false>(d, 3, cf[3], n_blocks, st);
 }
 
@@ -313,7 +313,7 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
     ClsCfg cf[NCLS];
     if (int rc = class_cfg(p.nb_mode, cf)) return rc;
     Caps c = plan_caps(S, sumL, p, est);
-    if ((size_t)c.sort_cap * 8 + MAX_PROD * 12 + (size_t)(p.max_stack + 4) * 36 + 256 > 150 * 1024)
+    if ((size_t)c.sort_cap * 8 + MAX_PROD * 16 + (size_t)(p.max_stack + 4) * 36 + 512 > 150 * 1024)
         return fail(RAFFT_ERR_PARAM, "max_branch + 2*max_stack too large for the LDS-resident beam sort");
     const size_t B = (size_t)p.max_stack;
 
@@ -418,12 +418,16 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
         return 0;
     }
 
-    const size_t bs_lds = (size_t)c.sort_cap * 8 + MAX_PROD * 12 + B * sizeof(ParentInfo) + ((B + 3) & ~(size_t)3) * 4 + 128;
+    const size_t bs_lds = (size_t)c.sort_cap * 8 + MAX_PROD * 12 + B * sizeof(ParentInfo) + ((B + 3) & ~(size_t)3) * 4 + 128 +
+                          MAX_PROD * 4 + 16 * 8;
     static size_t bs_lds_set = 0;
     if (bs_lds > bs_lds_set) {
-        HIPCHK(hipFuncSetAttribute((const void *)beam_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds));
+        HIPCHK(hipFuncSetAttribute((const void *)beam_step_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds));
+        HIPCHK(hipFuncSetAttribute((const void *)beam_step_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds));
         bs_lds_set = bs_lds;
     }
+    unsigned n_active = (unsigned)S;     // sequences still folding (from the last read-back)
+    static const unsigned wide_below = getenv("RAFFT_WIDE_BELOW") ? (unsigned)atoi(getenv("RAFFT_WIDE_BELOW")) : 600u;
     HIPCHK(hipStreamSynchronize(st));
     const double ms_setup = since(tw0);
     auto tw1 = std::chrono::steady_clock::now();
@@ -457,7 +461,10 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
         {
             Span sp{next_event(), next_event(), 1};
             HIPCHK(hipEventRecord(sp.a, st));
-            hipLaunchKernelGGL(beam_step_kernel, dim3((unsigned)S), dim3(BS_NT), bs_lds, st, d, c.sort_cap);
+            // few sequences left (the long ones): a 1024-thread workgroup per sequence shortens the serial
+            // chains (16 wavefronts for the prepass, 1024 combos per chunk); many sequences: 256 threads
+            if (n_active < wide_below) hipLaunchKernelGGL(beam_step_kernel<1024>, dim3((unsigned)S), dim3(1024), bs_lds, st, d, c.sort_cap);
+            else hipLaunchKernelGGL(beam_step_kernel<256>, dim3((unsigned)S), dim3(256), bs_lds, st, d, c.sort_cap);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(sp.b, st));
             spans.push_back(sp);
@@ -467,6 +474,7 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
         HIPCHK(hipStreamSynchronize(st));
         if (hc.overflow) { *ovf_bits = hc.overflow; break; }
         if (hc.n_mat == 0) break;
+        n_active = (unsigned)S - hc.n_done;
         {
             Span sp{next_event(), next_event(), 2};
             HIPCHK(hipEventRecord(sp.a, st));

@@ -619,7 +619,6 @@ __device__ inline void seen_insert(uint64_t *tab, uint32_t cap, uint64_t h1, uin
     }
 }
 
-#define BS_NT 256
 
 struct ParentInfo {         // filled by the parallel prepass, one entry per beam member
     unsigned long long total, h1, h2;
@@ -634,6 +633,7 @@ __device__ __forceinline__ unsigned long long sat_mul(unsigned long long a, unsi
 }
 
 // LDS: sort keys (dynamic) + product description + per-parent prepass records
+template <int BS_NT>
 __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
 {
     extern __shared__ __align__(16) unsigned char lds[];
@@ -643,6 +643,8 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
     ParentInfo *pinfo = (ParentInfo *)(prod_cnt + MAX_PROD);                    // [B]
     int *oldbeam = (int *)(pinfo + d.B);                                        // [B]
     int *sh = oldbeam + ((d.B + 3) & ~3);                                       // scratch [32]
+    int *digit = sh + 32;                                                       // [MAX_PROD] odometer digits
+    unsigned long long *bsum = (unsigned long long *)(digit + MAX_PROD);        // [16] partial sums
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int sq = blockIdx.x;
     // snapshot of the region allocators: whatever materialize adds after this kernel is "new"
@@ -758,8 +760,6 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
         }
         const int par_dcal = d.st_dcal[sid];
         const uint64_t ph1 = d.st_h[2 * (size_t)sid], ph2 = d.st_h[2 * (size_t)sid + 1];
-        int *digit = (int *)skey;              // [mprod] mixed-radix digits of combo `cur` (sort keys not live yet)
-        unsigned long long *bsum = (unsigned long long *)(digit + MAX_PROD);   // sums over the base digits
         constexpr int R = 1;                   // combos per thread and chunk (R=4 measured slower: register pressure)
         // digits of the first combo: zero for a fresh parent, one long division when resuming
         if (cur == 0) { for (int k = tid; k < mprod; k += BS_NT) digit[k] = 0; }
@@ -864,7 +864,8 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
             __syncthreads();
             if (lane == 0) sh[16 + wv] = hit;
             __syncthreads();
-            hit = min(min(sh[16], sh[17]), min(sh[18], sh[19]));
+            hit = sh[16];
+            for (int w = 1; w < BS_NT / 64; w++) hit = min(hit, sh[16 + w]);
             const int processed = hit < BS_NT * R ? hit + 1 : chunk;
             const int acc_tot = hit < BS_NT * R ? d.max_branch - nb_branch : tot;
             STAMP(9);   // scans

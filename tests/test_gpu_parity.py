@@ -134,3 +134,14 @@ def test_gpu_fft_and_direct_correlation_agree(monkeypatch, node_records):
     monkeypatch.delenv("RAFFT_FORCE_FFT")
     for (f1, t1), (f2, t2) in zip(a, b):
         assert as_lists(t1) == as_lists(t2)
+
+
+@pytest.mark.parametrize("mb,ms", [(50, 50), (3, 40), (1000, 1), (17, 200)])
+def test_gpu_small_max_branch_large_beam_vs_oracle(mb, ms):
+    """LDS carve-up of the beam step must hold for any (max_branch, max_stack) mix"""
+    rng = np.random.default_rng(41)
+    seqs = ["".join(rng.choice(list("ACGU"), int(n))) for n in (90, 150, 260, 420)]
+    got = rafft_amd.fold_batch(seqs, 100, ms, mb, traj=True)
+    for s, (fin, traj) in zip(seqs, got):
+        _, o = oracle.fold(s, 100, ms, mb, traj=True)
+        assert as_lists(traj) == as_lists(o), (len(s), mb, ms)
