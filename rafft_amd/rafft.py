@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _native as N
-from .utils import Structure
+from .utils import Structure, energies_from_dcal
 
 
 def _params(nb_mode, max_stack, max_branch, min_hp, min_nrj, traj, temp, gc_wei, au_wei, gu_wei):
@@ -53,13 +53,13 @@ def fold_batch(sequences, nb_mode=100, max_stack=1, max_branch=100, min_hp=3, mi
                     _raise_like_reference(sr.status, sequences[i])
                 out.append(None)
                 continue
-            w = sr.length + 1
-            raw = C.string_at(sr.db, sr.n_structs * w)
-            steps = []
-            for s in range(sr.n_steps):
-                o, k = sr.step_off[s], sr.step_size[s]
-                steps.append([Structure(raw[(o + j) * w:(o + j) * w + sr.length].decode(), sr.dcal[o + j])
-                              for j in range(k)])
+            w, Ln = sr.length + 1, sr.length
+            raw = C.string_at(sr.db, sr.n_structs * w).decode("ascii")
+            dcal = np.ctypeslib.as_array(sr.dcal, shape=(sr.n_structs,)) if sr.n_structs else np.zeros(0, np.int32)
+            en = energies_from_dcal(dcal).tolist()
+            dl = dcal.tolist()
+            rows = [Structure(raw[k * w:k * w + Ln], dl[k], en[k]) for k in range(sr.n_structs)]
+            steps = [rows[sr.step_off[s]:sr.step_off[s] + sr.step_size[s]] for s in range(sr.n_steps)]
             out.append((steps[-1], steps) if traj else steps[-1])
     finally:
         L.rafft_free_result(res)

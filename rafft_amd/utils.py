@@ -10,11 +10,12 @@ class Structure:
     `.pair_list`.  `.dcal` is the exact integer energy."""
     __slots__ = ("str_struct", "energy", "dcal", "node_list")
 
-    def __init__(self, str_struct="", dcal=0):
+    def __init__(self, str_struct="", dcal=0, energy=None):
         self.str_struct = str_struct
         self.dcal = int(dcal)
-        self.energy = float(np.float32(np.float32(dcal) / 100.0))
-        self.node_list = []
+        # ViennaRNA: `(float)en / 100.` returned through a float
+        self.energy = float(np.float32(np.float64(np.float32(dcal)) / 100.0)) if energy is None else energy
+        self.node_list = ()
 
     @property
     def pair_list(self):
@@ -22,6 +23,12 @@ class Structure:
 
     def __repr__(self):
         return f"{self.str_struct} {self.energy:6.1f}"
+
+
+def energies_from_dcal(dcal):
+    """Vectorised `(float)en / 100.` (float32 result widened to Python floats)."""
+    d = np.asarray(dcal)
+    return (d.astype(np.float32).astype(np.float64) / 100.0).astype(np.float32).astype(np.float64)
 
 
 def dot_bracket(pair_list, len_seq, SEQ=None):
