@@ -249,7 +249,9 @@ Caps plan_caps(size_t S, size_t sumL, const rafft_params &p, double est)
     c.looptab = 1024; while (c.looptab < 2 * c.nd) c.looptab <<= 1;
     c.ch_cap = p.max_branch + p.max_stack + 8;
     int need = p.max_branch + 2 * p.max_stack + 8;
-    c.sort_cap = 2; while (c.sort_cap < need) c.sort_cap <<= 1;
+    // keys of one step: children + old beam; only the max_stack selected ones are sorted (padded to a power of two)
+    int m2 = 2; while (m2 < p.max_stack) m2 <<= 1;
+    c.sort_cap = std::max((need + 1) & ~1, m2);
     c.bytes = c.st * (4 * 6 + 8 * 6) + c.nd * (4 * 8 + 8 * 3 + 4 * 4 + 16) + c.pos * 2 + c.br * 4 + c.db + c.cand * 32 + c.seen * 16 +
               c.looptab * 8 + c.trec * 16 + c.tsid * 4 + c.mat * 4 + S * (size_t)c.ch_cap * 32 + S * B * 4;
     return c;
@@ -498,7 +500,7 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
     if (*ovf_bits && getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] wave S=%zu est %.1f overflowed (bits %u) after %d steps, %.1f ms\n", S, est, *ovf_bits, steps, since(tw0));
     if (*ovf_bits) {
         if (*ovf_bits & (OVF_PROD | OVF_SORT))
-            return fail(RAFFT_ERR_PARAM, "structure with more than 512 productive regions or sort capacity exceeded");
+            return fail(RAFFT_ERR_PARAM, "structure with more than 256 productive regions or sort capacity exceeded");
         return RAFFT_ERR_CAPACITY;
     }
     // statistics (SURVEY.md 8d algorithmic bytes; only expansions the kernels really executed)
@@ -595,6 +597,7 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
     if (getenv("RAFFT_TRACE")) {
         auto mx = [&](const ShardCtr *sc) { unsigned long long m = 0, t = 0; for (int i = 0; i < NSHARD; i++) { m = std::max(m, sc[i].v); t += sc[i].v; } return std::make_pair(m, t); };
         auto nd = mx(hc.node), po = mx(hc.pos), br = mx(hc.br), db = mx(hc.db), ca = mx(hc.cand), pr = mx(hc.prod);
+        fprintf(stderr, "[rafft] max productive regions per structure: %u (limit %d)\n", hc.max_nprod, MAX_PROD);
         fprintf(stderr, "[rafft] arenas used/cap (max shard | total): st %llu/%zu  nd %llu/%llu|%llu  pos %llu/%llu|%llu  br %llu/%llu|%llu  db %llu/%llu  cand %llu/%llu|%llu  prod %llu/%llu  seen %llu/%zu  est %.1f\n",
                 hc.n_struct, c.st, nd.first, (unsigned long long)d.nd_shard_cap, nd.second, po.first, (unsigned long long)d.pos_shard_cap, po.second,
                 br.first, (unsigned long long)d.br_shard_cap, br.second, db.first, (unsigned long long)d.db_shard_cap,

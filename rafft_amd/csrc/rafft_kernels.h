@@ -44,7 +44,8 @@ struct Counters {
     unsigned int next_work[NCLS];  // dynamic fetch cursors of the persistent expand kernels
     unsigned int overflow;         // bit mask of which arena overflowed
     unsigned int n_done;
-    unsigned int pad_[5];
+    unsigned int max_nprod;        // largest number of productive regions seen in one structure
+    unsigned int pad_[4];
     unsigned long long n_struct, seen_top, trec_n, tsid_top;
     // statistics
     unsigned long long n_expand, sum_n, sum_lags, n_children, sum_struct_len, n_alias, sum_nbr;
@@ -115,7 +116,7 @@ struct Dev {
 #define CLS2_P 2048
 #define MAX_P 8192
 #define MAX_BR 1024
-#define MAX_PROD 512
+#define MAX_PROD 256
 
 __host__ __device__ inline int next_pow2_ge(int x) { int p = 2; while (p < x) p <<= 1; return p; }
 __host__ __device__ inline int node_class(int n, int L, int nbr)

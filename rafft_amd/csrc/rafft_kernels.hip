@@ -156,7 +156,8 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
 
     // Work items are fetched FETCH at a time and candidate slots are reserved in slabs, so that the
     // two atomics with a returned value (a full L2 round trip each) are paid once per several regions.
-    const unsigned FETCH = (NT == 64) ? 4u : 1u;
+    // (only when there is plenty of work: with fewer regions than workgroups every region gets its own)
+    const unsigned FETCH = (NT == 64 && n_items > 4u * gridDim.x) ? 4u : 1u;
     unsigned fetch_base = 0, fetch_left = 0;                 // uniform across the workgroup
     unsigned long long slab_base = 0; unsigned slab_left = 0;   // thread 0 only
 
@@ -718,6 +719,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
             wpos += __popcll(bal);
         }
         if (lane == 0) { d.st_prod[sid] = pbase == ~0ULL ? 0 : pbase; d.st_nprod[sid] = pbase == ~0ULL ? 0 : wpos; }
+        if (lane == 0 && wpos > 64) atomicMax(&d.c->max_nprod, (unsigned int)wpos);
         for (int o = 32; o > 0; o >>= 1) {
             tot = sat_mul(tot, __shfl_xor(tot, o, 64));
             h1 += __shfl_xor(h1, o, 64); h2 += __shfl_xor(h2, o, 64);
