@@ -95,7 +95,8 @@ typedef struct {
     int64_t n_children;       /* children accepted by the combine step */
     int64_t sum_struct_len;   /* sum of L over materialized structures */
     int64_t alg_bytes;        /* algorithmic HBM bytes, SURVEY.md section 8d formula */
-    int64_t alg_bytes_expand; /* the part attributed to the expand kernel */
+    int64_t alg_bytes_expand; /* the part of the dominant kernel expand_kernel<64> (its regions; 3L per structure pro rata) */
+    int64_t alg_bytes_expand_all; /* all three expand size classes */
 } rafft_stats;
 
 /* Select the GPU (HIP ordinal) and upload the energy tables.  Optional: every other

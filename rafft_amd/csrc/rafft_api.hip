@@ -519,7 +519,12 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
     g.stats.sum_struct_len += (int64_t)(hc.sum_struct_len + sumL);
     {
         int64_t ex = 3 * (int64_t)hc.sum_n + 16 * (int64_t)hc.sum_lags + 3 * (int64_t)(hc.sum_struct_len + sumL);
-        g.stats.alg_bytes_expand += ex;
+        // the dominant kernel (size class 1, P <= 512): its own regions, and the per-structure term in
+        // proportion to the regions it expanded
+        double share = hc.n_expand ? (double)hc.cls_items[1] / (double)hc.n_expand : 0.0;
+        g.stats.alg_bytes_expand += 3 * (int64_t)hc.cls_sum_n[1] + 16 * (int64_t)hc.cls_sum_lags[1] +
+                                    (int64_t)(share * 3.0 * (double)(hc.sum_struct_len + sumL));
+        g.stats.alg_bytes_expand_all += ex;
         g.stats.alg_bytes += ex + 2 * (int64_t)hc.sum_struct_len + 8 * (int64_t)(hc.n_struct - S);
     }
 

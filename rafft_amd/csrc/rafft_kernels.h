@@ -49,6 +49,7 @@ struct Counters {
     unsigned long long n_struct, seen_top, trec_n, tsid_top;
     // statistics
     unsigned long long n_expand, sum_n, sum_lags, n_children, sum_struct_len, n_alias, sum_nbr;
+    unsigned long long cls_items[NCLS], cls_sum_n[NCLS], cls_sum_lags[NCLS];   // per size class
     // sharded bump pointers of the arenas filled by materialize / expand
     ShardCtr node[NSHARD], pos[NSHARD], br[NSHARD], db[NSHARD], cand[NSHARD], node_prev[NSHARD], prod[NSHARD];
 };

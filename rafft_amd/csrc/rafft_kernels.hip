@@ -594,6 +594,9 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         atomicAdd(&d.c->sum_n, st_n);
         atomicAdd(&d.c->sum_lags, st_lags);
         atomicAdd(&d.c->sum_nbr, st_nbr);
+        atomicAdd(&d.c->cls_items[cls], st_items);
+        atomicAdd(&d.c->cls_sum_n[cls], st_n);
+        atomicAdd(&d.c->cls_sum_lags[cls], st_lags);
     }
 }
 
