@@ -184,6 +184,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         const int logP = 31 - __clz(P);
         const int Kp = d.K < m ? (d.K > 0 ? d.K : 0) : m;
 
+        for (int rep_ = 0; rep_ < 1 + ((d.rep >> 4) & 1); rep_++) {
         for (int t = tid; t < n; t += NT) {
             int p = posg[t];
             pos[t] = (uint16_t)p;
@@ -192,6 +193,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         for (int x = tid; x < L; x += NT) Sl[x] = codes[x];
         for (int t = tid; t < nbr; t += NT) brl[t] = brg[t];
         __syncthreads();
+        }
 
         // ---- correlation: conv(A,U), conv(G,C), conv(G,U).
         // Regions of <= 64 positions (one wavefront holds the whole strand in 64-bit masks) use the exact
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
             const int c = tid < n ? code[tid] : 0;
             const unsigned long long mA = __ballot(c == 1), mC = __ballot(c == 2), mG = __ballot(c == 3), mU = __ballot(c == 4);
             const unsigned long long rU = __brevll(mU) >> (64 - n), rC = __brevll(mC) >> (64 - n);   // strand reversed
-            for (int rep_ = 0; rep_ < 1 + (d.rep & 1); rep_++)
+            for (int rep_ = 0; rep_ < 1 + (d.rep & 1) + ((d.rep >> 5) & 1); rep_++)
             for (int k = tid; k < P; k += NT) {
                 double v = -INFINITY;
                 if (k < m) {
