@@ -421,6 +421,98 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         const int C = (NT >= 256 && selected) ? max(1, min(8, NT / max(Kp, 1))) : 1;
         struct WsPart { double score; int nb, mi, mj, any; };
         WsPart *parts = (WsPart *)(lds + lay.offA);       // big regions only: region A is free by now
+        // One-wavefront regions (n <= 256): the diagonal of a lag is a bit mask of pairing cells per pair type
+        // (base masks AND shifted reversed base masks, up to four 64-bit words), contiguity is a mask too, and
+        // only the pairing cells are visited - zero cells never change the result.  Same fp64 recurrence on the
+        // visited cells in the same order, same `>=` rule.
+        const bool ws_masks = (NT == 64) && n <= 256 && d.gc >= 0.0 && d.au >= 0.0 && d.gu >= 0.0 && !d.force_fft;
+        if (ws_masks) {
+            // forward masks F[0..3] = A,C,G,U, F[4] = contiguity with the previous position; R[] = reversed strings
+            // (region A: the sort keys are dead once rk[] exists; in unsorted mode keyv/lagk stay live, masks go past them)
+            unsigned long long *F = (unsigned long long *)(lds + lay.offA + (sorted ? 0 : ((10 * P + 15) & ~15)));
+            unsigned long long *R = F + 5 * 4;
+            const int W = (n + 63) >> 6;
+            for (int wq = 0; wq < 4; wq++) {
+                const int t = wq * 64 + tid;
+                const int c0 = t < n ? code[t] : 0;
+                const unsigned long long bA = __ballot(c0 == 1), bC = __ballot(c0 == 2), bG = __ballot(c0 == 3), bU = __ballot(c0 == 4);
+                const unsigned long long bg = __ballot(t >= 1 && t < n && (int)pos[t] - (int)pos[t > 0 ? t - 1 : 0] == 1);
+                if (tid == 0) { F[0 * 4 + wq] = bA; F[1 * 4 + wq] = bC; F[2 * 4 + wq] = bG; F[3 * 4 + wq] = bU; F[4 * 4 + wq] = bg; }
+            }
+            __syncthreads();
+            // reversed strings: bit j of R = bit (n-1-j) of F
+            if (tid < 20) {
+                const int which = tid >> 2, w = tid & 3;
+                unsigned long long out = 0;
+                // word w of R holds bits j = 64w..64w+63  <-  F bits n-1-j
+                // built bit by bit from F (20 lanes, 64 bits each; once per region)
+                for (int bi = 0; bi < 64; bi++) {
+                    const int j = 64 * w + bi, src = n - 1 - j;
+                    if (src >= 0 && src < n && ((F[which * 4 + (src >> 6)] >> (src & 63)) & 1ULL)) out |= 1ULL << bi;
+                }
+                R[which * 4 + w] = out;
+            }
+            __syncthreads();
+            // 64 bits of string X (W words) starting at bit `start` (may be negative / past the end -> zeros)
+            auto window = [&](const unsigned long long *X, int start) -> unsigned long long {
+                if (start >= 64 * W || start <= -64) return 0ULL;
+                const int q = start >> 6, bsh = start & 63;           // arithmetic shift: floor division
+                const unsigned long long lo = (q >= 0 && q < W) ? X[q] : 0ULL;
+                const unsigned long long hi = (q + 1 >= 0 && q + 1 < W) ? X[q + 1] : 0ULL;
+                return bsh ? (lo >> bsh) | (hi << (64 - bsh)) : lo;
+            };
+            for (int rep_ = 0; rep_ < 1 + ((d.rep >> 2) & 1); rep_++)
+            for (int r = tid; r < Kp; r += NT) {
+                const int lagp = rk[r];
+                const int len = lagp < n ? lagp + 1 : 2 * n - lagp - 1;
+                const int len2 = (len >> 1) + (len & 1);
+                const int ip0 = lagp < n ? 0 : lagp - n + 1, jp0 = lagp < n ? lagp : n - 1;
+                int lo = 0, hi = len2;                      // eligible cells (pos[jp]-pos[ip] > min_hp) form a prefix
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if ((int)pos[jp0 - mid] - (int)pos[ip0 + mid] > d.min_hp) lo = mid + 1; else hi = mid;
+                }
+                const int lim = lo;
+                double mx_s = 0.0, prev = 0.0;
+                int mx_nb = 0, mx_i = 0, mx_j = 0, last_ip = -2, runlen = 0;
+                bool found = false;
+                if (lim > 0) {
+                    const int sft = n - 1 - lagp;            // bit ip of x? = base at position lagp - ip
+                    const int ip_end = ip0 + lim;            // cells ip in [ip0, ip_end)
+                    for (int w = ip0 >> 6; w <= (ip_end - 1) >> 6; w++) {
+                        const int wb = w << 6;
+                        const unsigned long long xA = window(R + 0 * 4, wb + sft), xC = window(R + 1 * 4, wb + sft),
+                                                 xG = window(R + 2 * 4, wb + sft), xU = window(R + 3 * 4, wb + sft);
+                        unsigned long long range = ~0ULL;
+                        if (ip0 > wb) range &= ~0ULL << (ip0 - wb);
+                        if (ip_end < wb + 64) range &= (1ULL << (ip_end - wb)) - 1;
+                        const unsigned long long fA = F[0 * 4 + w], fC = F[1 * 4 + w], fG = F[2 * 4 + w], fU = F[3 * 4 + w];
+                        const unsigned long long pGC = d.gc != 0.0 ? ((fG & xC) | (fC & xG)) & range : 0ULL;
+                        const unsigned long long pAU = d.au != 0.0 ? ((fA & xU) | (fU & xA)) & range : 0ULL;
+                        const unsigned long long pGU = d.gu != 0.0 ? ((fG & xU) | (fU & xG)) & range : 0ULL;
+                        unsigned long long cm = F[4 * 4 + w] & window(R + 4 * 4, wb + sft - 1);   // contiguous with previous cell
+                        if (ip0 >= wb && ip0 < wb + 64) cm &= ~(1ULL << (ip0 - wb));          // never for the first cell
+                        unsigned long long any = pGC | pAU | pGU;
+                        while (any) {
+                            const int bi = __ffsll((long long)any) - 1;
+                            any &= any - 1;
+                            const unsigned long long bit = 1ULL << bi;
+                            const int ip = wb + bi;
+                            const double w8 = (pGC & bit) ? d.gc : (pAU & bit) ? d.au : d.gu;
+                            if (ip != last_ip + 1) { prev = 0.0; runlen = 0; }   // previous cell was a zero cell
+                            double t = w8;
+                            if (cm & bit) t = (prev + w8) * w8;
+                            runlen++;
+                            if (t >= mx_s) { mx_s = t; mx_nb = runlen; mx_i = ip; mx_j = lagp - ip; found = true; }
+                            prev = t; last_ip = ip;
+                        }
+                    }
+                    if (!found) { mx_i = ip0 + lim - 1; mx_j = jp0 - (lim - 1); }   // last eligible (zero) cell, nb = 0
+                }
+                wnb[r] = (uint16_t)mx_nb; wmi[r] = (uint16_t)mx_i; wmj[r] = (uint16_t)mx_j;
+                if (d.dbg.nb) { d.dbg.nb[r] = mx_nb; d.dbg.mi[r] = mx_i; d.dbg.mj[r] = mx_j; d.dbg.score[r] = mx_s; }
+            }
+        } else
         for (int rep_ = 0; rep_ < 1 + ((d.rep >> 2) & 1); rep_++) {
             for (int q = tid; q < Kp * C; q += NT) {
                 const int r = q / C, c = q - r * C;
