@@ -157,7 +157,7 @@ int init_ctx(int device)
 
 struct ClsCfg { int nt, Pmax, Lmax, nmax, brmax, Kmax, lds, grid; bool tab; };
 
-int class_cfg(int K, ClsCfg out[NCLS])
+int class_cfg(int K, int maxL, ClsCfg out[NCLS])
 {
     const int P[NCLS] = {CLS0_P, CLS1_P, CLS2_P, MAX_P}, LM[NCLS] = {CLS01_L, CLS01_L, RAFFT_MAX_LEN, RAFFT_MAX_LEN};
     const int NT[NCLS] = {64, 64, getenv("RAFFT_NT2") ? atoi(getenv("RAFFT_NT2")) : 256, 512}, BR[NCLS] = {CLS0_BR, CLS1_BR, MAX_BR, MAX_BR};
@@ -170,8 +170,12 @@ int class_cfg(int K, ClsCfg out[NCLS])
         ExpandLds l = expand_lds(P[c], LM[c], nmax, BR[c], Kmax, TAB[c]);
         int per_cu = std::max(1, std::min(32 / (NT[c] / 64), (160 * 1024) / l.total));
         out[c] = {NT[c], P[c], LM[c], nmax, BR[c], Kmax, l.total, g.n_cu * per_cu, TAB[c]};
-        if (l.total > 160 * 1024)
-            return fail(RAFFT_ERR_PARAM, "nb_mode too large for the LDS-resident expand kernel");
+        // a size class that no region of this batch can reach need not fit (class 3 needs n > 1024)
+        const bool reachable = c < 3 || maxL > CLS2_P / 2;
+        if (l.total > 160 * 1024 && reachable)
+            return fail(RAFFT_ERR_PARAM, "nb_mode too large for the LDS-resident expand kernel: with sequences longer than "
+                                         "1024 nt nb_mode must stay below ~400, otherwise below 2048");
+        if (l.total > 160 * 1024) out[c].lds = 160 * 1024, out[c].Kmax = 1;    // never launched with work
     }
     return 0;
 }
@@ -313,7 +317,9 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
             codes[off[i] + x] = ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : ch == 'U' ? 4 : 0;
         }
     ClsCfg cf[NCLS];
-    if (int rc = class_cfg(p.nb_mode, cf)) return rc;
+    int maxL = 0;
+    for (size_t i = 0; i < S; i++) maxL = std::max(maxL, len[i]);
+    if (int rc = class_cfg(p.nb_mode, maxL, cf)) return rc;
     Caps c = plan_caps(S, sumL, p, est);
     if ((size_t)c.sort_cap * 8 + MAX_PROD * 16 + (size_t)(p.max_stack + 4) * 36 + 512 > 150 * 1024)
         return fail(RAFFT_ERR_PARAM, "max_branch + 2*max_stack too large for the LDS-resident beam sort");

@@ -145,3 +145,20 @@ def test_gpu_small_max_branch_large_beam_vs_oracle(mb, ms):
     for s, (fin, traj) in zip(seqs, got):
         _, o = oracle.fold(s, 100, ms, mb, traj=True)
         assert as_lists(traj) == as_lists(o), (len(s), mb, ms)
+
+
+def test_gpu_randomised_parameters_vs_oracle():
+    """random lengths x (nb_mode, max_stack, max_branch, min_hp, weights): every code path of the
+    expand kernel (popcount / FFT correlation, skip / bitonic / radix-select ranking, mask / chunked
+    window_slide) and of the beam step against the oracle, full trajectories"""
+    rng = np.random.default_rng(77)
+    combos = [(5, 1, 2, 3, (3.0, 2.0, 1.0)), (30, 7, 100, 2, (3.0, 2.0, 1.0)), (100, 50, 1000, 3, (3.0, 2.0, 1.0)),
+              (300, 7, 1000, 6, (1.0, 1.0, 1.0)), (100, 20, 40, 3, (2.5, 1.75, 0.5)), (64, 3, 5, 4, (3.0, 2.0, 0.0)),
+              (1000, 10, 1000, 3, (3.0, 2.0, 1.0))]
+    for nb_mode, ms, mb, hp, (gc, au, gu) in combos:
+        lens = [int(x) for x in rng.integers(8, 330, size=10)] + [int(rng.integers(400, 900))]
+        seqs = ["".join(rng.choice(list("ACGU"), n)) for n in lens]
+        got = rafft_amd.fold_batch(seqs, nb_mode, ms, mb, hp, 0.0, True, 37.0, gc, au, gu)
+        for s, (fin, traj) in zip(seqs, got):
+            _, o = oracle.fold(s, nb_mode, ms, mb, hp, 0.0, True, 37.0, gc, au, gu)
+            assert as_lists(traj) == as_lists(o), (len(s), nb_mode, ms, mb, hp, gc, au, gu)
