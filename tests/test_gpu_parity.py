@@ -162,3 +162,13 @@ def test_gpu_randomised_parameters_vs_oracle():
         for s, (fin, traj) in zip(seqs, got):
             _, o = oracle.fold(s, nb_mode, ms, mb, hp, 0.0, True, 37.0, gc, au, gu)
             assert as_lists(traj) == as_lists(o), (len(s), nb_mode, ms, mb, hp, gc, au, gu)
+
+
+@pytest.mark.parametrize("nb_mode,mb", [(0, 100), (100, 0), (1, 1)])
+def test_gpu_degenerate_parameters_vs_oracle(nb_mode, mb):
+    rng = np.random.default_rng(5)
+    seqs = ["".join(rng.choice(list("ACGU"), n)) for n in (30, 80, 200)]
+    got = rafft_amd.fold_batch(seqs, nb_mode, 5, mb, traj=True)
+    for s, (fin, traj) in zip(seqs, got):
+        _, o = oracle.fold(s, nb_mode, 5, mb, traj=True)
+        assert as_lists(traj) == as_lists(o), (len(s), nb_mode, mb)
