@@ -64,3 +64,14 @@ def test_error_behaviour():
         oracle.fold("ACGT")
     with pytest.raises(np.exceptions.AxisError):
         oracle.fold("")
+
+
+def test_oracle_under_address_sanitizer():
+    """the C oracle folds and evaluates under ASan + UBSan without a report (CPU build only)"""
+    import subprocess
+    here = os.path.join(os.path.dirname(GOLD), "..", "oracle")
+    subprocess.check_call(["make", "-s", "-C", here, "asan_driver"])
+    out = subprocess.run([os.path.join(here, "asan_driver")], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.startswith("asan ok")
