@@ -64,11 +64,11 @@ def cpu_baseline(seqs, n, ms, mb, budget_s=20.0):
     ctx = mp.get_context("fork")
     with ctx.Pool(cores) as pool:
         t0 = time.time()
-        pool.map(_cpu_worker, [(s, n, ms, mb) for s in sample], chunksize=4)
+        finals = pool.map(_cpu_worker, [(s, n, ms, mb) for s in sample], chunksize=4)
         el = time.time() - t0
     return {"value": round(len(sample) / el, 2), "unit": "sequences/s", "cores": cores, "kind": "port",
             "sample": f"every {stride}-th sequence of the workload ({len(sample)} seqs, {el:.1f} s wall), "
-                      f"oracle/rafft_oracle.c, Pool({cores})"}
+                      f"oracle/rafft_oracle.c, Pool({cores})"}, dict(zip(sample, finals))
 
 
 def main():
@@ -88,9 +88,9 @@ def main():
     # CPU baseline first, on rank 0 at N=1 only, BEFORE this process touches the GPU
     # (fork-based pool; the timed GPU region below is unaffected)
     seqs = load_bench_sequences()
-    cpu = None
+    cpu, cpu_finals = None, {}
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(seqs, args.nb_mode, args.max_stack, args.max_branch)
+        cpu, cpu_finals = cpu_baseline(seqs, args.nb_mode, args.max_stack, args.max_branch)
 
     import torch
     import torch.distributed as dist
@@ -121,6 +121,26 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # parity of the measured path against the CPU oracle on the baseline's sample (outside the timed region):
+    # lowest-energy structure identical, energy MAE in kcal/mol (the metric's second half)
+    parity = None
+    if cpu_finals:
+        res = C.POINTER(N.Result)()
+        N.check(lib.rafft_fold_batch(C.byref(p), n, arr, lens, local_rank, C.byref(res)))
+        same, abs_err, cnt = 0, 0.0, 0
+        for i, s in enumerate(seqs):
+            if s not in cpu_finals:
+                continue
+            sr = res.contents.seq[i]
+            db0 = C.string_at(sr.db, sr.length).decode()
+            cdb, cd = cpu_finals[s]
+            same += int(db0 == cdb)
+            abs_err += abs(sr.dcal[0] - cd) / 100.0
+            cnt += 1
+        lib.rafft_free_result(res)
+        parity = {"sequences_compared": cnt, "lowest_energy_structure_identical": same,
+                  "energy_mae_kcal_per_mol": abs_err / max(cnt, 1)}
 
     for _ in range(args.warmup):
         step()
@@ -179,6 +199,7 @@ def main():
             "memoization": {"regions_created": agg["n_nodes_created"] // args.steps,
                             "regions_expanded": agg["n_node_expansions"] // args.steps},
             "cpu_baseline": cpu,
+            "parity_vs_cpu": parity,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

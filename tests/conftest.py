@@ -46,5 +46,7 @@ def bench_rows():
     with gzip.open(os.path.join(GOLD, "bench_inputs.tsv.gz"), "rt") as fh:
         for line in fh:
             f = line.rstrip("\n").split("\t")
-            out.append(dict(name=f[0], seq=f[1], best=(f[2], int(f[3])), ppv=(f[4], int(f[5])), ppv200=(f[6], int(f[7]))))
+            out.append(dict(name=f[0], seq=f[1], best=(f[2], int(f[3])), ppv=(f[4], int(f[5])), ppv200=(f[6], int(f[7])),
+                            known=f[8], best_scores=(float(f[9]), float(f[10])), ppv_scores=(float(f[11]), float(f[12])),
+                            ppv200_scores=(float(f[13]), float(f[14]))))
     return out

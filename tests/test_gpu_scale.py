@@ -50,6 +50,15 @@ def test_gpu_cfg3_benchmark_set_properties(bench_rows):
     assert hit >= 0.90 * len(seqs), hit
     member = sum(1 for r, beam in zip(bench_rows, res) if r["ppv"][0] in {x.str_struct for x in beam})
     assert member >= 0.80 * len(seqs), member
+    # accuracy against the known structures, scored as the reference does (scoring.py:83-94): the means must
+    # sit where the reference's published columns sit (59.1/64.8 lowest-energy, 77.5/79.2 best of the beam)
+    from rafft_amd import scoring
+    low = np.array([scoring.score(min(beam, key=lambda x: x.dcal).str_struct, r["known"]) for r, beam in zip(bench_rows, res)])
+    top = np.array([scoring.best_of(beam, r["known"])[:2] for r, beam in zip(bench_rows, res)])
+    ref_low = np.array([r["best_scores"] for r in bench_rows]).mean(axis=0)
+    ref_top = np.array([r["ppv_scores"] for r in bench_rows]).mean(axis=0)
+    assert np.all(np.abs(low.mean(axis=0) - ref_low) < 1.5), (low.mean(axis=0), ref_low)
+    assert np.all(np.abs(top.mean(axis=0) - ref_top) < 1.5), (top.mean(axis=0), ref_top)
 
 
 def test_gpu_cfg2_full_1000_random_L200():

@@ -136,17 +136,26 @@ def main():
     shutil.copy("/root/reference/example/rafft.out", os.path.join(GOLD, "example_rafft.out"))
     shutil.copy("/root/reference/example/rafft_20.out", os.path.join(GOLD, "example_rafft_20.out"))
 
-    # benchmark inputs + the reference's published result rows
+    bench_fixture(bench)
+
+
+def bench_fixture(bench=None):
+    """tests/golden/bench_inputs.tsv.gz: name, sequence, the reference's published result rows
+    (structure, dcal) for the three RAFFT runs, then the known structure and the published
+    (pvv, sens) of those rows (scoring.py:121-128 columns)."""
+    if bench is None:
+        bench = list(csv.reader(open("/root/reference/benchmark_results/benchmark_cleaned_all_length.csv")))
+
     def rows(f):
-        return {r["seq"]: (r["struct"], round(float(r["nrj"]) * 100)) for r in
+        return {r["seq"]: (r["struct"], round(float(r["nrj"]) * 100), r["pvv"], r["sens"]) for r in
                 csv.DictReader(open("/root/reference/benchmark_results/" + f))}
     best = rows("fft_100n_50ms_best_nrj_scores.csv")
     ppv = rows("fft_100n_50ms_scores.csv")
     ppv200 = rows("fft_200n_200ms_scores.csv")
     with gzip.GzipFile(os.path.join(GOLD, "bench_inputs.tsv.gz"), "wb", mtime=0) as fh:
-        for seq, _known, name in bench:
+        for seq, known, name in bench:
             b, p, q = best[seq], ppv[seq], ppv200[seq]
-            fh.write(f"{name}\t{seq}\t{b[0]}\t{b[1]}\t{p[0]}\t{p[1]}\t{q[0]}\t{q[1]}\n".encode())
+            fh.write(f"{name}\t{seq}\t{b[0]}\t{b[1]}\t{p[0]}\t{p[1]}\t{q[0]}\t{q[1]}\t{known}\t{b[2]}\t{b[3]}\t{p[2]}\t{p[3]}\t{q[2]}\t{q[3]}\n".encode())
 
 
 if __name__ == "__main__":
@@ -172,3 +181,7 @@ def kinetics_golden():
 
 if __name__ == "__main__" and "--kinetics" in sys.argv:
     kinetics_golden()
+
+
+if __name__ == "__main__" and "--bench-fixture" in sys.argv:
+    bench_fixture()
