@@ -84,6 +84,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("BENCH_SAME_GPU"):      # rehearsal of the N>1 path on a one-GPU box
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     # CPU baseline first, on rank 0 at N=1 only, BEFORE this process touches the GPU
     # (fork-based pool; the timed GPU region below is unaffected)
@@ -94,10 +96,17 @@ def main():
 
     import torch
     import torch.distributed as dist
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(local_rank)
+        # RCCL ("nccl") carries only the barrier and the max-reduction of the elapsed time: the fold itself
+        # needs no collective.  BENCH_BACKEND=gloo lets the same path be rehearsed without RCCL.
+        backend = os.environ.get("BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
 
     from rafft_amd import _native as N
@@ -156,7 +165,7 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        t = torch.tensor([el], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
