@@ -16,7 +16,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <deque>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 // kernels (rafft_kernels.hip is compiled into the same translation unit so the
@@ -45,26 +48,34 @@ struct Buf {
 };
 struct PinBuf { void *p = nullptr; size_t cap = 0; };
 
-struct Ctx {
+#define MAX_PIPES 2
+// One workspace = one folding pipeline: own stream set, grow-only device buffers, event pool and a pinned
+// slot for the per-step read-back.
+struct Workspace {
     bool ready = false;
-    int device = -1;
     hipStream_t stream = nullptr;
     hipStream_t cls_stream[NCLS] = {};
-    hipEvent_t ev_fork = nullptr, ev_join[NCLS] = {};
-    int n_cu = 256;
-    EnergyTables *T = nullptr;
-    float2 *tw = nullptr;
-    size_t hbm_total = 0;
-    std::vector<Buf *> bufs;
-    // named workspace buffers (grow-only)
+    hipEvent_t ev_fork = nullptr, ev_join[NCLS] = {}, ev_hot = nullptr;
+    void *hot = nullptr;                 // pinned, 256 B
+    // named device buffers (grow-only)
     Buf codes, seq_off, seq_len, beam, beam_n, done, nsteps, ch_parent, ch_combo, ch_dcal, ch_h, seen, seen_off,
         seen_cap, seen_cnt, st_seq, st_dcal, st_node0, st_nnodes, st_parent, st_h, st_db, st_cursor, st_combo, st_total, st_prod, st_nprod, prod, nd_seq, nd_pdcal,
         nd_n, nd_ci, nd_cj, nd_nbr, nd_canon, nd_ncand, nd_pos, nd_br, nd_cand, pos, br, db, cand, looptab, trec, tsid,
         work0, work1, work2, work3, mat, counters,
         row_sid, row_off, out_db, out_dcal, dbg;
-    std::vector<PinBuf> pin_free;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
+};
+
+struct Ctx {
+    bool ready = false;
+    int device = -1;
+    int n_cu = 256;
+    EnergyTables *T = nullptr;
+    float2 *tw = nullptr;
+    size_t hbm_total = 0;
+    Workspace ws[MAX_PIPES];
+    std::vector<PinBuf> pin_free;
     rafft_stats stats{};
     std::mutex mu;
 };
@@ -94,6 +105,21 @@ uint32_t key_of(const char *s, int m)
     return k;
 }
 
+int init_ws(Workspace &w)
+{
+    if (w.ready) return 0;
+    HIPCHK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+    for (int c = 0; c < NCLS; c++) {
+        HIPCHK(hipStreamCreateWithFlags(&w.cls_stream[c], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&w.ev_join[c], hipEventDisableTiming));
+    }
+    HIPCHK(hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&w.ev_hot, hipEventDisableTiming));
+    HIPCHK(hipHostMalloc(&w.hot, 256, hipHostMallocDefault));
+    w.ready = true;
+    return 0;
+}
+
 int init_ctx(int device)
 {
     if (g.ready && (device < 0 || device == g.device)) return 0;
@@ -108,12 +134,6 @@ int init_ctx(int device)
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     g.hbm_total = prop.totalGlobalMem;
-    HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-    for (int c = 0; c < NCLS; c++) {
-        HIPCHK(hipStreamCreateWithFlags(&g.cls_stream[c], hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&g.ev_join[c], hipEventDisableTiming));
-    }
-    HIPCHK(hipEventCreateWithFlags(&g.ev_fork, hipEventDisableTiming));
     g.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     // energy tables
     EnergyTables *h = new EnergyTables();
@@ -152,7 +172,7 @@ int init_ctx(int device)
     HIPCHK(hipMemcpy(g.tw, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice));
     g.device = device;
     g.ready = true;
-    return 0;
+    return init_ws(g.ws[0]);
 }
 
 struct ClsCfg { int nt, Pmax, Lmax, nmax, brmax, Kmax, lds, grid; bool tab; };
@@ -201,14 +221,14 @@ int launch_expand_cls(const Dev &d, int cls, const ClsCfg cf[NCLS], unsigned n_b
     return launch_expand<512, false>(d, 3, cf[3], n_blocks, st);
 }
 
-hipEvent_t next_event()
+hipEvent_t next_event(Workspace &w)
 {
-    if (g.ev_used == g.ev_pool.size()) {
+    if (w.ev_used == w.ev_pool.size()) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return nullptr;
-        g.ev_pool.push_back(e);
+        w.ev_pool.push_back(e);
     }
-    return g.ev_pool[g.ev_used++];
+    return w.ev_pool[w.ev_used++];
 }
 
 struct Span { hipEvent_t a, b; int kind; };
@@ -299,16 +319,52 @@ struct SeamIn {     // rafft_expand_node: one region of one given structure
     int ci, cj, pdcal;
 };
 
-// run one wave; returns 0, or RAFFT_ERR_CAPACITY with *ovf_bits set, or another error
-int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, HostOut &out, unsigned *ovf_bits,
-             std::vector<Span> &spans, const SeamIn *seam = nullptr)
+// One wave = one batch of sequences folded in lock-step folding steps on one workspace.  It is a small
+// state machine so that a single host thread can drive two waves at once (two pipelines): while it waits
+// for one wave's 152-byte read-back the kernels of the other keep the GPU busy.
+struct Wave {
+    Workspace &g;                 // NB: named `g` on purpose - the buffers used to live in the global context
+    rafft_params p;
+    std::vector<SeqIn> seqs;
+    double est;
+    HostOut &out;
+    std::vector<Span> &spans;
+    const SeamIn *seam;
+    size_t S = 0, sumL = 0, B = 0, bs_lds = 0;
+    std::vector<int> off, len;
+    ClsCfg cf[NCLS];
+    Caps c;
+    Dev d;
+    Counters hc;
+    unsigned n_active = 0, ovf = 0;
+    int steps = 0;
+    bool finished = false;
+    int result = 0;               // valid when finished: 0, RAFFT_ERR_CAPACITY (regrow) or a hard error
+    std::chrono::steady_clock::time_point tw0, tw1;
+    double ms_setup = 0;
+
+    Wave(Workspace &w, const rafft_params &pp, std::vector<SeqIn> s, double e, HostOut &o, std::vector<Span> &sp, const SeamIn *sm = nullptr)
+        : g(w), p(pp), seqs(std::move(s)), est(e), out(o), spans(sp), seam(sm) {}
+
+    double since(std::chrono::steady_clock::time_point t) const
+    {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+    }
+    hipEvent_t next_event() { return ::next_event(g); }
+    int setup();
+    int issue_step();
+    bool ready() { return hipEventQuery(g.ev_hot) == hipSuccess; }
+    int after_beam();
+    int finish();
+};
+
+int Wave::setup()
 {
-    const size_t S = seqs.size();
-    *ovf_bits = 0;
-    auto tw0 = std::chrono::steady_clock::now();
-    auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
-    std::vector<int> off(S), len(S);
-    size_t sumL = 0;
+    S = seqs.size();
+    tw0 = std::chrono::steady_clock::now();
+    g.ev_used = 0;
+    off.resize(S); len.resize(S);
+    sumL = 0;
     for (size_t i = 0; i < S; i++) { off[i] = (int)sumL; len[i] = seqs[i].len; sumL += seqs[i].len; }
     std::vector<uint8_t> codes(sumL + 16, 0);
     for (size_t i = 0; i < S; i++)
@@ -316,14 +372,13 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
             char ch = seqs[i].s[x];
             codes[off[i] + x] = ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : ch == 'U' ? 4 : 0;
         }
-    ClsCfg cf[NCLS];
     int maxL = 0;
     for (size_t i = 0; i < S; i++) maxL = std::max(maxL, len[i]);
     if (int rc = class_cfg(p.nb_mode, maxL, cf)) return rc;
-    Caps c = plan_caps(S, sumL, p, est);
+    c = plan_caps(S, sumL, p, est);
     if ((size_t)c.sort_cap * 8 + MAX_PROD * 16 + (size_t)(p.max_stack + 4) * 36 + 512 > 150 * 1024)
         return fail(RAFFT_ERR_PARAM, "max_branch + 2*max_stack too large for the LDS-resident beam sort");
-    const size_t B = (size_t)p.max_stack;
+    B = (size_t)p.max_stack;
 
 #define ENS(buf, bytes) do { if (int rc_ = ensure(g.buf, (bytes))) return rc_; } while (0)
     ENS(codes, sumL + 16); ENS(seq_off, S * 4); ENS(seq_len, S * 4);
@@ -342,9 +397,9 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
     ENS(counters, sizeof(Counters));
 #undef ENS
 
-    Dev d;
+
     memset(&d, 0, sizeof d);
-    d.T = g.T; d.tw = g.tw; d.S = (int)S;
+    d.T = ::g.T; d.tw = ::g.tw; d.S = (int)S;
     d.codes = (const uint8_t *)g.codes.p; d.seq_off = (const int *)g.seq_off.p; d.seq_len = (const int *)g.seq_len.p;
     d.K = p.nb_mode; d.B = p.max_stack; d.max_branch = p.max_branch; d.min_hp = p.min_hp; d.traj = p.traj;
     d.min_nrj = p.min_nrj; d.gc = p.gc_wei; d.au = p.au_wei; d.gu = p.gu_wei;
@@ -391,11 +446,11 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
         d.prof_seq = best;
     }
 
+
     hipStream_t st = g.stream;
     HIPCHK(hipMemcpyAsync(g.codes.p, codes.data(), sumL + 16, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(g.seq_off.p, off.data(), S * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(g.seq_len.p, len.data(), S * 4, hipMemcpyHostToDevice, st));
-    Counters hc;
     memset(&hc, 0, sizeof hc);
     hc.n_struct = S; hc.seen_top = S * (size_t)SEEN0;
     HIPCHK(hipMemcpyAsync(g.counters.p, &hc, sizeof hc, hipMemcpyHostToDevice, st));
@@ -403,136 +458,127 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
     HIPCHK(hipMemsetAsync(g.seen.p, 0, S * (size_t)SEEN0 * 16, st));   // first region of every sequence; later regions are zeroed on allocation
     hipLaunchKernelGGL(init_roots_kernel, dim3((unsigned)S), dim3(64), 0, st, d);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));      // `codes` (host vector) must outlive the copy
+    bs_lds = (size_t)c.sort_cap * 8 + MAX_PROD * 12 + B * sizeof(ParentInfo) + ((B + 3) & ~(size_t)3) * 4 + 128 + MAX_PROD * 4 + 16 * 8;
+    n_active = (unsigned)S;
+    ms_setup = since(tw0);
+    tw1 = std::chrono::steady_clock::now();
+    return 0;
+}
 
-    if (seam) {
-        // seam: overwrite the root region of sequence 0 with the given loop of the given structure
-        HIPCHK(hipStreamSynchronize(st));
-        HIPCHK(hipMemcpy(g.pos.p, seam->pos.data(), seam->pos.size() * 2, hipMemcpyHostToDevice));
-        if (!seam->br.empty()) HIPCHK(hipMemcpy(g.br.p, seam->br.data(), seam->br.size() * 4, hipMemcpyHostToDevice));
-        int n = (int)seam->pos.size(), nbr = (int)seam->br.size();
-        HIPCHK(hipMemcpy(g.nd_n.p, &n, 4, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(g.nd_nbr.p, &nbr, 4, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(g.nd_ci.p, &seam->ci, 4, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(g.nd_cj.p, &seam->cj, 4, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(g.nd_pdcal.p, &seam->pdcal, 4, hipMemcpyHostToDevice));
-        int cls = node_class(n, seqs[0].len, nbr);
-        int zero = 0;
-        memset(&hc.n_work, 0, sizeof hc.n_work);
-        hc.n_work[cls] = 1;
-        HIPCHK(hipMemcpy(g.counters.p, &hc, sizeof hc, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(d.work[cls], &zero, 4, hipMemcpyHostToDevice));
-        if (int rc = launch_expand_cls(d, cls, cf, 1, st)) return rc;
-        HIPCHK(hipStreamSynchronize(st));
-        return 0;
-    }
-
-    const size_t bs_lds = (size_t)c.sort_cap * 8 + MAX_PROD * 12 + B * sizeof(ParentInfo) + ((B + 3) & ~(size_t)3) * 4 + 128 +
-                          MAX_PROD * 4 + 16 * 8;
-    static size_t bs_lds_set = 0;
-    if (bs_lds > bs_lds_set) {
-        HIPCHK(hipFuncSetAttribute((const void *)beam_step_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds));
-        HIPCHK(hipFuncSetAttribute((const void *)beam_step_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds));
-        bs_lds_set = bs_lds;
-    }
-    unsigned n_active = (unsigned)S;     // sequences still folding (from the last read-back)
+// expand (three size classes on their own streams) -> beam step -> asynchronous read-back of the hot counters
+int Wave::issue_step()
+{
+    hipStream_t st = g.stream;
     static const unsigned wide_below = getenv("RAFFT_WIDE_BELOW") ? (unsigned)atoi(getenv("RAFFT_WIDE_BELOW")) : 600u;
-    HIPCHK(hipStreamSynchronize(st));
-    const double ms_setup = since(tw0);
-    auto tw1 = std::chrono::steady_clock::now();
+    static const bool serial = getenv("RAFFT_SERIAL") && atoi(getenv("RAFFT_SERIAL"));
     const size_t cnt_work_off = offsetof(Counters, n_work);
-    const size_t cnt_work_len = offsetof(Counters, overflow) - cnt_work_off;   // n_work[3], n_mat, next_work[3]
+    const size_t cnt_work_len = offsetof(Counters, overflow) - cnt_work_off;   // n_work[], n_mat, next_work[]
     const size_t hot_len = offsetof(Counters, node);
-    int steps = 0;
-    for (;;) {
-        // ---- expand: the three size classes run concurrently on their own streams
-        HIPCHK(hipEventRecord(g.ev_fork, st));
-        Span wall{next_event(), next_event(), 4};
-        HIPCHK(hipEventRecord(wall.a, st));
-        for (int cls = NCLS - 1; cls >= 1; cls--) {   // big-LDS classes first; class 0 is unused (node_class)
-            static const bool serial = getenv("RAFFT_SERIAL") && atoi(getenv("RAFFT_SERIAL"));
-            hipStream_t cs = serial ? st : g.cls_stream[cls];
-            if (!serial) HIPCHK(hipStreamWaitEvent(cs, g.ev_fork, 0));
-            Span sp{next_event(), next_event(), 10 + cls};
-            HIPCHK(hipEventRecord(sp.a, cs));
-            if (int rc = launch_expand_cls(d, cls, cf, (unsigned)cf[cls].grid, cs)) return rc;
-            HIPCHK(hipEventRecord(sp.b, cs));
-            spans.push_back(sp);
-            if (!serial) {
-                HIPCHK(hipEventRecord(g.ev_join[cls], cs));
-                HIPCHK(hipStreamWaitEvent(st, g.ev_join[cls], 0));
-            }
-        }
-        HIPCHK(hipEventRecord(wall.b, st));
-        spans.push_back(wall);
-        g.stats.n_expand_launches++;
-        HIPCHK(hipMemsetAsync((char *)g.counters.p + cnt_work_off, 0, cnt_work_len, st));
-        {
-            Span sp{next_event(), next_event(), 1};
-            HIPCHK(hipEventRecord(sp.a, st));
-            // few sequences left (the long ones): a 1024-thread workgroup per sequence shortens the serial
-            // chains (16 wavefronts for the prepass, 1024 combos per chunk); many sequences: 256 threads
-            if (n_active < wide_below) hipLaunchKernelGGL(beam_step_kernel<1024>, dim3((unsigned)S), dim3(1024), bs_lds, st, d, c.sort_cap);
-            else hipLaunchKernelGGL(beam_step_kernel<256>, dim3((unsigned)S), dim3(256), bs_lds, st, d, c.sort_cap);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipEventRecord(sp.b, st));
-            spans.push_back(sp);
-        }
-        steps++;
-        HIPCHK(hipMemcpyAsync(&hc, g.counters.p, hot_len, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        if (hc.overflow) { *ovf_bits = hc.overflow; break; }
-        if (hc.n_mat == 0) break;
-        n_active = (unsigned)S - hc.n_done;
-        {
-            Span sp{next_event(), next_event(), 2};
-            HIPCHK(hipEventRecord(sp.a, st));
-            hipLaunchKernelGGL(materialize_kernel, dim3(hc.n_mat), dim3(MAT_NT), 0, st, d);
-            HIPCHK(hipGetLastError());
-            hipLaunchKernelGGL(dedupe_kernel, dim3(g.n_cu * 4), dim3(256), 0, st, d);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipEventRecord(sp.b, st));
-            spans.push_back(sp);
-        }
-        if (const char *tr = getenv("RAFFT_TRACE")) if (atoi(tr) >= 2) {
-            Counters h2;
-            HIPCHK(hipMemcpyAsync(&h2, g.counters.p, hot_len, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            fprintf(stderr, "[rafft] step %d: n_mat %u -> work %u %u %u %u\n", steps, hc.n_mat, h2.n_work[0], h2.n_work[1], h2.n_work[2], h2.n_work[3]);
+    HIPCHK(hipEventRecord(g.ev_fork, st));
+    Span wall{next_event(), next_event(), 4};
+    HIPCHK(hipEventRecord(wall.a, st));
+    for (int cls = NCLS - 1; cls >= 1; cls--) {   // big-LDS classes first; class 0 is unused (node_class)
+        hipStream_t cs = serial ? st : g.cls_stream[cls];
+        if (!serial) HIPCHK(hipStreamWaitEvent(cs, g.ev_fork, 0));
+        Span sp{next_event(), next_event(), 10 + cls};
+        HIPCHK(hipEventRecord(sp.a, cs));
+        if (int rc = launch_expand_cls(d, cls, cf, (unsigned)cf[cls].grid, cs)) return rc;
+        HIPCHK(hipEventRecord(sp.b, cs));
+        spans.push_back(sp);
+        if (!serial) {
+            HIPCHK(hipEventRecord(g.ev_join[cls], cs));
+            HIPCHK(hipStreamWaitEvent(st, g.ev_join[cls], 0));
         }
     }
+    HIPCHK(hipEventRecord(wall.b, st));
+    spans.push_back(wall);
+    ::g.stats.n_expand_launches++;
+    HIPCHK(hipMemsetAsync((char *)g.counters.p + cnt_work_off, 0, cnt_work_len, st));
+    {
+        Span sp{next_event(), next_event(), 1};
+        HIPCHK(hipEventRecord(sp.a, st));
+        // few sequences left (the long ones): a 1024-thread workgroup per sequence shortens the serial
+        // chains (16 wavefronts for the prepass, 1024 combos per chunk); many sequences: 256 threads
+        if (n_active < wide_below) hipLaunchKernelGGL(beam_step_kernel<1024>, dim3((unsigned)S), dim3(1024), bs_lds, st, d, c.sort_cap);
+        else hipLaunchKernelGGL(beam_step_kernel<256>, dim3((unsigned)S), dim3(256), bs_lds, st, d, c.sort_cap);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(sp.b, st));
+        spans.push_back(sp);
+    }
+    steps++;
+    HIPCHK(hipMemcpyAsync(g.hot, g.counters.p, hot_len, hipMemcpyDeviceToHost, st));   // pinned: truly asynchronous
+    HIPCHK(hipEventRecord(g.ev_hot, st));
+    return 0;
+}
+
+// the beam step of this wave has finished: stop, or materialize the new beam members and go on
+int Wave::after_beam()
+{
+    hipStream_t st = g.stream;
+    const size_t hot_len = offsetof(Counters, node);
+    memcpy(&hc, g.hot, hot_len);
+    if (hc.overflow) { ovf = hc.overflow; return finish(); }
+    if (hc.n_mat == 0) return finish();
+    n_active = (unsigned)S - hc.n_done;
+    {
+        Span sp{next_event(), next_event(), 2};
+        HIPCHK(hipEventRecord(sp.a, st));
+        hipLaunchKernelGGL(materialize_kernel, dim3(hc.n_mat), dim3(MAT_NT), 0, st, d);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(dedupe_kernel, dim3(::g.n_cu * 4), dim3(256), 0, st, d);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(sp.b, st));
+        spans.push_back(sp);
+    }
+    if (const char *tr = getenv("RAFFT_TRACE")) if (atoi(tr) >= 2) {
+        Counters h2;
+        HIPCHK(hipMemcpyAsync(&h2, g.counters.p, hot_len, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        fprintf(stderr, "[rafft] step %d: n_mat %u -> work %u %u %u %u\n", steps, hc.n_mat, h2.n_work[0], h2.n_work[1], h2.n_work[2], h2.n_work[3]);
+    }
+    return issue_step();
+}
+
+int Wave::finish()
+{
+    hipStream_t st = g.stream;
+    finished = true;
     const double ms_loop = since(tw1);
     auto tw2 = std::chrono::steady_clock::now();
-    g.stats.n_steps = std::max<int64_t>(g.stats.n_steps, steps);
-    if (*ovf_bits && getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] wave S=%zu est %.1f overflowed (bits %u) after %d steps, %.1f ms\n", S, est, *ovf_bits, steps, since(tw0));
-    if (*ovf_bits) {
-        if (*ovf_bits & (OVF_PROD | OVF_SORT))
-            return fail(RAFFT_ERR_PARAM, "structure with more than 256 productive regions or sort capacity exceeded");
-        return RAFFT_ERR_CAPACITY;
+    ::g.stats.n_steps = std::max<int64_t>(::g.stats.n_steps, steps);
+    if (ovf && getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] wave S=%zu est %.1f overflowed (bits %u) after %d steps, %.1f ms\n", S, est, ovf, steps, since(tw0));
+    if (ovf) {
+        HIPCHK(hipStreamSynchronize(st));
+        if (ovf & (OVF_PROD | OVF_SORT))
+            return result = fail(RAFFT_ERR_PARAM, "structure with more than 256 productive regions or sort capacity exceeded");
+        return result = RAFFT_ERR_CAPACITY;
     }
     // statistics (SURVEY.md 8d algorithmic bytes; only expansions the kernels really executed)
     HIPCHK(hipMemcpy(&hc, g.counters.p, sizeof hc, hipMemcpyDeviceToHost));
     {
         unsigned long long nn = S;
         for (int i = 0; i < NSHARD; i++) nn += hc.node[i].v;
-        g.stats.n_nodes_created += (int64_t)nn;
+        ::g.stats.n_nodes_created += (int64_t)nn;
     }
-    g.stats.n_node_expansions += hc.n_expand;
-    g.stats.n_nodes_aliased += (int64_t)hc.n_alias;
-    g.stats.sum_node_len += hc.sum_n;
-    g.stats.sum_lags += hc.sum_lags;
-    g.stats.n_structs += (int64_t)hc.n_struct;
-    g.stats.n_children += hc.n_children;
-    g.stats.sum_struct_len += (int64_t)(hc.sum_struct_len + sumL);
+    ::g.stats.n_node_expansions += hc.n_expand;
+    ::g.stats.n_nodes_aliased += (int64_t)hc.n_alias;
+    ::g.stats.sum_node_len += hc.sum_n;
+    ::g.stats.sum_lags += hc.sum_lags;
+    ::g.stats.n_structs += (int64_t)hc.n_struct;
+    ::g.stats.n_children += hc.n_children;
+    ::g.stats.sum_struct_len += (int64_t)(hc.sum_struct_len + sumL);
     {
         int64_t ex = 3 * (int64_t)hc.sum_n + 16 * (int64_t)hc.sum_lags + 3 * (int64_t)(hc.sum_struct_len + sumL);
         // the dominant kernel (size class 1, P <= 512): its own regions, and the per-structure term in
         // proportion to the regions it expanded
         double share = hc.n_expand ? (double)hc.cls_items[1] / (double)hc.n_expand : 0.0;
-        g.stats.alg_bytes_expand += 3 * (int64_t)hc.cls_sum_n[1] + 16 * (int64_t)hc.cls_sum_lags[1] +
+        ::g.stats.alg_bytes_expand += 3 * (int64_t)hc.cls_sum_n[1] + 16 * (int64_t)hc.cls_sum_lags[1] +
                                     (int64_t)(share * 3.0 * (double)(hc.sum_struct_len + sumL));
-        g.stats.alg_bytes_expand_all += ex;
-        g.stats.alg_bytes += ex + 2 * (int64_t)hc.sum_struct_len + 8 * (int64_t)(hc.n_struct - S);
+        ::g.stats.alg_bytes_expand_all += ex;
+        ::g.stats.alg_bytes += ex + 2 * (int64_t)hc.sum_struct_len + 8 * (int64_t)(hc.n_struct - S);
     }
+
 
     // ---- gather the trajectory records and format rows on the device
     std::vector<int4> trec(hc.trec_n);
@@ -615,29 +661,99 @@ int run_wave(const rafft_params &p, const std::vector<SeqIn> &seqs, double est, 
                 ca.first, (unsigned long long)d.cand_shard_cap, ca.second, pr.first, (unsigned long long)d.prod_shard_cap, hc.seen_top, c.seen, est);
     }
     if (getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] wave S=%zu setup %.2f ms, loop %.2f ms (%d steps), tail %.2f ms\n", S, ms_setup, ms_loop, steps, since(tw2));
+    return result = 0;
+}
+
+// rafft_expand_node: one region of one given structure through the expand kernel
+int run_seam(const rafft_params &p, const std::vector<SeqIn> &one, HostOut &ho, std::vector<Span> &spans, const SeamIn &sm)
+{
+    Wave w(g.ws[0], p, one, 4.0, ho, spans, &sm);
+    if (int rc = w.setup()) return rc;
+    Workspace &W = g.ws[0];
+    // overwrite the root region of sequence 0 with the given loop of the given structure
+    HIPCHK(hipMemcpy(W.pos.p, sm.pos.data(), sm.pos.size() * 2, hipMemcpyHostToDevice));
+    if (!sm.br.empty()) HIPCHK(hipMemcpy(W.br.p, sm.br.data(), sm.br.size() * 4, hipMemcpyHostToDevice));
+    int n = (int)sm.pos.size(), nbr = (int)sm.br.size();
+    HIPCHK(hipMemcpy(W.nd_n.p, &n, 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(W.nd_nbr.p, &nbr, 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(W.nd_ci.p, &sm.ci, 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(W.nd_cj.p, &sm.cj, 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(W.nd_pdcal.p, &sm.pdcal, 4, hipMemcpyHostToDevice));
+    int cls = node_class(n, one[0].len, nbr);
+    int zero = 0;
+    memset(&w.hc.n_work, 0, sizeof w.hc.n_work);
+    w.hc.n_work[cls] = 1;
+    HIPCHK(hipMemcpy(W.counters.p, &w.hc, sizeof w.hc, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(w.d.work[cls], &zero, 4, hipMemcpyHostToDevice));
+    if (int rc = launch_expand_cls(w.d, cls, w.cf, 1, W.stream)) return rc;
+    HIPCHK(hipStreamSynchronize(W.stream));
     return 0;
 }
 
-int fold_range(const rafft_params &p, std::vector<SeqIn> seqs, double est, HostOut &out, std::vector<Span> &spans, int depth)
+struct Job { std::vector<SeqIn> seqs; double est; int depth; };
+
+// Drive up to MAX_PIPES waves at once from this one host thread.  Each pipeline has its own workspace and
+// job queue; a job that does not fit the pipeline's share of HBM is split, one that overflows its arenas is
+// re-queued with larger ones.
+int run_pipelines(const rafft_params &p, std::vector<std::deque<Job>> &queues, HostOut &out, std::vector<Span> &spans)
 {
-    if (seqs.empty()) return 0;
-    size_t sumL = 0;
-    for (auto &s : seqs) sumL += s.len;
-    const size_t budget = (size_t)((double)g.hbm_total * 0.55);
-    Caps c = plan_caps(seqs.size(), sumL, p, est);
-    if (c.bytes > budget && seqs.size() > 1) {
-        size_t h = seqs.size() / 2;
-        std::vector<SeqIn> a(seqs.begin(), seqs.begin() + h), b(seqs.begin() + h, seqs.end());
-        if (int rc = fold_range(p, a, est, out, spans, depth)) return rc;
-        return fold_range(p, b, est, out, spans, depth);
+    const int np = (int)queues.size();
+    std::vector<std::unique_ptr<Wave>> cur(np);
+    std::vector<Job> curjob(np);
+    const size_t budget = (size_t)((double)g.hbm_total * 0.55 / (double)std::max(np, 1));
+    for (;;) {
+        bool any = false, progressed = false;
+        for (int i = 0; i < np; i++) {
+            if (!cur[i]) {
+                if (queues[i].empty()) continue;
+                Job job = std::move(queues[i].front());
+                queues[i].pop_front();
+                progressed = true;
+                if (job.seqs.empty()) continue;
+                size_t sl = 0;
+                for (auto &s : job.seqs) sl += s.len;
+                Caps cc = plan_caps(job.seqs.size(), sl, p, job.est);
+                if (cc.bytes > budget && job.seqs.size() > 1) {
+                    size_t h = job.seqs.size() / 2;
+                    Job a{std::vector<SeqIn>(job.seqs.begin(), job.seqs.begin() + h), job.est, job.depth};
+                    Job b{std::vector<SeqIn>(job.seqs.begin() + h, job.seqs.end()), job.est, job.depth};
+                    queues[i].push_front(std::move(b));
+                    queues[i].push_front(std::move(a));
+                    any = true;
+                    continue;
+                }
+                if (int rc = init_ws(g.ws[i])) return rc;
+                cur[i].reset(new Wave(g.ws[i], p, job.seqs, job.est, out, spans));
+                curjob[i] = std::move(job);
+                if (int rc = cur[i]->setup()) return rc;
+                if (int rc = cur[i]->issue_step()) return rc;
+            }
+            any = true;
+            if (cur[i]->ready()) {
+                progressed = true;
+                int rc = cur[i]->after_beam();
+                if (cur[i]->finished) {
+                    rc = cur[i]->result;
+                    if (rc == RAFFT_ERR_CAPACITY) {
+                        if (curjob[i].depth >= 12)
+                            return fail(RAFFT_ERR_CAPACITY, "HBM arena overflow after 12 regrowths (bits " + std::to_string(cur[i]->ovf) + ")");
+                        Job again{std::move(curjob[i].seqs), curjob[i].est * (curjob[i].depth >= 2 ? 4.0 : 2.0), curjob[i].depth + 1};
+                        queues[i].push_front(std::move(again));
+                    } else if (rc)
+                        return rc;
+                    cur[i].reset();
+                } else if (rc)
+                    return rc;
+            }
+        }
+        if (!any) {
+            bool left = false;
+            for (auto &q : queues) left = left || !q.empty();
+            if (!left) break;
+        }
+        if (!progressed) std::this_thread::yield();
     }
-    unsigned ovf = 0;
-    int rc = run_wave(p, seqs, est, out, &ovf, spans);
-    if (rc == RAFFT_ERR_CAPACITY) {
-        if (depth >= 12) return fail(RAFFT_ERR_CAPACITY, "HBM arena overflow after 12 regrowths (bits " + std::to_string(ovf) + ")");
-        return fold_range(p, seqs, est * (depth >= 2 ? 4.0 : 2.0), out, spans, depth + 1);
-    }
-    return rc;
+    return 0;
 }
 
 void free_out(HostOut *o)
@@ -671,7 +787,6 @@ int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs, 
     if (int rc = init_ctx(device)) return rc;
     auto t0 = std::chrono::steady_clock::now();
     memset(&g.stats, 0, sizeof g.stats);
-    g.ev_used = 0;
     HostOut *ho = new HostOut();
     ho->seq.resize(n_seq); ho->step_size.resize(n_seq); ho->step_off.resize(n_seq);
     ho->dcal_ptr.assign(n_seq, nullptr); ho->db_ptr.assign(n_seq, nullptr);
@@ -692,13 +807,55 @@ int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs, 
         good.push_back({seqs[i], L, i});
     }
     std::vector<Span> spans;
-    // expected survivors per beam slot (~ folding steps in which a slot is renewed): grows with length
-    size_t sumL0 = 0;
-    for (auto &sq : good) sumL0 += sq.len;
-    double est0 = 6.0 + (good.empty() ? 0.0 : (double)sumL0 / (double)good.size()) / 100.0;
-    if (const char *e = getenv("RAFFT_EST")) if (atof(e) > 0) est0 = atof(e);
-    int rc = fold_range(*p, good, est0, *ho, spans, 0);
-    if (rc) { free_out(ho); return rc; }
+    // ---- pipelines.  Folds are independent, so how the batch is cut cannot change any result.  With enough
+    // sequences the batch is cut by length into two pipelines driven from this one thread: the long sequences
+    // need twice as many (latency-bound, nearly empty) folding steps as the short ones, and run beside them.
+    int split_len = 0;
+    {
+        const char *sp = getenv("RAFFT_SPLIT");
+        // default: one pipeline.  Two pipelines in one process were measured SLOWER on MI355X (47-73 ms against
+        // 31 ms for the benchmark batch: the persistent grids of both pipelines compete for dispatch), although
+        // two processes sharing the GPU gain 27 %.  RAFFT_SPLIT=<len> (or -1 for an automatic cut) enables it.
+        int want = sp ? atoi(sp) : 0;
+        if (good.size() >= 512 && want != 0) {
+            if (want > 0) split_len = want;
+            else {   // default cut: the length above which ~1/16 of the total length lies
+                std::vector<int> ls;
+                size_t tot = 0;
+                for (auto &sq : good) { ls.push_back(sq.len); tot += sq.len; }
+                std::sort(ls.begin(), ls.end(), std::greater<int>());
+                size_t acc = 0;
+                for (int L_ : ls) { acc += L_; split_len = L_; if (acc * 16 >= tot) break; }
+            }
+        }
+    }
+    std::vector<std::deque<Job>> queues;
+    {
+        auto est_of = [&](const std::vector<SeqIn> &v) {
+            // expected survivors per beam slot (~ folding steps in which a slot is renewed): grows with length
+            size_t sl = 0;
+            for (auto &sq : v) sl += sq.len;
+            double e0 = 6.0 + (v.empty() ? 0.0 : (double)sl / (double)v.size()) / 100.0;
+            if (const char *e = getenv("RAFFT_EST")) if (atof(e) > 0) e0 = atof(e);
+            return e0;
+        };
+        std::vector<SeqIn> shorts, longs;
+        for (auto &sq : good) (split_len > 0 && sq.len >= split_len ? longs : shorts).push_back(sq);
+        if (!longs.empty() && !shorts.empty()) {
+            queues.resize(2);
+            queues[0].push_back(Job{longs, est_of(longs), 0});      // the long tail starts first
+            queues[1].push_back(Job{shorts, est_of(shorts), 0});
+        } else {
+            queues.resize(1);
+            queues[0].push_back(Job{good, est_of(good), 0});
+        }
+    }
+    int rc = good.empty() ? 0 : run_pipelines(*p, queues, *ho, spans);
+    if (rc) {
+        for (int i = 0; i < MAX_PIPES; i++) if (g.ws[i].ready) { hipError_t e_ = hipStreamSynchronize(g.ws[i].stream); (void)e_; }
+        free_out(ho);
+        return rc;
+    }
     for (auto &sp : spans) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
@@ -787,10 +944,10 @@ static int eval_structures_impl(int n, const char *const *seqs, const char *cons
     HIPCHK(hipMemcpy(dp, pts.data(), (tot + 16) * 2, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(doff, off.data(), n * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dlen, len.data(), n * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(eval_kernel, dim3(n), dim3(64), 0, g.stream, g.T, n, (const uint8_t *)dc, (const int16_t *)dp,
+    hipLaunchKernelGGL(eval_kernel, dim3(n), dim3(64), 0, g.ws[0].stream, g.T, n, (const uint8_t *)dc, (const int16_t *)dp,
                        (const long long *)doff, (const int *)dlen, (int *)dout, (int *)dst);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipStreamSynchronize(g.ws[0].stream));
     std::vector<int> st2(n);
     HIPCHK(hipMemcpy(dcal_out, dout, n * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(st2.data(), dst, n * 4, hipMemcpyDeviceToHost));
@@ -846,8 +1003,8 @@ int rafft_expand_node(const rafft_params *p, const char *seq, const char *db, co
     if (int rc = eval_structures_impl(1, &seq, &db, &par_dcal, nullptr)) return rc;
     sm.pdcal = par_dcal;
     const int K = std::max(1, std::min(p->nb_mode, 2 * n - 1));
-    if (int rc = ensure(g.dbg, (size_t)K * (4 * 7 + 8 * 2) + 64)) return rc;
-    char *b = (char *)g.dbg.p;
+    if (int rc = ensure(g.ws[0].dbg, (size_t)K * (4 * 7 + 8 * 2) + 64)) return rc;
+    char *b = (char *)g.ws[0].dbg.p;
     DebugOut &dbg = sm.dbg;
     dbg.n_ranked = (int *)b; b += 16;
     dbg.lag = (int *)b; b += 4 * K; dbg.nb = (int *)b; b += 4 * K; dbg.mi = (int *)b; b += 4 * K; dbg.mj = (int *)b; b += 4 * K;
@@ -857,12 +1014,11 @@ int rafft_expand_node(const rafft_params *p, const char *seq, const char *db, co
     std::vector<SeqIn> one{{seq, L, 0}};
     HostOut ho;
     ho.seq.resize(1); ho.step_size.resize(1); ho.step_off.resize(1); ho.dcal_ptr.assign(1, nullptr); ho.db_ptr.assign(1, nullptr);
-    unsigned ovf = 0;
     std::vector<Span> spans;
-    g.ev_used = 0;
+    g.ws[0].ev_used = 0;
     rafft_params pp = *p;
     pp.max_stack = std::max(1, pp.max_stack);
-    if (int rc = run_wave(pp, one, 4.0, ho, &ovf, spans, &sm)) return rc;
+    if (int rc = run_seam(pp, one, ho, spans, sm)) return rc;
     int hdr[4];
     HIPCHK(hipMemcpy(hdr, dbg.n_ranked, 16, hipMemcpyDeviceToHost));
     *n_ranked = hdr[0]; *n_kept = hdr[1];
