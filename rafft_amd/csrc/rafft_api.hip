@@ -336,7 +336,7 @@ struct Wave {
     Caps c;
     Dev d;
     Counters hc;
-    unsigned n_active = 0, ovf = 0;
+    unsigned n_active = 0, ovf = 0, last_mat = 0;
     int steps = 0;
     bool finished = false;
     int result = 0;               // valid when finished: 0, RAFFT_ERR_CAPACITY (regrow) or a hard error
@@ -483,7 +483,14 @@ int Wave::issue_step()
         if (!serial) HIPCHK(hipStreamWaitEvent(cs, g.ev_fork, 0));
         Span sp{next_event(), next_event(), 10 + cls};
         HIPCHK(hipEventRecord(sp.a, cs));
-        if (int rc = launch_expand_cls(d, cls, cf, (unsigned)cf[cls].grid, cs)) return rc;
+        // persistent workgroups loop over the work list, so any grid is correct: when few structures were
+        // materialized (the tail of a batch) a small grid avoids dispatching thousands of empty workgroups
+        unsigned grid = (unsigned)cf[cls].grid;
+        if (steps > 0) {
+            const unsigned long long bound = (unsigned long long)last_mat * (cls == 1 ? 8ULL : 4ULL) + 32ULL;
+            if (bound < grid) grid = (unsigned)bound;
+        }
+        if (int rc = launch_expand_cls(d, cls, cf, grid, cs)) return rc;
         HIPCHK(hipEventRecord(sp.b, cs));
         spans.push_back(sp);
         if (!serial) {
@@ -521,6 +528,7 @@ int Wave::after_beam()
     if (hc.overflow) { ovf = hc.overflow; return finish(); }
     if (hc.n_mat == 0) return finish();
     n_active = (unsigned)S - hc.n_done;
+    last_mat = hc.n_mat;
     {
         Span sp{next_event(), next_event(), 2};
         HIPCHK(hipEventRecord(sp.a, st));
