@@ -8,26 +8,33 @@ import argparse
 import sys
 
 
+# (flags, keyword arguments) - the option surface of the reference's CLI, bin/rafft:11-30.  `--pad`, `--min_bp`
+# and `--bp_only` are accepted and ignored exactly as there (they are parsed but never forwarded, bin/rafft:50-52).
+_OPTIONS = [
+    (("--sequence", "-s"), dict(help="sequence")),
+    (("--seq_file", "-sf"), dict(help="sequence file (FASTA or plain)")),
+    (("--n_mode", "-n"), dict(type=int, default=100, help="number of positional lags searched for stems")),
+    (("--max_stack", "-ms"), dict(type=int, default=1, help="number of structures kept per folding step")),
+    (("--min_nrj", "-mn"), dict(type=float, default=0, help="a stem must change the energy by less than this")),
+    (("--min_bp", "-mb"), dict(type=int, default=1, help="accepted, unused")),
+    (("--min_hp", "-mh"), dict(type=int, default=3, help="minimum unpaired positions in a hairpin")),
+    (("--pad", "-p"), dict(type=float, default=1.0, help="accepted, unused")),
+    (("--max_branch",), dict(type=int, default=1000, help="maximum number of new structures per folding step")),
+    (("--bp_only",), dict(action="store_true", help="accepted, unused")),
+    (("--bench",), dict(action="store_true", help="one line per structure: seq len structure energy #pairs")),
+    (("-tr", "--traj"), dict(action="store_true", help="print the whole fast-folding graph")),
+    (("--temp",), dict(type=float, default=37.0, help="temperature; only 37.0 is supported")),
+    (("-gc", "--gc_wei"), dict(type=float, default=3.0, help="GC weight")),
+    (("-au", "--au_wei"), dict(type=float, default=2.0, help="AU weight")),
+    (("-gu", "--gu_wei"), dict(type=float, default=1.0, help="GU weight")),
+    (("--batch",), dict(action="store_true", help="every FASTA record / line of -sf is its own sequence (one GPU batch)")),
+]
+
+
 def parse_arguments(argv=None):
     parser = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawTextHelpFormatter)
-    parser.add_argument('--sequence', '-s', help="sequence")
-    parser.add_argument('--seq_file', '-sf', help="sequence file")
-    parser.add_argument('--n_mode', '-n', help="Number of positional lags to search for stems", type=int, default=100)
-    parser.add_argument('--max_stack', '-ms', help="number of stored structures (default=1)", type=int, default=1)
-    parser.add_argument('--min_nrj', '-mn', help="minimum loop energy to be formed", type=float, default=0)
-    parser.add_argument('--min_bp', '-mb', help="minimum bp number to be detectable (parsed, unused - as in the reference)", type=int, default=1)
-    parser.add_argument('--min_hp', '-mh', help="minimum unpaired positions in hairpins", type=int, default=3)
-    parser.add_argument('--pad', '-p', help="padding (parsed, unused - as in the reference)", type=float, default=1.0)
-    parser.add_argument('--max_branch', help="maximum branches to explor", type=int, default=1000)
-    parser.add_argument('--bp_only', action="store_true", help="(parsed, unused - as in the reference)")
-    parser.add_argument('--bench', action="store_true", help="output for benchmarks")
-    parser.add_argument('-tr', '--traj', action="store_true", help="output full trajectories")
-    parser.add_argument('--temp', type=float, help="temperature (only 37.0)", default=37.0)
-    parser.add_argument('-gc', '--gc_wei', type=float, help="GC weight", default=3.00)
-    parser.add_argument('-au', '--au_wei', type=float, help="AU weight", default=2.00)
-    parser.add_argument('-gu', '--gu_wei', type=float, help="GU weight", default=1.00)
-    parser.add_argument('--batch', action="store_true",
-                        help="treat every FASTA record / line of -sf as its own sequence (one GPU batch)")
+    for flags, kw in _OPTIONS:
+        parser.add_argument(*flags, **kw)
     return parser.parse_args(argv)
 
 

@@ -46,37 +46,45 @@ def get_transition_mat(fast_paths, nb_struct, struct_map):
     return transition_mat
 
 
+def unique_structures(fast_paths):
+    """Structures of the graph in order of first appearance (rafft_kin.py:106-112)."""
+    index, ordered = {}, []
+    for step in fast_paths:
+        for st in step:
+            if st.str_struct not in index:
+                index[st.str_struct] = len(ordered)
+                ordered.append(st)
+    return ordered, index
+
+
 def kinetics(fast_paths, max_time, n_steps, initial_pop=None):
-    """rafft_kin.py:94-150: returns (trajectory, times, struct_list, str_equi_pop)."""
-    seen = set()
-    struct_list = []
-    for el in fast_paths:
-        for struct in el:
-            if struct.str_struct not in seen:
-                seen.add(struct.str_struct)
-                struct_list += [struct]
-    struct_map = {struct.str_struct: (si, struct.energy) for si, struct in enumerate(struct_list)}
+    """Master-equation populations on the fast-folding graph; same contract as the reference's
+    `kinetics` (rafft_kin.py:94-150): returns (trajectory, times, struct_list, str_equi_pop) with
+    trajectory[0] the initial population and n_steps rows at times exp(k * max_time / n_steps - 4)."""
+    struct_list, index = unique_structures(fast_paths)
+    struct_map = {st.str_struct: (index[st.str_struct], st.energy) for st in struct_list}
     nb_struct = len(struct_list)
-    transition_mat = get_transition_mat(fast_paths, nb_struct, struct_map)
+    rate = get_transition_mat(fast_paths, nb_struct, struct_map)
+
+    p0 = zeros(nb_struct, dtype=np.longdouble)
     if initial_pop is None:
-        init_pop = array([1.0] + [0.0 for _ in range(nb_struct - 1)], dtype=np.longdouble)
+        p0[0] = 1.0                                  # everything starts unfolded
     else:
-        init_pop = array([0.0 for _ in range(nb_struct)], dtype=np.longdouble)
-        for p, w in initial_pop:
-            init_pop[p] = w
-    trajectory = [deepcopy(init_pop)]
-    V, W = eig(transition_mat.T, check_finite=True)
-    iW = inv(W)
-    time_step = max_time / n_steps
-    times = [exp(-4)]
-    for st in range(n_steps):
-        time = exp(time_step * st - 4)
-        times += [time]
-        tmp_pop = W @ diag(exp(V * time)) @ (iW @ init_pop)
-        trajectory += [tmp_pop.real / tmp_pop.real.sum()]
-    equi_pop = trajectory[-1]
-    str_equi_pop = [(struct.str_struct, struct.energy, ep, struct_map[struct.str_struct][0])
-                    for struct, ep in zip(struct_list, equi_pop.real)]
+        for where, weight in initial_pop:
+            p0[where] = weight
+
+    # p(t) = W exp(diag(V) t) W^-1 p0   with (V, W) the eigen-decomposition of the transposed rate matrix
+    V, W = eig(rate.T, check_finite=True)
+    coef = inv(W) @ p0
+    ks = np.arange(n_steps)
+    sample_times = np.exp(ks * (max_time / n_steps) - 4)
+    times = [exp(-4)] + [t for t in sample_times]
+    trajectory = [deepcopy(p0)]
+    for t in sample_times:
+        pop = (W @ (np.exp(V * t) * coef)).real
+        trajectory.append(pop / pop.sum())
+    final = trajectory[-1]
+    str_equi_pop = [(st.str_struct, st.energy, final[k].real, k) for k, st in enumerate(struct_list)]
     return trajectory, times, struct_list, str_equi_pop
 
 
