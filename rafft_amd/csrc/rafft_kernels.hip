@@ -142,6 +142,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
     uint16_t *wmj = (uint16_t *)(lds + lay.off_mj);
     int *dd = (int *)(lds + lay.off_dd);
     uint16_t *keep = (uint16_t *)(lds + lay.off_keep);
+    unsigned long long *ck = (unsigned long long *)(lds + lay.off_ck);
     double *wtab = (double *)(lds + lay.off_w);
     int *misc = (int *)(lds + lay.off_misc);
 
@@ -285,8 +286,10 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                 keyv[k] = v;
             }
             __syncthreads();
-            for (int k = tid; k < P; k += NT) lagk[k] = (uint16_t)k;
-            __syncthreads();
+            if (m > Kp || d.dbg.lag != nullptr) {           // lag column of the sort; unused when nothing is ranked
+                for (int k = tid; k < P; k += NT) lagk[k] = (uint16_t)k;
+                __syncthreads();
+            }
         } else {
             // keyv[k] aliases z1[k] byte for byte and is written by the thread that read it;
             // lagk aliases the head of z2, so it is filled only after every read of z2.
@@ -304,8 +307,10 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                 keyv[k] = v;
             }
             __syncthreads();
-            for (int k = tid; k < P; k += NT) lagk[k] = (uint16_t)k;
-            __syncthreads();
+            if (m > Kp || d.dbg.lag != nullptr) {           // lag column of the sort; unused when nothing is ranked
+                for (int k = tid; k < P; k += NT) lagk[k] = (uint16_t)k;
+                __syncthreads();
+            }
         }
         // When every lag is searched anyway (2n-1 <= nb_mode) the ranking only breaks dE ties
         // later on, so the sort is skipped and ties are resolved from (value, lag) directly.
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
             }
         for (int r = tid; r < Kp; r += NT) {
             rk[r] = sorted ? lagk[r] : (uint16_t)r;
-            if (d.dbg.lag) { d.dbg.lag[r] = lagk[r]; d.dbg.corval[r] = keyv[r]; }
+            if (d.dbg.lag) { d.dbg.lag[r] = lagk[r]; d.dbg.corval[r] = keyv[r]; }   // (debug seam always sorts)
         }
         if (tid == 0 && d.dbg.n_ranked) *d.dbg.n_ranked = Kp;
         __syncthreads();
@@ -442,15 +447,13 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
             __syncthreads();
             // reversed strings: bit j of R = bit (n-1-j) of F
             if (tid < 20) {
+                // Reverse the whole 256-bit string (word order and bit order), then shift the n live bits
+                // down: R bit j = T bit (j + 256 - n) with T[w] = brev(F[3 - w]); bits of F past n are zero.
                 const int which = tid >> 2, w = tid & 3;
-                unsigned long long out = 0;
-                // word w of R holds bits j = 64w..64w+63  <-  F bits n-1-j
-                // built bit by bit from F (20 lanes, 64 bits each; once per region)
-                for (int bi = 0; bi < 64; bi++) {
-                    const int j = 64 * w + bi, src = n - 1 - j;
-                    if (src >= 0 && src < n && ((F[which * 4 + (src >> 6)] >> (src & 63)) & 1ULL)) out |= 1ULL << bi;
-                }
-                R[which * 4 + w] = out;
+                const int s0 = 64 * w + 256 - n, q = s0 >> 6, bsh = s0 & 63;
+                const unsigned long long lo = q < 4 ? __brevll(F[which * 4 + 3 - q]) : 0ULL;
+                const unsigned long long hi = q + 1 < 4 ? __brevll(F[which * 4 + 2 - q]) : 0ULL;
+                R[which * 4 + w] = bsh ? (lo >> bsh) | (hi << (64 - bsh)) : lo;
             }
             __syncthreads();
             // 64 bits of string X (W words) starting at bit `start` (may be negative / past the end -> zeros)
@@ -649,19 +652,30 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         const unsigned long long cbase = *(unsigned long long *)&misc[4];
         const bool ovf = misc[2] != 0;
         if (!ovf) {
+            // packed sort key of every kept candidate: (dE biased to unsigned) << 32 | lag rank
             for (int x = tid; x < nkept; x += NT) {
                 const int r = keep[x];
+                ck[x] = ((unsigned long long)((unsigned)dd[r] ^ 0x80000000u) << 32) | (unsigned)r;
+            }
+            __syncthreads();
+            for (int x = tid; x < nkept; x += NT) {
+                const unsigned long long kx = ck[x];
+                const int r = (int)(kx & 0xFFFFFFFFu);
                 const int my = dd[r];
-                const double myv = keyv[r];
                 int rank = 0;
-                for (int y = 0; y < nkept; y++) {
-                    const int q = keep[y];
-                    const int oq = dd[q];
-                    bool before;
-                    if (oq != my) before = oq < my;
-                    else if (sorted) before = q < r;
-                    else { const double qv = keyv[q]; before = (qv > myv) || (qv == myv && q > r); }
-                    rank += (q != r && before) ? 1 : 0;
+                if (sorted) {
+                    for (int y = 0; y < nkept; y++) rank += ck[y] < kx ? 1 : 0;
+                } else {
+                    const double myv = keyv[r];
+                    for (int y = 0; y < nkept; y++) {
+                        const unsigned long long ky = ck[y];
+                        if ((ky >> 32) == (kx >> 32)) {          // dE tie: (value desc, lag desc)
+                            const int q = (int)(ky & 0xFFFFFFFFu);
+                            const double qv = keyv[q];
+                            rank += (q != r && ((qv > myv) || (qv == myv && q > r))) ? 1 : 0;
+                        } else
+                            rank += ky < kx ? 1 : 0;
+                    }
                 }
                 int mi = wmi[r], mj = wmj[r], nb = wnb[r];
                 uint64_t h1 = 0, h2 = 0;

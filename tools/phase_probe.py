@@ -19,5 +19,5 @@ for rep in (0, 1, 2, 4, 8, 16, 32):
     st = json.loads(out)
     if rep == 0:
         base = st
-    print(f"{names[rep]:16s} small {st['ms_expand']:7.2f} (+{st['ms_expand'] - base['ms_expand']:6.2f})  medium {st['ms_expand_c2']:7.2f} (+{st['ms_expand_c2'] - base['ms_expand_c2']:6.2f})"
+    print(f"{names[rep]:16s} tiny {st['ms_expand_c1']:7.2f} (+{st['ms_expand_c1'] - base['ms_expand_c1']:6.2f})  small {st['ms_expand']:7.2f} (+{st['ms_expand'] - base['ms_expand']:6.2f})  medium {st['ms_expand_c2']:7.2f} (+{st['ms_expand_c2'] - base['ms_expand_c2']:6.2f})"
           f"  large {st['ms_expand_c3']:7.2f} (+{st['ms_expand_c3'] - base['ms_expand_c3']:6.2f})  total {st['ms_total']:7.2f}", flush=True)
