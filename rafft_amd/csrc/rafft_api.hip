@@ -376,7 +376,7 @@ int Wave::setup()
     for (size_t i = 0; i < S; i++) maxL = std::max(maxL, len[i]);
     if (int rc = class_cfg(p.nb_mode, maxL, cf)) return rc;
     c = plan_caps(S, sumL, p, est);
-    if ((size_t)c.sort_cap * 8 + MAX_PROD * 16 + (size_t)(p.max_stack + 4) * 36 + 512 > 150 * 1024)
+    if ((size_t)c.sort_cap * 8 + MAX_PROD * 28 + (size_t)(p.max_stack + 4) * (sizeof(ParentInfo) + 4) + BS_CACHE * 20 + 1024 > 150 * 1024)
         return fail(RAFFT_ERR_PARAM, "max_branch + 2*max_stack too large for the LDS-resident beam sort");
     B = (size_t)p.max_stack;
 
@@ -444,6 +444,11 @@ int Wave::setup()
         int best = 0;
         for (size_t i = 0; i < S; i++) if (len[i] > len[best]) best = (int)i;
         d.prof_seq = best;
+        if (const char *ps = getenv("RAFFT_PROF_SEQ")) d.prof_seq = atoi(ps);
+        static unsigned long long *ws_buf = nullptr; static size_t ws_cap = 0;
+        if (ws_cap < S) { if (ws_buf) HIPCHK(hipFree(ws_buf)); HIPCHK(hipMalloc((void **)&ws_buf, S * 24)); ws_cap = S; }
+        HIPCHK(hipMemset(ws_buf, 0, S * 24));
+        d.prof_ws = ws_buf;
     }
 
 
@@ -459,7 +464,8 @@ int Wave::setup()
     hipLaunchKernelGGL(init_roots_kernel, dim3((unsigned)S), dim3(64), 0, st, d);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));      // `codes` (host vector) must outlive the copy
-    bs_lds = (size_t)c.sort_cap * 8 + MAX_PROD * 12 + B * sizeof(ParentInfo) + ((B + 3) & ~(size_t)3) * 4 + 128 + MAX_PROD * 4 + 16 * 8;
+    bs_lds = (size_t)c.sort_cap * 8 + MAX_PROD * 12 + B * sizeof(ParentInfo) + ((B + 3) & ~(size_t)3) * 4 + 128 + MAX_PROD * 4 + 16 * 8 * 4 +
+             BS_CACHE * 20 + MAX_PROD * 12;
     n_active = (unsigned)S;
     ms_setup = since(tw0);
     tw1 = std::chrono::steady_clock::now();
@@ -650,6 +656,20 @@ int Wave::finish()
         rafft_seq_result &sr = out.seq[gi];
         sr.status = RAFFT_OK; sr.length = len[i]; sr.n_steps = (int)v.size(); sr.n_structs = nst;
         row += nst;
+    }
+    if (d.prof_ws) {
+        std::vector<unsigned long long> wsv(S * 3);
+        HIPCHK(hipMemcpy(wsv.data(), d.prof_ws, S * 24, hipMemcpyDeviceToHost));
+        std::vector<int> ord(S);
+        for (size_t i = 0; i < S; i++) ord[i] = (int)i;
+        std::sort(ord.begin(), ord.end(), [&](int a, int b) { return wsv[3 * a] > wsv[3 * b]; });
+        unsigned long long tot = 0, totc = 0;
+        for (size_t i = 0; i < S; i++) { tot += wsv[3 * i]; totc += wsv[3 * i + 1]; }
+        fprintf(stderr, "[rafft] beam_step per sequence: total cycles %llu, total chunks %llu over %zu sequences\n", tot, totc, S);
+        for (size_t k = 0; k < std::min<size_t>(S, 12); k++) {
+            int i = ord[k];
+            fprintf(stderr, "[rafft]   #%zu local seq %d (L=%d): cycles %llu, chunks %llu, slowest step %llu\n", k, i, len[i], wsv[3 * i], wsv[3 * i + 1], wsv[3 * i + 2]);
+        }
     }
     if (d.prof) {
         unsigned long long pv[16];
@@ -863,6 +883,20 @@ int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs, 
         for (int i = 0; i < MAX_PIPES; i++) if (g.ws[i].ready) { hipError_t e_ = hipStreamSynchronize(g.ws[i].stream); (void)e_; }
         free_out(ho);
         return rc;
+    }
+    if (getenv("RAFFT_TRACE")) {       // per-step timeline: spans are recorded in step order
+        float acc[16] = {0};
+        int stepno = 0;
+        for (auto &sp : spans) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, sp.a, sp.b) != hipSuccess) continue;
+            if (sp.kind < 16) acc[sp.kind] += ms;
+            if (sp.kind == 1) {        // the beam step closes a folding step (materialize of it follows)
+                fprintf(stderr, "[rafft] t-step %2d: expand wall %.3f (c1 %.3f c2 %.3f c3 %.3f) beam %.3f  prev-materialize %.3f\n",
+                        ++stepno, acc[4], acc[11], acc[12], acc[13], acc[1], acc[2]);
+                for (float &x : acc) x = 0;
+            }
+        }
     }
     for (auto &sp : spans) {
         float ms = 0;

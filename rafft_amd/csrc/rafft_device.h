@@ -35,11 +35,17 @@ struct EnergyTables {
     BigT b;
 };
 
-__device__ __constant__ static const int8_t kPairType[5][5] = {
-    {0, 0, 0, 0, 0}, {0, 0, 0, 0, 5}, {0, 0, 0, 1, 0}, {0, 0, 2, 0, 3}, {0, 6, 0, 4, 0}};
-__device__ __constant__ static const int8_t kRtype[7] = {0, 2, 1, 4, 3, 6, 5};
-
-__device__ __forceinline__ int pair_type(int a, int b) { return kPairType[a][b]; }
+// Pair type of two base codes (ViennaRNA numbering: CG=1 GC=2 GU=3 UG=4 AU=5 UA=6, 0 = no pair) and the
+// type of the reversed pair, as register arithmetic on packed 3-bit tables: a per-lane table load from
+// memory here would sit on the dependency chain of every energy lookup.
+//   row a (1..4) occupies bits 15(a-1) .. 15(a-1)+14, entry b at 3b inside the row
+#define RAFFT_PT_BITS 0x1060c2001005000ULL
+#define RAFFT_RT_BITS 0x173850u
+__device__ __host__ __forceinline__ int pair_type(int a, int b)
+{
+    return a ? (int)((RAFFT_PT_BITS >> (15 * (a - 1) + 3 * b)) & 7ULL) : 0;
+}
+__device__ __host__ __forceinline__ int rtype(int t) { return (int)((RAFFT_RT_BITS >> (3 * t)) & 7u); }
 
 // special-loop key: 3 bits per base, first base in the low bits
 __device__ __forceinline__ uint32_t loop_key(const uint8_t *S, int i, int m)
@@ -156,7 +162,7 @@ __device__ inline int loop_energy(const SmallT *T, const BigT *B, const uint8_t 
     if (nbr == 1) {
         int t2 = pair_type(S[p1], S[q1]);
         if (!t2) { *bad = 1; return 0; }
-        return e_intloop(T, B, p1 - ci - 1, cj - q1 - 1, type, kRtype[t2], S[ci + 1], S[cj - 1], S[p1 - 1], S[q1 + 1]);
+        return e_intloop(T, B, p1 - ci - 1, cj - q1 - 1, type, rtype(t2), S[ci + 1], S[cj - 1], S[p1 - 1], S[q1 + 1]);
     }
     int e = 0, u = cj - ci - 1;
     for (int p = ci + 1; p < cj;) {
@@ -168,7 +174,7 @@ __device__ inline int loop_energy(const SmallT *T, const BigT *B, const uint8_t 
         u -= q - p + 1;
         p = q + 1;
     }
-    e += e_stem(T, kRtype[type], S[cj - 1], S[ci + 1], false);
+    e += e_stem(T, rtype(type), S[cj - 1], S[ci + 1], false);
     e += T->ml_closing + u * T->ml_base;
     return e;
 }
@@ -228,7 +234,7 @@ __device__ inline int loop_energy_br(const SmallT *T, const BigT *B, const uint8
     if (k == 1) {
         int p, q;
         bl.get(0, p, q);
-        return e_intloop(T, B, p - ci - 1, cj - q - 1, type, kRtype[pair_type(S[p], S[q])], S[ci + 1], S[cj - 1], S[p - 1], S[q + 1]);
+        return e_intloop(T, B, p - ci - 1, cj - q - 1, type, rtype(pair_type(S[p], S[q])), S[ci + 1], S[cj - 1], S[p - 1], S[q + 1]);
     }
     int e = 0, u = cj - ci - 1;
     for (int i = 0; i < k; i++) {
@@ -237,7 +243,7 @@ __device__ inline int loop_energy_br(const SmallT *T, const BigT *B, const uint8
         e += e_stem(T, pair_type(S[p], S[q]), S[p - 1], S[q + 1], false);
         u -= q - p + 1;
     }
-    e += e_stem(T, kRtype[type], S[cj - 1], S[ci + 1], false);
+    e += e_stem(T, rtype(type), S[cj - 1], S[ci + 1], false);
     return e + T->ml_closing + u * T->ml_base;
 }
 

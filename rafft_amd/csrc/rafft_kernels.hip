@@ -148,7 +148,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
 
     if (tid < 25) {
         int a = tid / 5, b = tid % 5;
-        int tp = kPairType[a][b];
+        int tp = pair_type(a, b);
         wtab[tid] = (tp == 5 || tp == 6) ? d.au : (tp == 1 || tp == 2) ? d.gc : (tp == 3 || tp == 4) ? d.gu : 0.0;
     }
     const unsigned n_items = d.c->n_work[cls];
@@ -437,6 +437,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
             unsigned long long *F = (unsigned long long *)(lds + lay.offA + (sorted ? 0 : ((10 * P + 15) & ~15)));
             unsigned long long *R = F + 5 * 4;
             const int W = (n + 63) >> 6;
+            for (int rep_ = 0; rep_ < 1 + ((d.rep >> 7) & 1); rep_++) {
             for (int wq = 0; wq < 4; wq++) {
                 const int t = wq * 64 + tid;
                 const int c0 = t < n ? code[t] : 0;
@@ -456,6 +457,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                 R[which * 4 + w] = bsh ? (lo >> bsh) | (hi << (64 - bsh)) : lo;
             }
             __syncthreads();
+            }
             // 64 bits of string X (W words) starting at bit `start` (may be negative / past the end -> zeros)
             auto window = [&](const unsigned long long *X, int start) -> unsigned long long {
                 if (start >= 64 * W || start <= -64) return 0ULL;
@@ -586,7 +588,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                     for (int t = 1; t < nb; t++) {
                         const int a = pos[mi - t], b = pos[mj + t];
                         if (pa == a + 1 && pb == b - 1)
-                            e_new += T->stack[pair_type(Sl[a], Sl[b])][kRtype[pair_type(Sl[pa], Sl[pb])]];
+                            e_new += T->stack[pair_type(Sl[a], Sl[b])][rtype(pair_type(Sl[pa], Sl[pb]))];
                         else {
                             const int lo2 = br_lower(brl, nbr, a), hi2 = br_lower(brl, nbr, b);
                             BrList mid{brl, lo2, lo, hi, hi2, 1, pa, pb};
@@ -651,7 +653,8 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         __syncthreads();
         const unsigned long long cbase = *(unsigned long long *)&misc[4];
         const bool ovf = misc[2] != 0;
-        if (!ovf) {
+        if (!ovf)
+        for (int rep_ = 0; rep_ < 1 + ((d.rep >> 6) & 1); rep_++) {
             // packed sort key of every kept candidate: (dE biased to unsigned) << 32 | lag rank
             for (int x = tid; x < nkept; x += NT) {
                 const int r = keep[x];
@@ -720,6 +723,18 @@ __device__ inline bool seen_lookup(const uint64_t *tab, uint32_t cap, uint64_t h
         sl = (sl + 1) & mask;
     }
 }
+// insert unless present; true if it was new.  Keys inserted concurrently by other threads are always
+// different structures (distinct combos of one parent), so a half-written entry can only be someone else's.
+__device__ inline bool seen_insert_new(uint64_t *tab, uint32_t cap, uint64_t h1, uint64_t h2)
+{
+    uint32_t mask = cap - 1, sl = (uint32_t)h1 & mask;
+    for (;;) {
+        unsigned long long old = atomicCAS((unsigned long long *)&tab[2 * (uint64_t)sl], 0ULL, (unsigned long long)h1);
+        if (old == 0) { tab[2 * (uint64_t)sl + 1] = h2; return true; }
+        if (old == h1 && tab[2 * (uint64_t)sl + 1] == h2) return false;
+        sl = (sl + 1) & mask;
+    }
+}
 __device__ inline void seen_insert(uint64_t *tab, uint32_t cap, uint64_t h1, uint64_t h2)
 {
     uint32_t mask = cap - 1, sl = (uint32_t)h1 & mask;
@@ -733,9 +748,12 @@ __device__ inline void seen_insert(uint64_t *tab, uint32_t cap, uint64_t h1, uin
 
 
 struct ParentInfo {         // filled by the parallel prepass, one entry per beam member
-    unsigned long long total, h1, h2;
-    int dcal0, flag;        // flag: 0 live, 1 nothing to produce
+    unsigned long long total, h1, h2;     // product size; pair-set hash of combo 0
+    unsigned long long cur, prod, ph1, ph2;   // cursor, productive-region list, the parent's own hash
+    int dcal0, flag;        // energy of combo 0; flag: 0 live, 1 nothing to produce, 2 cursor already moved
+    int nprod, pdcal;       // productive regions, the parent's own energy
 };
+#define BS_CACHE 256        // candidates of one parent kept in LDS during its product walk
 
 __device__ __forceinline__ unsigned long long sat_mul(unsigned long long a, unsigned long long b)
 {
@@ -757,6 +775,12 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
     int *sh = oldbeam + ((d.B + 3) & ~3);                                       // scratch [32]
     int *digit = sh + 32;                                                       // [MAX_PROD] odometer digits
     unsigned long long *bsum = (unsigned long long *)(digit + MAX_PROD);        // [16] partial sums
+    unsigned long long *cc_h1 = bsum + 16 * 4;                                  // [BS_CACHE] cached candidates of the
+    unsigned long long *cc_h2 = cc_h1 + BS_CACHE;                               //   parent being walked
+    int *cc_dd = (int *)(cc_h2 + BS_CACHE);                                     // [BS_CACHE]
+    int *cc_off = cc_dd + BS_CACHE;                                             // [MAX_PROD] first cache slot of region k
+    int *dnew = cc_off + MAX_PROD;                                              // [MAX_PROD] digits of the next base combo
+    float *prod_rc = (float *)(dnew + MAX_PROD);                                // [MAX_PROD] 1 / prod_cnt
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int sq = blockIdx.x;
     // snapshot of the region allocators: whatever materialize adds after this kernel is "new"
@@ -764,6 +788,10 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
     if (d.done[sq]) return;
     const bool prof = d.prof && sq == d.prof_seq && tid == 0;   // diagnostic stamps (RAFFT_TRACE=3)
     unsigned long long tprev = prof ? clock64() : 0;
+    const unsigned long long t_begin = d.prof_ws ? clock64() : 0;
+    unsigned long long n_chunks = 0;
+#define WS_END() do { if (d.prof_ws && tid == 0) { unsigned long long dt_ = clock64() - t_begin; d.prof_ws[3 * sq] += dt_; d.prof_ws[3 * sq + 1] += n_chunks; \
+        if (dt_ > d.prof_ws[3 * sq + 2]) d.prof_ws[3 * sq + 2] = dt_; } } while (0)
 #define STAMP(k) do { if (prof) { unsigned long long tn_ = clock64(); d.prof[k] += tn_ - tprev; tprev = tn_; } } while (0)
     const int nbeam = d.beam_n[sq];
     int *beam = d.beam + (size_t)sq * d.B;
@@ -785,65 +813,83 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
     }
     if (tid == 0) d.nsteps[sq] += 1;
 
-    // ---- prepass, one wavefront per beam member: product size and combo 0 of every parent
-    for (int b = wv; b < nbeam; b += BS_NT / 64) {
-        const int sid = oldbeam[b];
-        const unsigned long long cur0 = d.st_cursor[sid], tot0 = d.st_total[sid];
-        if (tot0 && cur0 >= tot0) { if (lane == 0) pinfo[b].flag = 1; continue; }
-        const int curbit = cur0 > 0 ? 2 : 0;
-        if (tot0 && cur0 > 0) {      // expanded in an earlier step: only the cursor/total matter now
-            if (lane == 0) { ParentInfo pi; pi.flag = curbit; pi.total = tot0; pi.h1 = pi.h2 = 0; pi.dcal0 = 0; pinfo[b] = pi; }
-            continue;
-        }
-        const int node0 = d.st_node0[sid], nn = d.st_nnodes[sid];
-        unsigned long long tot = 1, h1 = 0, h2 = 0;
-        int dc = 0, np = 0;
-        // first visit of this structure: its productive regions (node order, rafft/rafft.py:166-171) are
-        // written once as a compact list that the product walk and materialize_kernel read back
-        unsigned long long pbase = 0;
-        if (lane == 0) {
-            const int shd = sq & (NSHARD - 1);
-            pbase = atomicAdd(&d.c->prod[shd].v, (unsigned long long)nn);
-            if (pbase + nn > d.prod_shard_cap) { atomicOr(&d.c->overflow, OVF_PRODLIST); pbase = ~0ULL; }
-            else pbase += (unsigned long long)shd * d.prod_shard_cap;
-        }
-        pbase = __shfl(pbase, 0, 64);
-        int wpos = 0;
-        for (int base = 0; base < nn; base += 64) {
-            int i = base + lane, cnt = 0, cn = 0;
-            unsigned long long coff = 0;
-            if (i < nn) {
-                cn = d.nd_canon[node0 + i];
-                cnt = d.nd_ncand[cn];
-                if (cnt > 0) {
-                    coff = d.nd_cand[cn];
-                    const Cand *cp = &d.cand[coff];
-                    tot = sat_mul(tot, (unsigned long long)cnt);
-                    dc += cp->ddcal; h1 += cp->h1; h2 += cp->h2; np++;
+    // ---- prepass: product size and combo 0 of every parent.  A group of G lanes per beam member (G = 16 for
+    // short sequences, whose structures have few regions; a whole wavefront otherwise): every member costs a
+    // chain of dependent loads (structure -> regions -> canonical region -> candidate), so the more members
+    // are in flight at once the fewer round trips the prepass takes.
+    {
+        const int G = d.seq_len[sq] <= 800 ? 16 : 64;
+        const int gpw = 64 / G, gl = lane & (G - 1), grp = lane / G;
+        const int nslots = (BS_NT / 64) * gpw;
+        const unsigned long long gmask = G == 64 ? ~0ULL : ((1ULL << G) - 1ULL);
+        for (int b0 = 0; b0 < nbeam; b0 += nslots) {
+            const int b = b0 + wv * gpw + grp;
+            if (b >= nbeam) continue;
+            const int sid = oldbeam[b];
+            const unsigned long long cur0 = d.st_cursor[sid], tot0 = d.st_total[sid];
+            if (tot0 && cur0 >= tot0) { if (gl == 0) pinfo[b].flag = 1; continue; }
+            const int curbit = cur0 > 0 ? 2 : 0;
+            const int sdcal = d.st_dcal[sid];
+            const unsigned long long sh1 = d.st_h[2 * (size_t)sid], sh2 = d.st_h[2 * (size_t)sid + 1];
+            if (tot0 && cur0 > 0) {      // expanded in an earlier step: only the cursor/total matter now
+                if (gl == 0) {
+                    ParentInfo pi; pi.flag = curbit; pi.total = tot0; pi.h1 = pi.h2 = 0; pi.dcal0 = 0;
+                    pi.cur = cur0; pi.prod = d.st_prod[sid]; pi.nprod = d.st_nprod[sid]; pi.pdcal = sdcal; pi.ph1 = sh1; pi.ph2 = sh2;
+                    pinfo[b] = pi;
                 }
+                continue;
             }
-            const unsigned long long bal = __ballot(cnt > 0);
-            if (cnt > 0 && pbase != ~0ULL) {
-                ProdEnt pe; pe.cnt = (uint32_t)cnt; pe.node = cn; pe.off = coff;
-                d.prod[pbase + wpos + __popcll(bal & ((1ULL << lane) - 1))] = pe;
+            const int node0 = d.st_node0[sid], nn = d.st_nnodes[sid];
+            unsigned long long tot = 1, h1 = 0, h2 = 0;
+            int dc = 0, np = 0;
+            // first visit of this structure: its productive regions (node order, rafft/rafft.py:166-171) are
+            // written once as a compact list that the product walk and materialize_kernel read back
+            unsigned long long pbase = 0;
+            if (gl == 0) {
+                const int shd = sq & (NSHARD - 1);
+                pbase = atomicAdd(&d.c->prod[shd].v, (unsigned long long)nn);
+                if (pbase + nn > d.prod_shard_cap) { atomicOr(&d.c->overflow, OVF_PRODLIST); pbase = ~0ULL; }
+                else pbase += (unsigned long long)shd * d.prod_shard_cap;
             }
-            wpos += __popcll(bal);
-        }
-        if (lane == 0) { d.st_prod[sid] = pbase == ~0ULL ? 0 : pbase; d.st_nprod[sid] = pbase == ~0ULL ? 0 : wpos; }
-        if (lane == 0 && wpos > 64) atomicMax(&d.c->max_nprod, (unsigned int)wpos);
-        for (int o = 32; o > 0; o >>= 1) {
-            tot = sat_mul(tot, __shfl_xor(tot, o, 64));
-            h1 += __shfl_xor(h1, o, 64); h2 += __shfl_xor(h2, o, 64);
-            dc += __shfl_xor(dc, o, 64); np += __shfl_xor(np, o, 64);
-        }
-        if (lane == 0) {
-            ParentInfo pi;
-            pi.flag = (np == 0 ? 1 : 0) | curbit;
-            pi.total = tot;
-            pi.h1 = d.st_h[2 * (size_t)sid] + h1; pi.h2 = d.st_h[2 * (size_t)sid + 1] + h2;
-            pi.dcal0 = d.st_dcal[sid] + dc;
-            pinfo[b] = pi;
-            if (np == 0) { d.st_total[sid] = 1; d.st_cursor[sid] = 1; }
+            pbase = __shfl(pbase, grp * G, 64);
+            int wpos = 0;
+            for (int base = 0; base < nn; base += G) {
+                int i = base + gl, cnt = 0, cn = 0;
+                unsigned long long coff = 0;
+                if (i < nn) {
+                    cn = d.nd_canon[node0 + i];
+                    cnt = d.nd_ncand[cn];
+                    if (cnt > 0) {
+                        coff = d.nd_cand[cn];
+                        const Cand *cp = &d.cand[coff];
+                        tot = sat_mul(tot, (unsigned long long)cnt);
+                        dc += cp->ddcal; h1 += cp->h1; h2 += cp->h2; np++;
+                    }
+                }
+                const unsigned long long bal = (__ballot(cnt > 0) >> (grp * G)) & gmask;   // this group's lanes
+                if (cnt > 0 && pbase != ~0ULL) {
+                    ProdEnt pe; pe.cnt = (uint32_t)cnt; pe.node = cn; pe.off = coff;
+                    d.prod[pbase + wpos + __popcll(bal & ((1ULL << gl) - 1))] = pe;
+                }
+                wpos += __popcll(bal);
+            }
+            if (gl == 0) { d.st_prod[sid] = pbase == ~0ULL ? 0 : pbase; d.st_nprod[sid] = pbase == ~0ULL ? 0 : wpos; }
+            if (gl == 0 && wpos > 64) atomicMax(&d.c->max_nprod, (unsigned int)wpos);
+            for (int o = G >> 1; o > 0; o >>= 1) {
+                tot = sat_mul(tot, __shfl_xor(tot, o, 64));
+                h1 += __shfl_xor(h1, o, 64); h2 += __shfl_xor(h2, o, 64);
+                dc += __shfl_xor(dc, o, 64); np += __shfl_xor(np, o, 64);
+            }
+            if (gl == 0) {
+                ParentInfo pi;
+                pi.flag = (np == 0 ? 1 : 0) | curbit;
+                pi.total = tot;
+                pi.h1 = sh1 + h1; pi.h2 = sh2 + h2;
+                pi.dcal0 = sdcal + dc;
+                pi.cur = 0; pi.prod = pbase == ~0ULL ? 0 : pbase; pi.nprod = pbase == ~0ULL ? 0 : wpos; pi.pdcal = sdcal; pi.ph1 = sh1; pi.ph2 = sh2;
+                pinfo[b] = pi;
+                if (np == 0) { d.st_total[sid] = 1; d.st_cursor[sid] = 1; }
+            }
         }
     }
     __syncthreads();
@@ -861,23 +907,43 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
         if (nb_branch >= d.max_branch) { single_from = b; break; }
         if (pinfo[b].flag & 1) continue;
         const int sid = oldbeam[b];
-        unsigned long long cur = d.st_cursor[sid];
+        unsigned long long cur = pinfo[b].cur;
         const unsigned long long total = pinfo[b].total;
         // productive regions of this parent (compact list written at its first visit)
-        int mprod = d.st_nprod[sid];
+        int mprod = pinfo[b].nprod;
         if (mprod > MAX_PROD) { if (tid == 0) atomicOr(&d.c->overflow, OVF_PROD); mprod = MAX_PROD; }
+        bool cached;
         {
-            const ProdEnt *pl = d.prod + d.st_prod[sid];
-            for (int k = tid; k < mprod; k += BS_NT) { prod_cnt[k] = (int)pl[k].cnt; prod_off[k] = pl[k].off; }
+            const ProdEnt *pl = d.prod + pinfo[b].prod;
+            int mycnt = 0;
+            for (int k = tid; k < mprod; k += BS_NT) { mycnt = (int)pl[k].cnt; prod_cnt[k] = mycnt; prod_off[k] = pl[k].off; }
+            // the candidates of all productive regions go to LDS when they fit (they nearly always do):
+            // the walk below then touches global memory only for the `seen` set and the child records
+            int ctot, cex = block_exscan<BS_NT>(tid < mprod ? mycnt : 0, sh, &ctot);   // MAX_PROD <= BS_NT
+            if (tid < mprod) cc_off[tid] = cex;
+            cached = ctot <= BS_CACHE;
             __syncthreads();
+            if (cached) {
+                for (int e = tid; e < ctot; e += BS_NT) {
+                    int lo = 0, hi = mprod - 1;                   // region k with cc_off[k] <= e < cc_off[k] + cnt[k]
+                    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (cc_off[mid] <= e) lo = mid; else hi = mid - 1; }
+                    const Cand *cp = &d.cand[prod_off[lo] + (unsigned)(e - cc_off[lo])];
+                    cc_dd[e] = cp->ddcal; cc_h1[e] = cp->h1; cc_h2[e] = cp->h2;
+                }
+                __syncthreads();
+            }
         }
-        const int par_dcal = d.st_dcal[sid];
-        const uint64_t ph1 = d.st_h[2 * (size_t)sid], ph2 = d.st_h[2 * (size_t)sid + 1];
-        constexpr int R = 1;                   // combos per thread and chunk (R=4 measured slower: register pressure)
-        // digits of the first combo: zero for a fresh parent, one long division when resuming
+        const int par_dcal = pinfo[b].pdcal;
+        const uint64_t ph1 = pinfo[b].ph1, ph2 = pinfo[b].ph2;
+        // Digits in LDS describe combo (cur - shift): thread t decodes combo cur + t as "base + carry".  A
+        // fresh parent starts at its combo 0 (shift 0); afterwards the base is the LAST combo of the previous
+        // chunk (shift 1), whose digits and sums that chunk's last thread has computed anyway - nobody has to
+        // advance the odometer serially between chunks (itertools.product order, rafft/rafft.py:180).
+        int shift = cur == 0 ? 0 : 1;
+        for (int k = tid; k < mprod; k += BS_NT) prod_rc[k] = 1.0f / (float)prod_cnt[k];
         if (cur == 0) { for (int k = tid; k < mprod; k += BS_NT) digit[k] = 0; }
-        else if (tid == 0) {
-            unsigned long long idx = cur;
+        else if (tid == 0) {                   // resuming: one long division
+            unsigned long long idx = cur - 1;
             for (int k = mprod - 1; k >= 0; k--) {
                 unsigned long long c = (unsigned long long)prod_cnt[k], q = idx / c;
                 digit[k] = (int)(idx - q * c);
@@ -885,12 +951,31 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
             }
         }
         __syncthreads();
+        auto c_dd = [&](int k, int dg) -> int { return cached ? cc_dd[cc_off[k] + dg] : d.cand[prod_off[k] + (unsigned)dg].ddcal; };
+        auto c_h1 = [&](int k, int dg) -> uint64_t { return cached ? cc_h1[cc_off[k] + dg] : d.cand[prod_off[k] + (unsigned)dg].h1; };
+        auto c_h2 = [&](int k, int dg) -> uint64_t { return cached ? cc_h2[cc_off[k] + dg] : d.cand[prod_off[k] + (unsigned)dg].h2; };
+        {   // sums over the base digits, once per parent
+            unsigned long long a1 = 0, a2 = 0; long long ad = 0;
+            for (int k = tid; k < mprod; k += BS_NT) { const int dg = digit[k]; a1 += c_h1(k, dg); a2 += c_h2(k, dg); ad += c_dd(k, dg); }
+            for (int o = 32; o > 0; o >>= 1) {
+                a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); ad += __shfl_xor(ad, o, 64);
+            }
+            if (lane == 0) { bsum[4 + 3 * wv] = a1; bsum[5 + 3 * wv] = a2; bsum[6 + 3 * wv] = (unsigned long long)ad; }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned long long t1 = 0, t2 = 0, td = 0;
+                for (int w = 0; w < BS_NT / 64; w++) { t1 += bsum[4 + 3 * w]; t2 += bsum[5 + 3 * w]; td += bsum[6 + 3 * w]; }
+                bsum[0] = t1; bsum[1] = t2; bsum[2] = td;
+            }
+            __syncthreads();
+        }
+        bool hit_done = false;
         while (cur < total) {
             const unsigned long long left = total - cur;
-            const int chunk = left < (unsigned long long)(BS_NT * R) ? (int)left : BS_NT * R;
+            const int chunk = left < (unsigned long long)BS_NT ? (int)left : BS_NT;
             if ((unsigned long long)(scnt + chunk) * 2 > scap) {   // grow the seen set (rehash into a zeroed region)
                 uint32_t ncap = scap;
-                while ((unsigned long long)(scnt + BS_NT * R) * 2 > ncap) ncap <<= 1;
+                while ((unsigned long long)(scnt + BS_NT) * 2 > ncap) ncap <<= 1;
                 if (tid == 0) {
                     unsigned long long o = atomicAdd(&d.c->seen_top, (unsigned long long)ncap);
                     if (o + ncap > d.seen_cap_total) { atomicOr(&d.c->overflow, OVF_SEEN); *(unsigned long long *)&sh[8] = ~0ULL; }
@@ -911,111 +996,71 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
                 stab = ntab; scap = ncap;
                 if (tid == 0) { d.seen_off[sq] = o; d.seen_cap[sq] = ncap; }
             }
+            n_chunks++;
             STAMP(6);   // loop head / seen growth
-            // sums over the base digits by the whole block; thread t then adds its offsets with carry:
-            // only the last few digits differ from the base (itertools.product order, rafft.py:180)
-            {
-                unsigned long long a1 = 0, a2 = 0; long long ad = 0;
-                for (int k = tid; k < mprod; k += BS_NT) {
-                    const Cand *cp = &d.cand[prod_off[k] + digit[k]];
-                    a1 += cp->h1; a2 += cp->h2; ad += cp->ddcal;
-                }
-                for (int o = 32; o > 0; o >>= 1) {
-                    a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); ad += __shfl_xor(ad, o, 64);
-                }
-                if (lane == 0) { bsum[4 + 3 * wv] = a1; bsum[5 + 3 * wv] = a2; bsum[6 + 3 * wv] = (unsigned long long)ad; }
-                __syncthreads();
-                if (tid == 0) {
-                    unsigned long long t1 = 0, t2 = 0, td = 0;
-                    for (int w = 0; w < BS_NT / 64; w++) { t1 += bsum[4 + 3 * w]; t2 += bsum[5 + 3 * w]; td += bsum[6 + 3 * w]; }
-                    bsum[0] = t1; bsum[1] = t2; bsum[2] = td;
-                }
-                __syncthreads();
-            }
-            STAMP(7);   // base sums
-            int isnew[R], cdd[R];
-            uint64_t hh1[R], hh2[R];
-            int cnt_new = 0;
-#pragma unroll
-            for (int j = 0; j < R; j++) {
-                const int pos = tid * R + j;
-                isnew[j] = 0; cdd[j] = 0; hh1[j] = 0; hh2[j] = 0;
-                if (pos < chunk) {
-                    uint64_t h1 = ph1 + bsum[0], h2 = ph2 + bsum[1];
-                    int cd = par_dcal + (int)(long long)bsum[2];
-                    unsigned int carry = (unsigned int)pos;
-                    for (int k = mprod - 1; k >= 0 && carry; k--) {
-                        const unsigned int c = (unsigned int)prod_cnt[k], v = (unsigned int)digit[k] + carry;
-                        const unsigned int nd = v % c;
-                        carry = v / c;
-                        if ((int)nd != digit[k]) {
-                            const Cand *cn = &d.cand[prod_off[k] + nd], *co = &d.cand[prod_off[k] + digit[k]];
-                            cd += cn->ddcal - co->ddcal; h1 += cn->h1 - co->h1; h2 += cn->h2 - co->h2;
-                        }
-                    }
-                    if (h1 == 0) h1 = 1;
-                    if (h2 == 0) h2 = 1;
-                    hh1[j] = h1; hh2[j] = h2; cdd[j] = cd;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < R; j++)
-                if (tid * R + j < chunk) { isnew[j] = seen_lookup(stab, scap, hh1[j], hh2[j]) ? 0 : 1; cnt_new += isnew[j]; }
-            STAMP(8);   // carry decode + seen lookups (thread 0's share)
-            int tot, ex = block_exscan<BS_NT>(cnt_new, sh, &tot);
-            // first position where nb_branch reaches max_branch (the reference checks after every combo)
-            int hit = BS_NT * R;
-            {
-                int incl = ex;
-#pragma unroll
-                for (int j = 0; j < R; j++) {
-                    incl += isnew[j];
-                    if (tid * R + j < chunk && nb_branch + incl >= d.max_branch && hit == BS_NT * R) hit = tid * R + j;
-                }
-            }
-            for (int o = 32; o > 0; o >>= 1) hit = min(hit, __shfl_xor(hit, o, 64));
-            __syncthreads();
-            if (lane == 0) sh[16 + wv] = hit;
-            __syncthreads();
-            hit = sh[16];
-            for (int w = 1; w < BS_NT / 64; w++) hit = min(hit, sh[16 + w]);
-            const int processed = hit < BS_NT * R ? hit + 1 : chunk;
-            const int acc_tot = hit < BS_NT * R ? d.max_branch - nb_branch : tot;
-            STAMP(9);   // scans
-            {
-                int ci2 = nchild + ex;
-#pragma unroll
-                for (int j = 0; j < R; j++) {
-                    const int pos = tid * R + j;
-                    if (pos < processed && isnew[j]) {
-                        if (ci2 < d.ch_cap) {
-                            d.ch_parent[chb + ci2] = (uint16_t)b;
-                            d.ch_combo[chb + ci2] = cur + pos;
-                            d.ch_dcal[chb + ci2] = cdd[j];
-                            d.ch_h[2 * (chb + ci2)] = hh1[j];
-                            d.ch_h[2 * (chb + ci2) + 1] = hh2[j];
-                        } else atomicOr(&d.c->overflow, OVF_SORT);
-                        seen_insert(stab, scap, hh1[j], hh2[j]);
-                        ci2++;
-                    }
-                }
-            }
-            nchild += acc_tot; nb_branch += acc_tot; scnt += acc_tot;
-            cur += processed;
-            __syncthreads();
-            STAMP(10);  // child records + seen insert
-            if (nb_branch >= d.max_branch || cur >= total) break;
-            if (tid == 0) {                    // advance the base digits by `processed`
-                unsigned int carry = (unsigned int)processed;
+            // the reference stops after the combo that brings nb_branch to max_branch; while this chunk cannot
+            // get there every new structure in it is accepted, so lookup and insert are one pass
+            const int need = d.max_branch - nb_branch;
+            const bool fused = chunk < need;
+            int isnew = 0, cd = 0;
+            uint64_t h1 = 0, h2 = 0;
+            if (tid < chunk) {
+                unsigned long long a1 = bsum[0], a2 = bsum[1];
+                long long ad = (long long)bsum[2];
+                unsigned int carry = (unsigned int)(tid + shift);
+                int klow = mprod;
+                const bool last = tid == chunk - 1;           // its combo is the next chunk's base
                 for (int k = mprod - 1; k >= 0 && carry; k--) {
-                    const unsigned int c = (unsigned int)prod_cnt[k], v = (unsigned int)digit[k] + carry;
-                    digit[k] = (int)(v % c);
-                    carry = v / c;
+                    const unsigned int c = (unsigned int)prod_cnt[k], dg = (unsigned int)digit[k], v = dg + carry;
+                    unsigned int q = (unsigned int)((float)v * prod_rc[k]);      // v < 2^24: off by one at most
+                    int r = (int)(v - q * c);
+                    if (r < 0) { q--; r += (int)c; } else if (r >= (int)c) { q++; r -= (int)c; }
+                    carry = q;
+                    if ((unsigned)r != dg) {
+                        ad += c_dd(k, r) - c_dd(k, (int)dg); a1 += c_h1(k, r) - c_h1(k, (int)dg); a2 += c_h2(k, r) - c_h2(k, (int)dg);
+                    }
+                    if (last) { dnew[k] = r; klow = k; }
                 }
+                if (last) { sh[20] = klow; bsum[56] = a1; bsum[57] = a2; bsum[58] = (unsigned long long)ad; }
+                h1 = ph1 + a1; h2 = ph2 + a2; cd = par_dcal + (int)ad;
+                if (h1 == 0) h1 = 1;
+                if (h2 == 0) h2 = 1;
+                isnew = fused ? (seen_insert_new(stab, scap, h1, h2) ? 1 : 0) : (seen_lookup(stab, scap, h1, h2) ? 0 : 1);
             }
-            __syncthreads();
+            STAMP(8);   // carry decode + seen lookups (thread 0's share)
+            const unsigned long long bal = __ballot(isnew != 0);
+            if (lane == 0) sh[wv] = __popcll(bal);
+            __syncthreads();                                   // S1
+            int ex = __popcll(bal & ((1ULL << lane) - 1)), tot = 0;
+            for (int w = 0; w < BS_NT / 64; w++) { const int t = sh[w]; if (w < wv) ex += t; tot += t; }
+            const bool hit = tot >= need;                      // never in a fused chunk
+            if (isnew && ex < need) {
+                const int ci2 = nchild + ex;
+                if (ci2 < d.ch_cap) {
+                    d.ch_parent[chb + ci2] = (uint16_t)b;
+                    d.ch_combo[chb + ci2] = cur + tid;
+                    d.ch_dcal[chb + ci2] = cd;
+                    d.ch_h[2 * (chb + ci2)] = h1;
+                    d.ch_h[2 * (chb + ci2) + 1] = h2;
+                } else atomicOr(&d.c->overflow, OVF_SORT);
+                if (!fused) seen_insert(stab, scap, h1, h2);
+                if (hit && ex == need - 1) { d.st_cursor[sid] = cur + tid + 1; d.st_total[sid] = total; }   // walk stops here
+            }
+            STAMP(9);
+            const int acc = hit ? need : tot;
+            nchild += acc; nb_branch += acc; scnt += acc;
+            if (hit) { hit_done = true; __syncthreads(); break; }
+            cur += chunk;
+            if (cur < total) {                                 // adopt the last combo as the new base
+                const int klow = sh[20];
+                for (int k = klow + tid; k < mprod; k += BS_NT) digit[k] = dnew[k];
+                if (tid == 0) { bsum[0] = bsum[56]; bsum[1] = bsum[57]; bsum[2] = bsum[58]; }
+                shift = 1;
+            }
+            __syncthreads();                                   // S2
+            STAMP(10);  // child records + seen insert
         }
-        if (tid == 0) { d.st_cursor[sid] = cur; d.st_total[sid] = total; }
+        if (tid == 0 && !hit_done) { d.st_cursor[sid] = cur; d.st_total[sid] = total; }
     }
     STAMP(1);
     if (single_from < nbeam) {
@@ -1140,6 +1185,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
                 }
             }
         }
+        WS_END();
         return;
     }
     if (tid == 0) {
@@ -1183,6 +1229,8 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
     if (tid == 0) d.beam_n[sq] = nnew;
     STAMP(4);
     if (prof) d.prof[5] += 1;
+    WS_END();
+#undef WS_END
 #undef STAMP
 }
 

@@ -12,8 +12,8 @@ rafft_amd.fold_batch(seqs, 100, 50, 1000)
 print(json.dumps(rafft_amd.last_stats()))
 '''
 base = None
-names = {0: "baseline", 1: "FFT/corr x2", 2: "rank sort x2", 4: "window_slide x2", 8: "dE x2", 16: "LDS fill x2", 32: "direct corr+values x2"}
-for rep in (0, 1, 2, 4, 8, 16, 32):
+names = {0: "baseline", 1: "FFT/corr x2", 2: "rank sort x2", 4: "window_slide x2", 8: "dE x2", 16: "LDS fill x2", 32: "direct corr+values x2", 64: "emit x2", 128: "mask setup x2"}
+for rep in (0, 1, 2, 4, 8, 16, 32, 64, 128):
     env = dict(os.environ, RAFFT_REP=str(rep), RAFFT_SERIAL="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip().split("\n")[-1]
     st = json.loads(out)
