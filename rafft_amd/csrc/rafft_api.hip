@@ -59,7 +59,7 @@ struct Workspace {
     void *hot = nullptr;                 // pinned, 256 B
     // named device buffers (grow-only)
     Buf codes, seq_off, seq_len, beam, beam_n, done, nsteps, ch_parent, ch_combo, ch_dcal, ch_h, seen, seen_off,
-        seen_cap, seen_cnt, st_seq, st_dcal, st_node0, st_nnodes, st_parent, st_h, st_db, st_cursor, st_combo, st_total, st_prod, st_nprod, prod, nd_seq, nd_pdcal,
+        seen_cap, seen_cnt, st_seq, st_dcal, st_node0, st_nnodes, st_parent, st_h, st_db, st_cursor, st_combo, st_total, st_prod, st_nprod, st_c0h, st_c0d, prod, nd_seq, nd_pdcal,
         nd_n, nd_ci, nd_cj, nd_nbr, nd_canon, nd_ncand, nd_pos, nd_br, nd_cand, pos, br, db, cand, looptab, trec, tsid,
         work0, work1, work2, work3, mat, counters,
         row_sid, row_off, out_db, out_dcal, dbg;
@@ -276,7 +276,7 @@ Caps plan_caps(size_t S, size_t sumL, const rafft_params &p, double est)
     // keys of one step: children + old beam; only the max_stack selected ones are sorted (padded to a power of two)
     int m2 = 2; while (m2 < p.max_stack) m2 <<= 1;
     c.sort_cap = std::max((need + 1) & ~1, m2);
-    c.bytes = c.st * (4 * 6 + 8 * 6) + c.nd * (4 * 8 + 8 * 3 + 4 * 4 + 16) + c.pos * 2 + c.br * 4 + c.db + c.cand * 32 + c.seen * 16 +
+    c.bytes = c.st * (4 * 7 + 8 * 8) + c.nd * (4 * 8 + 8 * 3 + 4 * 4 + 16) + c.pos * 2 + c.br * 4 + c.db + c.cand * 32 + c.seen * 16 +
               c.looptab * 8 + c.trec * 16 + c.tsid * 4 + c.mat * 4 + S * (size_t)c.ch_cap * 32 + S * B * 4;
     return c;
 }
@@ -330,7 +330,7 @@ struct Wave {
     HostOut &out;
     std::vector<Span> &spans;
     const SeamIn *seam;
-    size_t S = 0, sumL = 0, B = 0, bs_lds = 0;
+    size_t S = 0, sumL = 0, B = 0, bs_lds[2] = {0, 0};
     std::vector<int> off, len;
     ClsCfg cf[NCLS];
     Caps c;
@@ -376,7 +376,7 @@ int Wave::setup()
     for (size_t i = 0; i < S; i++) maxL = std::max(maxL, len[i]);
     if (int rc = class_cfg(p.nb_mode, maxL, cf)) return rc;
     c = plan_caps(S, sumL, p, est);
-    if ((size_t)c.sort_cap * 8 + MAX_PROD * 28 + (size_t)(p.max_stack + 4) * (sizeof(ParentInfo) + 4) + BS_CACHE * 20 + 1024 > 150 * 1024)
+    if (std::max((size_t)c.sort_cap * 8, (size_t)24 * 1024) + RL_CAP * 12 + (size_t)(p.max_stack + 4) * (sizeof(ParentInfo) + 12) + 1024 > 150 * 1024)
         return fail(RAFFT_ERR_PARAM, "max_branch + 2*max_stack too large for the LDS-resident beam sort");
     B = (size_t)p.max_stack;
 
@@ -386,7 +386,7 @@ int Wave::setup()
     ENS(ch_parent, S * c.ch_cap * 2); ENS(ch_combo, S * c.ch_cap * 8); ENS(ch_dcal, S * c.ch_cap * 4); ENS(ch_h, S * c.ch_cap * 16);
     ENS(seen, c.seen * 16); ENS(seen_off, S * 8); ENS(seen_cap, S * 4); ENS(seen_cnt, S * 4);
     ENS(st_seq, c.st * 4); ENS(st_dcal, c.st * 4); ENS(st_node0, c.st * 4); ENS(st_nnodes, c.st * 4); ENS(st_parent, c.st * 4);
-    ENS(st_h, c.st * 16); ENS(st_db, c.st * 8); ENS(st_cursor, c.st * 8); ENS(st_combo, c.st * 8); ENS(st_total, c.st * 8); ENS(st_prod, c.st * 8); ENS(st_nprod, c.st * 4); ENS(prod, c.nd * 16);
+    ENS(st_h, c.st * 16); ENS(st_db, c.st * 8); ENS(st_cursor, c.st * 8); ENS(st_combo, c.st * 8); ENS(st_total, c.st * 8); ENS(st_prod, c.st * 8); ENS(st_nprod, c.st * 4); ENS(st_c0h, c.st * 16); ENS(st_c0d, c.st * 4); ENS(prod, c.nd * 16);
     ENS(nd_seq, c.nd * 4); ENS(nd_pdcal, c.nd * 4); ENS(nd_n, c.nd * 4); ENS(nd_ci, c.nd * 4); ENS(nd_cj, c.nd * 4);
     ENS(nd_nbr, c.nd * 4); ENS(nd_canon, c.nd * 4); ENS(nd_ncand, c.nd * 4);
     ENS(nd_pos, c.nd * 8); ENS(nd_br, c.nd * 8); ENS(nd_cand, c.nd * 8);
@@ -417,6 +417,7 @@ int Wave::setup()
     d.st_seq = (int *)g.st_seq.p; d.st_dcal = (int *)g.st_dcal.p; d.st_node0 = (int *)g.st_node0.p; d.st_nnodes = (int *)g.st_nnodes.p;
     d.st_parent = (int *)g.st_parent.p; d.st_h = (uint64_t *)g.st_h.p; d.st_db = (uint64_t *)g.st_db.p;
     d.st_cursor = (uint64_t *)g.st_cursor.p; d.st_combo = (uint64_t *)g.st_combo.p; d.st_total = (uint64_t *)g.st_total.p; d.st_prod = (uint64_t *)g.st_prod.p; d.st_nprod = (int *)g.st_nprod.p;
+    d.st_c0h = (uint64_t *)g.st_c0h.p; d.st_c0d = (int *)g.st_c0d.p;
     d.prod = (ProdEnt *)g.prod.p; d.prod_shard_cap = c.nd / NSHARD;
     d.nd_cap = (uint32_t)c.nd;
     d.nd_seq = (int *)g.nd_seq.p; d.nd_pdcal = (int *)g.nd_pdcal.p; d.nd_n = (int *)g.nd_n.p; d.nd_ci = (int *)g.nd_ci.p;
@@ -464,8 +465,11 @@ int Wave::setup()
     hipLaunchKernelGGL(init_roots_kernel, dim3((unsigned)S), dim3(64), 0, st, d);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));      // `codes` (host vector) must outlive the copy
-    bs_lds = (size_t)c.sort_cap * 8 + MAX_PROD * 12 + B * sizeof(ParentInfo) + ((B + 3) & ~(size_t)3) * 4 + 128 + MAX_PROD * 4 + 16 * 8 * 4 +
-             BS_CACHE * 20 + MAX_PROD * 12;
+    // beam_step_kernel LDS: time-shared region 0 (walk scratch 24 B/thread, then sort keys), region list, per-member records
+    for (int v = 0; v < 2; v++) {
+        const size_t nt = v ? 1024 : 256;
+        bs_lds[v] = std::max((size_t)c.sort_cap * 8, 24 * nt) + RL_CAP * 12 + B * sizeof(ParentInfo) + (B + 1) * 8 + ((B + 3) & ~(size_t)3) * 4 + 128;
+    }
     n_active = (unsigned)S;
     ms_setup = since(tw0);
     tw1 = std::chrono::steady_clock::now();
@@ -513,8 +517,8 @@ int Wave::issue_step()
         HIPCHK(hipEventRecord(sp.a, st));
         // few sequences left (the long ones): a 1024-thread workgroup per sequence shortens the serial
         // chains (16 wavefronts for the prepass, 1024 combos per chunk); many sequences: 256 threads
-        if (n_active < wide_below) hipLaunchKernelGGL(beam_step_kernel<1024>, dim3((unsigned)S), dim3(1024), bs_lds, st, d, c.sort_cap);
-        else hipLaunchKernelGGL(beam_step_kernel<256>, dim3((unsigned)S), dim3(256), bs_lds, st, d, c.sort_cap);
+        if (n_active < wide_below) hipLaunchKernelGGL(beam_step_kernel<1024>, dim3((unsigned)S), dim3(1024), bs_lds[1], st, d, c.sort_cap);
+        else hipLaunchKernelGGL(beam_step_kernel<256>, dim3((unsigned)S), dim3(256), bs_lds[0], st, d, c.sort_cap);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(sp.b, st));
         spans.push_back(sp);
@@ -664,11 +668,12 @@ int Wave::finish()
         for (size_t i = 0; i < S; i++) ord[i] = (int)i;
         std::sort(ord.begin(), ord.end(), [&](int a, int b) { return wsv[3 * a] > wsv[3 * b]; });
         unsigned long long tot = 0, totc = 0;
-        for (size_t i = 0; i < S; i++) { tot += wsv[3 * i]; totc += wsv[3 * i + 1]; }
-        fprintf(stderr, "[rafft] beam_step per sequence: total cycles %llu, total chunks %llu over %zu sequences\n", tot, totc, S);
+        unsigned long long totp = 0, totk = 0;
+        for (size_t i = 0; i < S; i++) { tot += wsv[3 * i]; totc += wsv[3 * i + 1] & 0xFFFFFF; totk += wsv[3 * i + 1] >> 24; totp += wsv[3 * i + 2]; }
+        fprintf(stderr, "[rafft] beam_step per sequence: total cycles %llu, chunks %llu, combos %llu, parents walked %llu over %zu sequences\n", tot, totc, totk, totp, S);
         for (size_t k = 0; k < std::min<size_t>(S, 12); k++) {
             int i = ord[k];
-            fprintf(stderr, "[rafft]   #%zu local seq %d (L=%d): cycles %llu, chunks %llu, slowest step %llu\n", k, i, len[i], wsv[3 * i], wsv[3 * i + 1], wsv[3 * i + 2]);
+            fprintf(stderr, "[rafft]   #%zu local seq %d (L=%d): cycles %llu, chunks %llu, combos %llu, parents walked %llu\n", k, i, len[i], wsv[3 * i], wsv[3 * i + 1] & 0xFFFFFF, wsv[3 * i + 1] >> 24, wsv[3 * i + 2]);
         }
     }
     if (d.prof) {

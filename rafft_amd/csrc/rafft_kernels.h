@@ -82,6 +82,7 @@ struct Dev {
     int *st_seq, *st_dcal, *st_node0, *st_nnodes, *st_parent;
     uint64_t *st_h, *st_db, *st_cursor, *st_combo, *st_total, *st_prod;
     int *st_nprod;
+    uint64_t *st_c0h; int *st_c0d;   // hash and energy of a structure's combo 0 (kept for resumed product walks)
     ProdEnt *prod; uint64_t prod_shard_cap;
     // nodes
     uint32_t nd_cap;
@@ -119,6 +120,7 @@ struct Dev {
 #define MAX_P 8192
 #define MAX_BR 1024
 #define MAX_PROD 256
+#define RL_CAP 1024        // beam_step_kernel: regions with >= 2 candidates of all beam members, kept in LDS
 
 __host__ __device__ inline int next_pow2_ge(int x) { int p = 2; while (p < x) p <<= 1; return p; }
 __host__ __device__ inline int node_class(int n, int L, int nbr)

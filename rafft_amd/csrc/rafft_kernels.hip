@@ -748,12 +748,14 @@ __device__ inline void seen_insert(uint64_t *tab, uint32_t cap, uint64_t h1, uin
 
 
 struct ParentInfo {         // filled by the parallel prepass, one entry per beam member
-    unsigned long long total, h1, h2;     // product size; pair-set hash of combo 0
-    unsigned long long cur, prod, ph1, ph2;   // cursor, productive-region list, the parent's own hash
+    unsigned long long total, cur;        // product size, cursor
+    unsigned long long h1, h2;            // pair-set hash of combo 0 (absolute)
     int dcal0, flag;        // energy of combo 0; flag: 0 live, 1 nothing to produce, 2 cursor already moved
-    int nprod, pdcal;       // productive regions, the parent's own energy
+    int sid, nprod;         // structure id; productive regions
+    unsigned long long prod;              // productive-region list (global)
+    int rl0, nrl;           // this member's regions with >= 2 candidates in the LDS list (rl0 < 0: not resident)
 };
-#define BS_CACHE 256        // candidates of one parent kept in LDS during its product walk
+static_assert(sizeof(ParentInfo) == 64, "ParentInfo layout");
 
 __device__ __forceinline__ unsigned long long sat_mul(unsigned long long a, unsigned long long b)
 {
@@ -767,20 +769,18 @@ template <int BS_NT>
 __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
 {
     extern __shared__ __align__(16) unsigned char lds[];
+    // region 0 is time-shared: scratch of the product walk (per-thread keys + dedupe table), then the sort keys
+    const size_t r0 = max((size_t)8 * (size_t)sort_cap, (size_t)24 * BS_NT);
     unsigned long long *skey = (unsigned long long *)lds;                       // [sort_cap]
-    unsigned long long *prod_off = (unsigned long long *)(lds + 8 * (size_t)sort_cap); // [MAX_PROD]
-    int *prod_cnt = (int *)(prod_off + MAX_PROD);                               // [MAX_PROD]
-    ParentInfo *pinfo = (ParentInfo *)(prod_cnt + MAX_PROD);                    // [B]
-    int *oldbeam = (int *)(pinfo + d.B);                                        // [B]
+    unsigned long long *wk_h1 = (unsigned long long *)lds;                      // [BS_NT] keys of this chunk's combos
+    unsigned long long *wk_h2 = wk_h1 + BS_NT;                                  // [BS_NT]
+    unsigned int *wk_tab = (unsigned int *)(wk_h2 + BS_NT);                     // [2 BS_NT] first claimant of a key
+    unsigned long long *rl_off = (unsigned long long *)(lds + r0);              // [RL_CAP] candidate offset of a region
+    int *rl_cnt = (int *)(rl_off + RL_CAP);                                     // [RL_CAP] its candidate count (>= 2)
+    ParentInfo *pinfo = (ParentInfo *)(rl_cnt + RL_CAP);                        // [B]
+    unsigned long long *ppre = (unsigned long long *)(pinfo + d.B);             // [B + 1] flat positions of the products
+    int *oldbeam = (int *)(ppre + d.B + 1);                                     // [B]
     int *sh = oldbeam + ((d.B + 3) & ~3);                                       // scratch [32]
-    int *digit = sh + 32;                                                       // [MAX_PROD] odometer digits
-    unsigned long long *bsum = (unsigned long long *)(digit + MAX_PROD);        // [16] partial sums
-    unsigned long long *cc_h1 = bsum + 16 * 4;                                  // [BS_CACHE] cached candidates of the
-    unsigned long long *cc_h2 = cc_h1 + BS_CACHE;                               //   parent being walked
-    int *cc_dd = (int *)(cc_h2 + BS_CACHE);                                     // [BS_CACHE]
-    int *cc_off = cc_dd + BS_CACHE;                                             // [MAX_PROD] first cache slot of region k
-    int *dnew = cc_off + MAX_PROD;                                              // [MAX_PROD] digits of the next base combo
-    float *prod_rc = (float *)(dnew + MAX_PROD);                                // [MAX_PROD] 1 / prod_cnt
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int sq = blockIdx.x;
     // snapshot of the region allocators: whatever materialize adds after this kernel is "new"
@@ -789,9 +789,9 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
     const bool prof = d.prof && sq == d.prof_seq && tid == 0;   // diagnostic stamps (RAFFT_TRACE=3)
     unsigned long long tprev = prof ? clock64() : 0;
     const unsigned long long t_begin = d.prof_ws ? clock64() : 0;
-    unsigned long long n_chunks = 0;
-#define WS_END() do { if (d.prof_ws && tid == 0) { unsigned long long dt_ = clock64() - t_begin; d.prof_ws[3 * sq] += dt_; d.prof_ws[3 * sq + 1] += n_chunks; \
-        if (dt_ > d.prof_ws[3 * sq + 2]) d.prof_ws[3 * sq + 2] = dt_; } } while (0)
+    unsigned long long n_chunks = 0, n_par = 0, n_combos = 0;
+#define WS_END() do { if (d.prof_ws && tid == 0) { unsigned long long dt_ = clock64() - t_begin; d.prof_ws[3 * sq] += dt_; d.prof_ws[3 * sq + 1] += n_chunks | (n_combos << 24); \
+        d.prof_ws[3 * sq + 2] += n_par; } } while (0)
 #define STAMP(k) do { if (prof) { unsigned long long tn_ = clock64(); d.prof[k] += tn_ - tprev; tprev = tn_; } } while (0)
     const int nbeam = d.beam_n[sq];
     int *beam = d.beam + (size_t)sq * d.B;
@@ -813,254 +813,295 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
     }
     if (tid == 0) d.nsteps[sq] += 1;
 
-    // ---- prepass: product size and combo 0 of every parent.  A group of G lanes per beam member (G = 16 for
-    // short sequences, whose structures have few regions; a whole wavefront otherwise): every member costs a
-    // chain of dependent loads (structure -> regions -> canonical region -> candidate), so the more members
-    // are in flight at once the fewer round trips the prepass takes.
+    // ---- prepass: product size and combo 0 of every parent, and its regions with a real choice (>= 2
+    // candidates) as a compact list in LDS.  A group of G lanes per beam member (G = 16 for short sequences,
+    // whose structures have few regions; a whole wavefront otherwise): every member costs a chain of dependent
+    // loads (structure -> regions -> canonical region -> candidate), so the more members are in flight at once
+    // the fewer round trips the prepass takes.
+    if (tid == 0) sh[26] = 0;                  // fill of the LDS region list
+    __syncthreads();
     {
         const int G = d.seq_len[sq] <= 800 ? 16 : 64;
         const int gpw = 64 / G, gl = lane & (G - 1), grp = lane / G;
         const int nslots = (BS_NT / 64) * gpw;
         const unsigned long long gmask = G == 64 ? ~0ULL : ((1ULL << G) - 1ULL);
+        const unsigned long long lt = (1ULL << gl) - 1ULL;
         for (int b0 = 0; b0 < nbeam; b0 += nslots) {
             const int b = b0 + wv * gpw + grp;
             if (b >= nbeam) continue;
             const int sid = oldbeam[b];
             const unsigned long long cur0 = d.st_cursor[sid], tot0 = d.st_total[sid];
             if (tot0 && cur0 >= tot0) { if (gl == 0) pinfo[b].flag = 1; continue; }
-            const int curbit = cur0 > 0 ? 2 : 0;
-            const int sdcal = d.st_dcal[sid];
-            const unsigned long long sh1 = d.st_h[2 * (size_t)sid], sh2 = d.st_h[2 * (size_t)sid + 1];
-            if (tot0 && cur0 > 0) {      // expanded in an earlier step: only the cursor/total matter now
+            const bool resumed = tot0 && cur0 > 0;
+            unsigned long long pbase = 0, tot = 1, h1 = 0, h2 = 0;
+            int dc = 0, np = 0, wpos = 0, nm = 0, rl0 = -1;
+            if (resumed) {       // expanded in an earlier step: cursor, total and combo 0 are on record
+                pbase = d.st_prod[sid]; wpos = d.st_nprod[sid];
+                for (int base = 0; base < wpos; base += G) {
+                    const int i = base + gl;
+                    const int cnt = i < wpos ? (int)d.prod[pbase + i].cnt : 0;
+                    nm += __popcll((__ballot(cnt >= 2) >> (grp * G)) & gmask);
+                }
+            } else {
+                const int node0 = d.st_node0[sid], nn = d.st_nnodes[sid];
+                // first visit of this structure: its productive regions (node order, rafft/rafft.py:166-171) are
+                // written once as a compact list that later product walks and materialize_kernel read back
                 if (gl == 0) {
-                    ParentInfo pi; pi.flag = curbit; pi.total = tot0; pi.h1 = pi.h2 = 0; pi.dcal0 = 0;
-                    pi.cur = cur0; pi.prod = d.st_prod[sid]; pi.nprod = d.st_nprod[sid]; pi.pdcal = sdcal; pi.ph1 = sh1; pi.ph2 = sh2;
-                    pinfo[b] = pi;
+                    const int shd = sq & (NSHARD - 1);
+                    pbase = atomicAdd(&d.c->prod[shd].v, (unsigned long long)nn);
+                    if (pbase + nn > d.prod_shard_cap) { atomicOr(&d.c->overflow, OVF_PRODLIST); pbase = ~0ULL; }
+                    else pbase += (unsigned long long)shd * d.prod_shard_cap;
                 }
-                continue;
-            }
-            const int node0 = d.st_node0[sid], nn = d.st_nnodes[sid];
-            unsigned long long tot = 1, h1 = 0, h2 = 0;
-            int dc = 0, np = 0;
-            // first visit of this structure: its productive regions (node order, rafft/rafft.py:166-171) are
-            // written once as a compact list that the product walk and materialize_kernel read back
-            unsigned long long pbase = 0;
-            if (gl == 0) {
-                const int shd = sq & (NSHARD - 1);
-                pbase = atomicAdd(&d.c->prod[shd].v, (unsigned long long)nn);
-                if (pbase + nn > d.prod_shard_cap) { atomicOr(&d.c->overflow, OVF_PRODLIST); pbase = ~0ULL; }
-                else pbase += (unsigned long long)shd * d.prod_shard_cap;
-            }
-            pbase = __shfl(pbase, grp * G, 64);
-            int wpos = 0;
-            for (int base = 0; base < nn; base += G) {
-                int i = base + gl, cnt = 0, cn = 0;
-                unsigned long long coff = 0;
-                if (i < nn) {
-                    cn = d.nd_canon[node0 + i];
-                    cnt = d.nd_ncand[cn];
-                    if (cnt > 0) {
-                        coff = d.nd_cand[cn];
-                        const Cand *cp = &d.cand[coff];
-                        tot = sat_mul(tot, (unsigned long long)cnt);
-                        dc += cp->ddcal; h1 += cp->h1; h2 += cp->h2; np++;
+                pbase = __shfl(pbase, grp * G, 64);
+                for (int base = 0; base < nn; base += G) {
+                    int i = base + gl, cnt = 0, cn = 0;
+                    unsigned long long coff = 0;
+                    if (i < nn) {
+                        cn = d.nd_canon[node0 + i];
+                        cnt = d.nd_ncand[cn];
+                        if (cnt > 0) {
+                            coff = d.nd_cand[cn];
+                            const Cand *cp = &d.cand[coff];
+                            tot = sat_mul(tot, (unsigned long long)cnt);
+                            dc += cp->ddcal; h1 += cp->h1; h2 += cp->h2; np++;
+                        }
                     }
+                    const unsigned long long bal = (__ballot(cnt > 0) >> (grp * G)) & gmask;   // this group's lanes
+                    const unsigned long long bal2 = (__ballot(cnt >= 2) >> (grp * G)) & gmask;
+                    if (cnt > 0 && pbase != ~0ULL) {
+                        ProdEnt pe; pe.cnt = (uint32_t)cnt; pe.node = cn; pe.off = coff;
+                        d.prod[pbase + wpos + __popcll(bal & lt)] = pe;
+                    }
+                    if (nn <= G) {           // the usual case, one round: the region list straight from registers
+                        nm = __popcll(bal2);
+                        if (gl == 0) { const int o = atomicAdd(&sh[26], nm); rl0 = o + nm <= RL_CAP ? o : -1; }
+                        rl0 = __shfl(rl0, grp * G, 64);
+                        if (cnt >= 2 && rl0 >= 0) { const int sl = rl0 + __popcll(bal2 & lt); rl_cnt[sl] = cnt; rl_off[sl] = coff; }
+                    } else nm += __popcll(bal2);
+                    wpos += __popcll(bal);
                 }
-                const unsigned long long bal = (__ballot(cnt > 0) >> (grp * G)) & gmask;   // this group's lanes
-                if (cnt > 0 && pbase != ~0ULL) {
-                    ProdEnt pe; pe.cnt = (uint32_t)cnt; pe.node = cn; pe.off = coff;
-                    d.prod[pbase + wpos + __popcll(bal & ((1ULL << gl) - 1))] = pe;
+                if (pbase == ~0ULL) { pbase = 0; wpos = 0; nm = 0; }
+                if (wpos > MAX_PROD && gl == 0) atomicOr(&d.c->overflow, OVF_PROD);     // materialize_kernel's limit
+                if (gl == 0) { d.st_prod[sid] = pbase; d.st_nprod[sid] = wpos; }
+                if (gl == 0 && wpos > 64) atomicMax(&d.c->max_nprod, (unsigned int)wpos);
+                for (int o = G >> 1; o > 0; o >>= 1) {
+                    tot = sat_mul(tot, __shfl_xor(tot, o, 64));
+                    h1 += __shfl_xor(h1, o, 64); h2 += __shfl_xor(h2, o, 64);
+                    dc += __shfl_xor(dc, o, 64); np += __shfl_xor(np, o, 64);
                 }
-                wpos += __popcll(bal);
+                if (nn > G) __threadfence_block();       // the list is read back below by other lanes of the group
             }
-            if (gl == 0) { d.st_prod[sid] = pbase == ~0ULL ? 0 : pbase; d.st_nprod[sid] = pbase == ~0ULL ? 0 : wpos; }
-            if (gl == 0 && wpos > 64) atomicMax(&d.c->max_nprod, (unsigned int)wpos);
-            for (int o = G >> 1; o > 0; o >>= 1) {
-                tot = sat_mul(tot, __shfl_xor(tot, o, 64));
-                h1 += __shfl_xor(h1, o, 64); h2 += __shfl_xor(h2, o, 64);
-                dc += __shfl_xor(dc, o, 64); np += __shfl_xor(np, o, 64);
+            if (resumed || (!resumed && wpos > 0 && rl0 < 0 && nm > 0 && d.st_nnodes[sid] > G)) {
+                // region list from the productive-region list in global memory
+                if (gl == 0) { const int o = atomicAdd(&sh[26], nm); rl0 = o + nm <= RL_CAP ? o : -1; }
+                rl0 = __shfl(rl0, grp * G, 64);
+                int w = 0;
+                if (rl0 >= 0)
+                    for (int base = 0; base < wpos; base += G) {
+                        const int i = base + gl;
+                        ProdEnt pe; pe.cnt = 0; pe.off = 0;
+                        if (i < wpos) pe = d.prod[pbase + i];
+                        const unsigned long long bal2 = (__ballot(pe.cnt >= 2) >> (grp * G)) & gmask;
+                        if (pe.cnt >= 2) { const int sl = rl0 + w + __popcll(bal2 & lt); rl_cnt[sl] = (int)pe.cnt; rl_off[sl] = pe.off; }
+                        w += __popcll(bal2);
+                    }
             }
             if (gl == 0) {
                 ParentInfo pi;
-                pi.flag = (np == 0 ? 1 : 0) | curbit;
-                pi.total = tot;
-                pi.h1 = sh1 + h1; pi.h2 = sh2 + h2;
-                pi.dcal0 = sdcal + dc;
-                pi.cur = 0; pi.prod = pbase == ~0ULL ? 0 : pbase; pi.nprod = pbase == ~0ULL ? 0 : wpos; pi.pdcal = sdcal; pi.ph1 = sh1; pi.ph2 = sh2;
+                pi.sid = sid; pi.prod = pbase; pi.nprod = wpos; pi.rl0 = nm == 0 ? 0 : rl0; pi.nrl = nm;
+                if (resumed) {
+                    pi.flag = 2; pi.total = tot0; pi.cur = cur0;
+                    pi.h1 = d.st_c0h[2 * (size_t)sid]; pi.h2 = d.st_c0h[2 * (size_t)sid + 1]; pi.dcal0 = d.st_c0d[sid];
+                } else {
+                    pi.flag = np == 0 ? 1 : 0; pi.total = tot; pi.cur = 0;
+                    pi.h1 = d.st_h[2 * (size_t)sid] + h1; pi.h2 = d.st_h[2 * (size_t)sid + 1] + h2;
+                    pi.dcal0 = d.st_dcal[sid] + dc;
+                    d.st_c0h[2 * (size_t)sid] = pi.h1; d.st_c0h[2 * (size_t)sid + 1] = pi.h2; d.st_c0d[sid] = pi.dcal0;
+                    if (np == 0) { d.st_total[sid] = 1; d.st_cursor[sid] = 1; }
+                }
                 pinfo[b] = pi;
-                if (np == 0) { d.st_total[sid] = 1; d.st_cursor[sid] = 1; }
             }
         }
     }
     __syncthreads();
-
     STAMP(0);
+
+    // ---- the product walk (rafft/rafft.py:173-204), flat over all parents: position p of the walk is combo
+    // cur_b + (p - ppre[b]) of the parent b whose range holds p, in beam order and itertools.product order.
+    // One chunk of BS_NT consecutive positions per pass - usually several whole parents at once.
+    if (wv == 0) {
+        unsigned long long carry = 0;
+        const unsigned long long LIM = 1ULL << 63;
+        for (int base = 0; base < nbeam; base += 64) {
+            const int b = base + lane;
+            unsigned long long rem = 0;
+            if (b < nbeam && !(pinfo[b].flag & 1)) rem = pinfo[b].total - pinfo[b].cur;
+            unsigned long long x = rem;
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned long long y = __shfl_up(x, o, 64);
+                if (lane >= o) x = (x > LIM - y) ? LIM : x + y;
+            }
+            unsigned long long incl = (x > LIM - carry) ? LIM : x + carry;
+            if (b < nbeam) ppre[b + 1] = incl;
+            carry = __shfl(incl, 63, 64);
+        }
+        if (lane == 0) ppre[0] = 0;
+    }
+    for (int i = tid; i < 2 * BS_NT; i += BS_NT) wk_tab[i] = 0;
+    __syncthreads();
     uint64_t *stab = d.seen + 2 * d.seen_off[sq];
     uint32_t scap = d.seen_cap[sq], scnt = d.seen_cnt[sq];
     const size_t chb = (size_t)sq * d.ch_cap;
     int nb_branch = 0, nchild = 0;
-
     int single_from = nbeam;
-    for (int b = 0; b < nbeam; b++) {
-        // once nb_branch >= max_branch every later parent only replays its combo 0
-        // (rafft/rafft.py:202-203): those are handled together, in parallel, after this loop
-        if (nb_branch >= d.max_branch) { single_from = b; break; }
-        if (pinfo[b].flag & 1) continue;
-        const int sid = oldbeam[b];
-        unsigned long long cur = pinfo[b].cur;
-        const unsigned long long total = pinfo[b].total;
-        // productive regions of this parent (compact list written at its first visit)
-        int mprod = pinfo[b].nprod;
-        if (mprod > MAX_PROD) { if (tid == 0) atomicOr(&d.c->overflow, OVF_PROD); mprod = MAX_PROD; }
-        bool cached;
-        {
-            const ProdEnt *pl = d.prod + pinfo[b].prod;
-            int mycnt = 0;
-            for (int k = tid; k < mprod; k += BS_NT) { mycnt = (int)pl[k].cnt; prod_cnt[k] = mycnt; prod_off[k] = pl[k].off; }
-            // the candidates of all productive regions go to LDS when they fit (they nearly always do):
-            // the walk below then touches global memory only for the `seen` set and the child records
-            int ctot, cex = block_exscan<BS_NT>(tid < mprod ? mycnt : 0, sh, &ctot);   // MAX_PROD <= BS_NT
-            if (tid < mprod) cc_off[tid] = cex;
-            cached = ctot <= BS_CACHE;
-            __syncthreads();
-            if (cached) {
-                for (int e = tid; e < ctot; e += BS_NT) {
-                    int lo = 0, hi = mprod - 1;                   // region k with cc_off[k] <= e < cc_off[k] + cnt[k]
-                    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (cc_off[mid] <= e) lo = mid; else hi = mid - 1; }
-                    const Cand *cp = &d.cand[prod_off[lo] + (unsigned)(e - cc_off[lo])];
-                    cc_dd[e] = cp->ddcal; cc_h1[e] = cp->h1; cc_h2[e] = cp->h2;
-                }
-                __syncthreads();
-            }
-        }
-        const int par_dcal = pinfo[b].pdcal;
-        const uint64_t ph1 = pinfo[b].ph1, ph2 = pinfo[b].ph2;
-        // Digits in LDS describe combo (cur - shift): thread t decodes combo cur + t as "base + carry".  A
-        // fresh parent starts at its combo 0 (shift 0); afterwards the base is the LAST combo of the previous
-        // chunk (shift 1), whose digits and sums that chunk's last thread has computed anyway - nobody has to
-        // advance the odometer serially between chunks (itertools.product order, rafft/rafft.py:180).
-        int shift = cur == 0 ? 0 : 1;
-        for (int k = tid; k < mprod; k += BS_NT) prod_rc[k] = 1.0f / (float)prod_cnt[k];
-        if (cur == 0) { for (int k = tid; k < mprod; k += BS_NT) digit[k] = 0; }
-        else if (tid == 0) {                   // resuming: one long division
-            unsigned long long idx = cur - 1;
-            for (int k = mprod - 1; k >= 0; k--) {
-                unsigned long long c = (unsigned long long)prod_cnt[k], q = idx / c;
-                digit[k] = (int)(idx - q * c);
-                idx = q;
-            }
-        }
-        __syncthreads();
-        auto c_dd = [&](int k, int dg) -> int { return cached ? cc_dd[cc_off[k] + dg] : d.cand[prod_off[k] + (unsigned)dg].ddcal; };
-        auto c_h1 = [&](int k, int dg) -> uint64_t { return cached ? cc_h1[cc_off[k] + dg] : d.cand[prod_off[k] + (unsigned)dg].h1; };
-        auto c_h2 = [&](int k, int dg) -> uint64_t { return cached ? cc_h2[cc_off[k] + dg] : d.cand[prod_off[k] + (unsigned)dg].h2; };
-        {   // sums over the base digits, once per parent
-            unsigned long long a1 = 0, a2 = 0; long long ad = 0;
-            for (int k = tid; k < mprod; k += BS_NT) { const int dg = digit[k]; a1 += c_h1(k, dg); a2 += c_h2(k, dg); ad += c_dd(k, dg); }
-            for (int o = 32; o > 0; o >>= 1) {
-                a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); ad += __shfl_xor(ad, o, 64);
-            }
-            if (lane == 0) { bsum[4 + 3 * wv] = a1; bsum[5 + 3 * wv] = a2; bsum[6 + 3 * wv] = (unsigned long long)ad; }
-            __syncthreads();
+    // once nb_branch >= max_branch every later parent only replays its combo 0
+    // (rafft/rafft.py:202-203): those are handled together, in parallel, after this loop
+    if (d.max_branch <= 0) single_from = 0;
+    const unsigned long long Ptot = ppre[nbeam];
+    unsigned long long W = 0;
+    while (single_from == nbeam && W < Ptot) {
+        const unsigned long long left = Ptot - W;
+        const int chunk = left < (unsigned long long)BS_NT ? (int)left : BS_NT;
+        if ((unsigned long long)(scnt + chunk) * 2 > scap) {   // grow the seen set (rehash into a zeroed region)
+            uint32_t ncap = scap;
+            while ((unsigned long long)(scnt + BS_NT) * 2 > ncap) ncap <<= 1;
             if (tid == 0) {
-                unsigned long long t1 = 0, t2 = 0, td = 0;
-                for (int w = 0; w < BS_NT / 64; w++) { t1 += bsum[4 + 3 * w]; t2 += bsum[5 + 3 * w]; td += bsum[6 + 3 * w]; }
-                bsum[0] = t1; bsum[1] = t2; bsum[2] = td;
+                unsigned long long o = atomicAdd(&d.c->seen_top, (unsigned long long)ncap);
+                if (o + ncap > d.seen_cap_total) { atomicOr(&d.c->overflow, OVF_SEEN); *(unsigned long long *)&sh[8] = ~0ULL; }
+                else *(unsigned long long *)&sh[8] = o;
             }
             __syncthreads();
-        }
-        bool hit_done = false;
-        while (cur < total) {
-            const unsigned long long left = total - cur;
-            const int chunk = left < (unsigned long long)BS_NT ? (int)left : BS_NT;
-            if ((unsigned long long)(scnt + chunk) * 2 > scap) {   // grow the seen set (rehash into a zeroed region)
-                uint32_t ncap = scap;
-                while ((unsigned long long)(scnt + BS_NT) * 2 > ncap) ncap <<= 1;
-                if (tid == 0) {
-                    unsigned long long o = atomicAdd(&d.c->seen_top, (unsigned long long)ncap);
-                    if (o + ncap > d.seen_cap_total) { atomicOr(&d.c->overflow, OVF_SEEN); *(unsigned long long *)&sh[8] = ~0ULL; }
-                    else *(unsigned long long *)&sh[8] = o;
-                }
-                __syncthreads();
-                unsigned long long o = *(unsigned long long *)&sh[8];
-                __syncthreads();
-                if (o == ~0ULL) { d.done[sq] = 1; return; }
-                uint64_t *ntab = d.seen + 2 * o;
-                for (uint32_t i = tid; i < 2 * ncap; i += BS_NT) ntab[i] = 0;   // arena is not pre-zeroed
-                __syncthreads();
-                for (uint32_t i = tid; i < scap; i += BS_NT) {
-                    uint64_t k1 = stab[2 * (uint64_t)i];
-                    if (k1) seen_insert(ntab, ncap, k1, stab[2 * (uint64_t)i + 1]);
-                }
-                __syncthreads();
-                stab = ntab; scap = ncap;
-                if (tid == 0) { d.seen_off[sq] = o; d.seen_cap[sq] = ncap; }
+            unsigned long long o = *(unsigned long long *)&sh[8];
+            __syncthreads();
+            if (o == ~0ULL) { d.done[sq] = 1; return; }
+            uint64_t *ntab = d.seen + 2 * o;
+            for (uint32_t i = tid; i < 2 * ncap; i += BS_NT) ntab[i] = 0;   // arena is not pre-zeroed
+            __syncthreads();
+            for (uint32_t i = tid; i < scap; i += BS_NT) {
+                uint64_t k1 = stab[2 * (uint64_t)i];
+                if (k1) seen_insert(ntab, ncap, k1, stab[2 * (uint64_t)i + 1]);
             }
-            n_chunks++;
-            STAMP(6);   // loop head / seen growth
-            // the reference stops after the combo that brings nb_branch to max_branch; while this chunk cannot
-            // get there every new structure in it is accepted, so lookup and insert are one pass
-            const int need = d.max_branch - nb_branch;
-            const bool fused = chunk < need;
-            int isnew = 0, cd = 0;
-            uint64_t h1 = 0, h2 = 0;
-            if (tid < chunk) {
-                unsigned long long a1 = bsum[0], a2 = bsum[1];
-                long long ad = (long long)bsum[2];
-                unsigned int carry = (unsigned int)(tid + shift);
-                int klow = mprod;
-                const bool last = tid == chunk - 1;           // its combo is the next chunk's base
-                for (int k = mprod - 1; k >= 0 && carry; k--) {
-                    const unsigned int c = (unsigned int)prod_cnt[k], dg = (unsigned int)digit[k], v = dg + carry;
-                    unsigned int q = (unsigned int)((float)v * prod_rc[k]);      // v < 2^24: off by one at most
-                    int r = (int)(v - q * c);
-                    if (r < 0) { q--; r += (int)c; } else if (r >= (int)c) { q++; r -= (int)c; }
-                    carry = q;
-                    if ((unsigned)r != dg) {
-                        ad += c_dd(k, r) - c_dd(k, (int)dg); a1 += c_h1(k, r) - c_h1(k, (int)dg); a2 += c_h2(k, r) - c_h2(k, (int)dg);
+            __syncthreads();
+            stab = ntab; scap = ncap;
+            if (tid == 0) { d.seen_off[sq] = o; d.seen_cap[sq] = ncap; }
+        }
+        n_chunks++; n_combos += chunk;
+        STAMP(6);   // loop head / seen growth
+        const int need = d.max_branch - nb_branch;      // > 0
+        int b = 0, sidb = 0, cd = 0, slot = -1;
+        bool cand_new = false, last_combo = false;
+        unsigned long long idx = 0, totb = 0, h1 = 0, h2 = 0;
+        const unsigned long long pos = W + (unsigned long long)tid;
+        if (tid < chunk) {
+            int lo = 0, hi = nbeam - 1;                  // the last member whose range starts at or before pos
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (ppre[mid] <= pos) lo = mid; else hi = mid - 1; }
+            b = lo;
+            const ParentInfo pi = pinfo[b];
+            sidb = pi.sid; totb = pi.total;
+            idx = pi.cur + (pos - ppre[b]);
+            last_combo = idx == totb - 1;
+            // combo idx = combo 0 with the digits of idx (mixed radix over the regions with a choice, last
+            // region fastest) swapped in
+            unsigned long long a1 = pi.h1, a2 = pi.h2, rest = idx;
+            int ad = pi.dcal0;
+            auto divmod = [&](unsigned int c, unsigned int &r) {
+                if (rest < (1ULL << 24)) {
+                    const unsigned int v = (unsigned int)rest;
+                    unsigned int q = (unsigned int)((float)v * __frcp_rn((float)c));       // off by one at most
+                    int rr = (int)(v - q * c);
+                    if (rr < 0) { q--; rr += (int)c; } else if (rr >= (int)c) { q++; rr -= (int)c; }
+                    r = (unsigned int)rr; rest = q;
+                } else { const unsigned long long q = rest / c; r = (unsigned int)(rest - q * c); rest = q; }
+            };
+            if (pi.rl0 >= 0) {
+                int j = pi.nrl - 1;
+                // up to four changed digits are located first and their candidates loaded together
+                const Cand *pn0 = nullptr, *pn1 = nullptr, *pn2 = nullptr, *pn3 = nullptr, *po0 = nullptr, *po1 = nullptr, *po2 = nullptr, *po3 = nullptr;
+                auto next = [&](const Cand *&pn, const Cand *&po) {
+                    while (j >= 0 && rest) {
+                        unsigned int r;
+                        divmod((unsigned int)rl_cnt[pi.rl0 + j], r);
+                        j--;
+                        if (r) { po = &d.cand[rl_off[pi.rl0 + j + 1]]; pn = po + r; return; }
                     }
-                    if (last) { dnew[k] = r; klow = k; }
+                };
+                next(pn0, po0); next(pn1, po1); next(pn2, po2); next(pn3, po3);
+                if (pn0) { ad += pn0->ddcal - po0->ddcal; a1 += pn0->h1 - po0->h1; a2 += pn0->h2 - po0->h2; }
+                if (pn1) { ad += pn1->ddcal - po1->ddcal; a1 += pn1->h1 - po1->h1; a2 += pn1->h2 - po1->h2; }
+                if (pn2) { ad += pn2->ddcal - po2->ddcal; a1 += pn2->h1 - po2->h1; a2 += pn2->h2 - po2->h2; }
+                if (pn3) { ad += pn3->ddcal - po3->ddcal; a1 += pn3->h1 - po3->h1; a2 += pn3->h2 - po3->h2; }
+                while (j >= 0 && rest) {
+                    const Cand *pn = nullptr, *po = nullptr;
+                    next(pn, po);
+                    if (pn) { ad += pn->ddcal - po->ddcal; a1 += pn->h1 - po->h1; a2 += pn->h2 - po->h2; }
                 }
-                if (last) { sh[20] = klow; bsum[56] = a1; bsum[57] = a2; bsum[58] = (unsigned long long)ad; }
-                h1 = ph1 + a1; h2 = ph2 + a2; cd = par_dcal + (int)ad;
-                if (h1 == 0) h1 = 1;
-                if (h2 == 0) h2 = 1;
-                isnew = fused ? (seen_insert_new(stab, scap, h1, h2) ? 1 : 0) : (seen_lookup(stab, scap, h1, h2) ? 0 : 1);
+            } else {
+                // region list not resident in LDS (more than RL_CAP regions with a choice in this beam)
+                for (int j = pi.nprod - 1; j >= 0 && rest; j--) {
+                    const ProdEnt pe = d.prod[pi.prod + j];
+                    if (pe.cnt < 2) continue;
+                    unsigned int r;
+                    divmod(pe.cnt, r);
+                    if (r) { const Cand *po = &d.cand[pe.off], *pn = po + r; ad += pn->ddcal - po->ddcal; a1 += pn->h1 - po->h1; a2 += pn->h2 - po->h2; }
+                }
             }
-            STAMP(8);   // carry decode + seen lookups (thread 0's share)
-            const unsigned long long bal = __ballot(isnew != 0);
-            if (lane == 0) sh[wv] = __popcll(bal);
-            __syncthreads();                                   // S1
-            int ex = __popcll(bal & ((1ULL << lane) - 1)), tot = 0;
-            for (int w = 0; w < BS_NT / 64; w++) { const int t = sh[w]; if (w < wv) ex += t; tot += t; }
-            const bool hit = tot >= need;                      // never in a fused chunk
-            if (isnew && ex < need) {
-                const int ci2 = nchild + ex;
-                if (ci2 < d.ch_cap) {
-                    d.ch_parent[chb + ci2] = (uint16_t)b;
-                    d.ch_combo[chb + ci2] = cur + tid;
-                    d.ch_dcal[chb + ci2] = cd;
-                    d.ch_h[2 * (chb + ci2)] = h1;
-                    d.ch_h[2 * (chb + ci2) + 1] = h2;
-                } else atomicOr(&d.c->overflow, OVF_SORT);
-                if (!fused) seen_insert(stab, scap, h1, h2);
-                if (hit && ex == need - 1) { d.st_cursor[sid] = cur + tid + 1; d.st_total[sid] = total; }   // walk stops here
-            }
-            STAMP(9);
-            const int acc = hit ? need : tot;
-            nchild += acc; nb_branch += acc; scnt += acc;
-            if (hit) { hit_done = true; __syncthreads(); break; }
-            cur += chunk;
-            if (cur < total) {                                 // adopt the last combo as the new base
-                const int klow = sh[20];
-                for (int k = klow + tid; k < mprod; k += BS_NT) digit[k] = dnew[k];
-                if (tid == 0) { bsum[0] = bsum[56]; bsum[1] = bsum[57]; bsum[2] = bsum[58]; }
-                shift = 1;
-            }
-            __syncthreads();                                   // S2
-            STAMP(10);  // child records + seen insert
+            h1 = a1 ? a1 : 1; h2 = a2 ? a2 : 1; cd = ad;
+            wk_h1[tid] = h1; wk_h2[tid] = h2;
+            cand_new = !seen_lookup(stab, scap, h1, h2);
         }
-        if (tid == 0 && !hit_done) { d.st_cursor[sid] = cur; d.st_total[sid] = total; }
+        // the same structure can come from several parents of this chunk: its first position wins (`seen` order)
+        if (cand_new) {
+            unsigned int sl = (unsigned int)(h1 ^ (h1 >> 32)) & (2 * BS_NT - 1);
+            for (;;) {
+                const unsigned int old = atomicCAS(&wk_tab[sl], 0u, (unsigned int)tid + 1u);
+                if (old == 0) break;
+                if (wk_h1[old - 1] == h1 && wk_h2[old - 1] == h2) { atomicMin(&wk_tab[sl], (unsigned int)tid + 1u); break; }
+                sl = (sl + 1) & (2 * BS_NT - 1);
+            }
+            slot = (int)sl;
+        }
+        STAMP(8);   // decode + seen lookups
+        __syncthreads();
+        const bool isnew = cand_new && wk_tab[slot < 0 ? 0 : slot] == (unsigned int)tid + 1u;
+        const unsigned long long bal = __ballot(isnew);
+        if (lane == 0) sh[wv] = __popcll(bal);
+        __syncthreads();
+        int ex = __popcll(bal & ((1ULL << lane) - 1)), tot = 0;
+        for (int w = 0; w < BS_NT / 64; w++) { const int t = sh[w]; if (w < wv) ex += t; tot += t; }
+        const bool hit = tot >= need;
+        const bool accepted = isnew && ex < need;
+        if (accepted) {
+            const int ci2 = nchild + ex;
+            if (ci2 < d.ch_cap) {
+                d.ch_parent[chb + ci2] = (uint16_t)b;
+                d.ch_combo[chb + ci2] = idx;
+                d.ch_dcal[chb + ci2] = cd;
+                d.ch_h[2 * (chb + ci2)] = h1;
+                d.ch_h[2 * (chb + ci2) + 1] = h2;
+            } else atomicOr(&d.c->overflow, OVF_SORT);
+            seen_insert(stab, scap, h1, h2);
+        }
+        STAMP(9);
+        if (hit) {
+            // the reference stops walking after the combo that brings nb_branch to max_branch
+            if (accepted && ex == need - 1) {
+                sh[21] = b; *(unsigned long long *)&sh[22] = pos;
+                d.st_cursor[sidb] = idx + 1; d.st_total[sidb] = totb;
+            }
+            __syncthreads();
+            const unsigned long long hpos = *(unsigned long long *)&sh[22];
+            if (tid < chunk && last_combo && pos < hpos) { d.st_cursor[sidb] = totb; d.st_total[sidb] = totb; }
+            nchild += need; nb_branch += need; scnt += need;
+            single_from = sh[21] + 1;
+            __syncthreads();
+            break;
+        }
+        if (tid < chunk && last_combo) { d.st_cursor[sidb] = totb; d.st_total[sidb] = totb; }   // product exhausted
+        nchild += tot; nb_branch += tot; scnt += tot;
+        W += (unsigned long long)chunk;
+        for (int i = tid; i < 2 * BS_NT; i += BS_NT) wk_tab[i] = 0;
+        __syncthreads();
+        STAMP(10);  // child records + seen insert
     }
     STAMP(1);
     if (single_from < nbeam) {
@@ -1142,7 +1183,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
     {
         // only the max_stack best survive: select them exactly (radix select), then sort just those
         const int K = N < d.B ? N : d.B;
-        select_smallest_inplace<BS_NT>(skey, N, K, prod_cnt, sh);
+        select_smallest_inplace<BS_NT>(skey, N, K, rl_cnt, sh);
         int M = 2; while (M < K) M <<= 1;
         for (int i = K + tid; i < M; i += BS_NT) skey[i] = ~0ULL;
         __syncthreads();
