@@ -408,6 +408,8 @@ int Wave::setup()
     d.memo = (p.min_nrj == 0.0) ? 1 : 0;
     if (const char *e = getenv("RAFFT_NO_MEMO")) if (atoi(e)) d.memo = 0;
     if (const char *e = getenv("RAFFT_FORCE_FFT")) if (atoi(e)) d.force_fft = 1;   // tests: FFT path for short regions too
+    d.rl_cap = RL_CAP;
+    if (const char *e = getenv("RAFFT_RL_CAP")) d.rl_cap = std::max(0, std::min(atoi(e), RL_CAP));   // tests: region lists not resident in LDS
     d.beam = (int *)g.beam.p; d.beam_n = (int *)g.beam_n.p; d.done = (int *)g.done.p; d.nsteps = (int *)g.nsteps.p;
     d.ch_cap = c.ch_cap;
     d.ch_parent = (uint16_t *)g.ch_parent.p; d.ch_combo = (uint64_t *)g.ch_combo.p; d.ch_dcal = (int *)g.ch_dcal.p; d.ch_h = (uint64_t *)g.ch_h.p;

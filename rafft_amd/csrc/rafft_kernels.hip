@@ -874,7 +874,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
                     }
                     if (nn <= G) {           // the usual case, one round: the region list straight from registers
                         nm = __popcll(bal2);
-                        if (gl == 0) { const int o = atomicAdd(&sh[26], nm); rl0 = o + nm <= RL_CAP ? o : -1; }
+                        if (gl == 0) { const int o = atomicAdd(&sh[26], nm); rl0 = o + nm <= d.rl_cap ? o : -1; }
                         rl0 = __shfl(rl0, grp * G, 64);
                         if (cnt >= 2 && rl0 >= 0) { const int sl = rl0 + __popcll(bal2 & lt); rl_cnt[sl] = cnt; rl_off[sl] = coff; }
                     } else nm += __popcll(bal2);
@@ -893,7 +893,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
             }
             if (resumed || (!resumed && wpos > 0 && rl0 < 0 && nm > 0 && d.st_nnodes[sid] > G)) {
                 // region list from the productive-region list in global memory
-                if (gl == 0) { const int o = atomicAdd(&sh[26], nm); rl0 = o + nm <= RL_CAP ? o : -1; }
+                if (gl == 0) { const int o = atomicAdd(&sh[26], nm); rl0 = o + nm <= d.rl_cap ? o : -1; }
                 rl0 = __shfl(rl0, grp * G, 64);
                 int w = 0;
                 if (rl0 >= 0)

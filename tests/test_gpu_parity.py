@@ -136,6 +136,22 @@ def test_gpu_fft_and_direct_correlation_agree(monkeypatch, node_records):
         assert as_lists(t1) == as_lists(t2)
 
 
+def test_gpu_beam_region_lists_not_resident(monkeypatch):
+    """the beam step keeps every member's regions-with-a-choice in LDS; members that do not fit are decoded
+    from the productive-region list in HBM instead - same trajectories either way, and both equal the oracle"""
+    rng = np.random.default_rng(33)
+    seqs = ["".join(rng.choice(list("ACGU"), int(n))) for n in (70, 180, 333, 512, 900)]
+    a = rafft_amd.fold_batch(seqs, 100, 30, 200, traj=True)
+    monkeypatch.setenv("RAFFT_RL_CAP", "6")
+    b = rafft_amd.fold_batch(seqs, 100, 30, 200, traj=True)
+    monkeypatch.delenv("RAFFT_RL_CAP")
+    for s, (f1, t1), (f2, t2) in zip(seqs, a, b):
+        assert as_lists(t1) == as_lists(t2)
+        if len(s) <= 333:
+            _, o = oracle.fold(s, 100, 30, 200, traj=True)
+            assert as_lists(t1) == as_lists(o)
+
+
 @pytest.mark.parametrize("mb,ms", [(50, 50), (3, 40), (1000, 1), (17, 200)])
 def test_gpu_small_max_branch_large_beam_vs_oracle(mb, ms):
     """LDS carve-up of the beam step must hold for any (max_branch, max_stack) mix"""
