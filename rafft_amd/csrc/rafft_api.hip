@@ -155,10 +155,18 @@ int init_ctx(int device)
     memcpy(h->s.interior, t04_interior, sizeof h->s.interior);
     h->s.ml_base = T04_ML_BASE; h->s.ml_closing = T04_ML_CLOSING; h->s.ml_intern = T04_ML_INTERN;
     h->s.ninio = T04_NINIO; h->s.max_ninio = T04_MAX_NINIO; h->s.term_au = T04_TERMINAL_AU;
-    h->s.n_tri = T04_N_TRILOOPS; h->s.n_tetra = T04_N_TETRALOOPS; h->s.n_hexa = T04_N_HEXALOOPS;
-    for (int i = 0; i < T04_N_TRILOOPS; i++) { h->s.tri_key[i] = key_of(t04_triloops_seq[i], 5); h->s.tri_e[i] = t04_triloops_e[i]; }
-    for (int i = 0; i < T04_N_TETRALOOPS; i++) { h->s.tetra_key[i] = key_of(t04_tetraloops_seq[i], 6); h->s.tetra_e[i] = t04_tetraloops_e[i]; }
-    for (int i = 0; i < T04_N_HEXALOOPS; i++) { h->s.hexa_key[i] = key_of(t04_hexaloops_seq[i], 8); h->s.hexa_e[i] = t04_hexaloops_e[i]; }
+    {
+        auto put = [&](uint32_t key, int size, int e) {
+            const uint32_t k = key | sp_tag(size);
+            uint32_t sl = sp_slot(k);
+            while (h->s.sp_key[sl]) sl = (sl + 1) & 127u;
+            h->s.sp_key[sl] = k; h->s.sp_e[sl] = e;
+        };
+        static_assert(T04_N_TRILOOPS + T04_N_TETRALOOPS + T04_N_HEXALOOPS <= 64, "special hairpin table too full");
+        for (int i = 0; i < T04_N_TRILOOPS; i++) put(key_of(t04_triloops_seq[i], 5), 3, t04_triloops_e[i]);
+        for (int i = 0; i < T04_N_TETRALOOPS; i++) put(key_of(t04_tetraloops_seq[i], 6), 4, t04_tetraloops_e[i]);
+        for (int i = 0; i < T04_N_HEXALOOPS; i++) put(key_of(t04_hexaloops_seq[i], 8), 6, t04_hexaloops_e[i]);
+    }
     for (int sz = 31; sz <= RAFFT_MAX_LEN + 1; sz++) h->b.logext[sz] = (int)(T04_LXC * log(sz / 30.));
     HIPCHK(hipMalloc((void **)&g.T, sizeof(EnergyTables)));
     HIPCHK(hipMemcpy(g.T, h, sizeof(EnergyTables), hipMemcpyHostToDevice));
@@ -452,6 +460,10 @@ int Wave::setup()
         if (ws_cap < S) { if (ws_buf) HIPCHK(hipFree(ws_buf)); HIPCHK(hipMalloc((void **)&ws_buf, S * 24)); ws_cap = S; }
         HIPCHK(hipMemset(ws_buf, 0, S * 24));
         d.prof_ws = ws_buf;
+        static unsigned long long *pe_buf = nullptr;
+        if (!pe_buf) HIPCHK(hipMalloc((void **)&pe_buf, NCLS * 16 * 8));
+        HIPCHK(hipMemset(pe_buf, 0, NCLS * 16 * 8));
+        d.prof_e = pe_buf;
     }
 
 
@@ -662,6 +674,18 @@ int Wave::finish()
         rafft_seq_result &sr = out.seq[gi];
         sr.status = RAFFT_OK; sr.length = len[i]; sr.n_steps = (int)v.size(); sr.n_structs = nst;
         row += nst;
+    }
+    if (d.prof_e) {
+        unsigned long long pe[NCLS * 16];
+        HIPCHK(hipMemcpy(pe, d.prof_e, sizeof pe, hipMemcpyDeviceToHost));
+        static const char *nm[8] = {"fetch+header", "LDS fill", "FFT", "lag values", "ranking", "window_slide", "dE", "emit"};
+        for (int c = 1; c < NCLS; c++) {
+            unsigned long long t = 0;
+            for (int k = 0; k < 8; k++) t += pe[c * 16 + k];
+            fprintf(stderr, "[rafft] expand class %d phase shares (first wavefront of every workgroup, %llu Mcycles):", c, t / 1000000);
+            for (int k = 0; k < 8; k++) fprintf(stderr, " %s %.1f%%", nm[k], t ? 100.0 * (double)pe[c * 16 + k] / (double)t : 0.0);
+            fprintf(stderr, "\n");
+        }
     }
     if (d.prof_ws) {
         std::vector<unsigned long long> wsv(S * 3);

@@ -18,11 +18,12 @@ struct SmallT {
     int16_t d5[7][5], d3[7][5];
     int32_t hairpin[31], bulge[31], interior[31];
     int32_t ml_base, ml_closing, ml_intern, ninio, max_ninio, term_au;
-    int32_t n_tri, n_tetra, n_hexa;
-    uint32_t tri_key[4];   int32_t tri_e[4];
-    uint32_t tetra_key[32]; int32_t tetra_e[32];
-    uint32_t hexa_key[8];  int32_t hexa_e[8];
+    // special hairpins (tri-, tetra-, hexaloops) in one open-addressing hash table: key = 3 bits per base of
+    // the loop with its closing pair, tagged with the loop size in bits 28..; 0 = empty slot
+    uint32_t sp_key[128]; int32_t sp_e[128];
 };
+__host__ __device__ inline uint32_t sp_tag(int size) { return (uint32_t)(size == 3 ? 1 : size == 4 ? 2 : 3) << 28; }
+__host__ __device__ inline uint32_t sp_slot(uint32_t tagged) { return (tagged * 2654435761u) >> 25; }
 // Big, rarely hit tables stay in HBM/L2.
 struct BigT {
     int16_t int11[7][7][5][5];
@@ -59,19 +60,14 @@ __device__ inline int e_hairpin(const SmallT *T, const BigT *B, int size, int ty
 {
     int e = (size <= 30) ? T->hairpin[size] : T->hairpin[30] + B->logext[size];
     if (size < 3) return e;
-    if (size == 4) {
-        uint32_t k = loop_key(S, ci, 6);
-        for (int t = 0; t < T->n_tetra; t++)
-            if (T->tetra_key[t] == k) return T->tetra_e[t];
-    } else if (size == 6) {
-        uint32_t k = loop_key(S, ci, 8);
-        for (int t = 0; t < T->n_hexa; t++)
-            if (T->hexa_key[t] == k) return T->hexa_e[t];
-    } else if (size == 3) {
-        uint32_t k = loop_key(S, ci, 5);
-        for (int t = 0; t < T->n_tri; t++)
-            if (T->tri_key[t] == k) return T->tri_e[t];
-        return e + (type > 2 ? T->term_au : 0);
+    if (size == 3 || size == 4 || size == 6) {
+        const uint32_t k = loop_key(S, ci, size + 2) | sp_tag(size);
+        for (uint32_t sl = sp_slot(k);; sl = (sl + 1) & 127u) {
+            const uint32_t kk = T->sp_key[sl];
+            if (kk == k) return T->sp_e[sl];
+            if (kk == 0) break;
+        }
+        if (size == 3) return e + (type > 2 ? T->term_au : 0);
     }
     return e + T->mmH[type][S[ci + 1]][S[cj - 1]];
 }
@@ -242,6 +238,36 @@ __device__ inline int loop_energy_br(const SmallT *T, const BigT *B, const uint8
         bl.get(i, p, q);
         e += e_stem(T, pair_type(S[p], S[q]), S[p - 1], S[q + 1], false);
         u -= q - p + 1;
+    }
+    e += e_stem(T, rtype(type), S[cj - 1], S[ci + 1], false);
+    return e + T->ml_closing + u * T->ml_base;
+}
+
+// The same loop energy from prefix sums over the region's branches: pe_ext[i] / pe_ml[i] = sum of the stem
+// terms of branches < i as exterior-loop / multiloop branches, psp[i] = sum of their spans.  O(1) per loop
+// whatever the number of branches; integer sums, so identical to loop_energy_br.
+struct BrPrefix { const int *pe_ext, *pe_ml; const uint16_t *psp; };
+__device__ inline int loop_energy_pre(const SmallT *T, const BigT *B, const uint8_t *S, int L, int ci, int cj, const BrList &bl, const BrPrefix &pf)
+{
+    const int k = bl.count();
+    if (ci < 0) {
+        int e = pf.pe_ext[bl.a1] - pf.pe_ext[bl.a0] + pf.pe_ext[bl.b1] - pf.pe_ext[bl.b0];
+        if (bl.has_mid)
+            e += e_stem(T, pair_type(S[bl.mp], S[bl.mq]), bl.mp > 0 ? (int)S[bl.mp - 1] : -1, bl.mq < L - 1 ? (int)S[bl.mq + 1] : -1, true);
+        return e;
+    }
+    const int type = pair_type(S[ci], S[cj]);
+    if (k == 0) return e_hairpin(T, B, cj - ci - 1, type, S, ci, cj);
+    if (k == 1) {
+        int p, q;
+        bl.get(0, p, q);
+        return e_intloop(T, B, p - ci - 1, cj - q - 1, type, rtype(pair_type(S[p], S[q])), S[ci + 1], S[cj - 1], S[p - 1], S[q + 1]);
+    }
+    int e = pf.pe_ml[bl.a1] - pf.pe_ml[bl.a0] + pf.pe_ml[bl.b1] - pf.pe_ml[bl.b0];
+    int u = cj - ci - 1 - ((int)pf.psp[bl.a1] - (int)pf.psp[bl.a0] + (int)pf.psp[bl.b1] - (int)pf.psp[bl.b0]);
+    if (bl.has_mid) {
+        e += e_stem(T, pair_type(S[bl.mp], S[bl.mq]), S[bl.mp - 1], S[bl.mq + 1], false);
+        u -= bl.mq - bl.mp + 1;
     }
     e += e_stem(T, rtype(type), S[cj - 1], S[ci + 1], false);
     return e + T->ml_closing + u * T->ml_base;

@@ -158,6 +158,9 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
     // Work items are fetched FETCH at a time and candidate slots are reserved in slabs, so that the
     // two atomics with a returned value (a full L2 round trip each) are paid once per several regions.
     // (only when there is plenty of work: with fewer regions than workgroups every region gets its own)
+    const bool eprof = d.prof_e != nullptr && tid == 0;      // diagnostic phase stamps (RAFFT_TRACE=3)
+    unsigned long long eacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, et = eprof ? clock64() : 0;
+#define ESTAMP(k) do { if (eprof) { const unsigned long long tn_ = clock64(); eacc[k] += tn_ - et; et = tn_; } } while (0)
     const unsigned FETCH = (NT == 64 && n_items > 4u * gridDim.x) ? 4u : 1u;
     unsigned fetch_base = 0, fetch_left = 0;                 // uniform across the workgroup
     unsigned long long slab_base = 0; unsigned slab_left = 0;   // thread 0 only
@@ -177,12 +180,14 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         const int sq = d.nd_seq[nid];
         const int L = d.seq_len[sq];
         const int n = d.nd_n[nid], ci = d.nd_ci[nid], cj = d.nd_cj[nid], nbr = d.nd_nbr[nid];
+        const int par_dcal = d.nd_pdcal[nid];
         const uint16_t *posg = d.pos + d.nd_pos[nid];
         const uint32_t *brg = d.br + d.nd_br[nid];
         const uint8_t *codes = d.codes + d.seq_off[sq];
         const int m = 2 * n - 1;
         const int P = next_pow2_ge(m);
         const int logP = 31 - __clz(P);
+        ESTAMP(0);   // fetch + header
         const int Kp = d.K < m ? (d.K > 0 ? d.K : 0) : m;
 
         for (int rep_ = 0; rep_ < 1 + ((d.rep >> 4) & 1); rep_++) {
@@ -196,6 +201,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         __syncthreads();
         }
 
+        ESTAMP(1);   // LDS fill
         // ---- correlation: conv(A,U), conv(G,C), conv(G,U).
         // Regions of <= 64 positions (one wavefront holds the whole strand in 64-bit masks) use the exact
         // direct form: popcount(mask & shifted reversed mask) per lag - the analogue of scipy's own
@@ -262,6 +268,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
             }
         }
 
+        ESTAMP(2);   // FFTs
         // ---- lag values (exact integer pair counts, IEEE fp64 divide) and ranking
         double *keyv = (double *)(lds + lay.offA);
         uint16_t *lagk = (uint16_t *)(lds + lay.offA + 8 * P);
@@ -312,6 +319,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                 __syncthreads();
             }
         }
+        ESTAMP(3);   // lag values
         // When every lag is searched anyway (2n-1 <= nb_mode) the ranking only breaks dE ties
         // later on, so the sort is skipped and ties are resolved from (value, lag) directly.
         const bool sorted = (m > Kp) || d.dbg.lag != nullptr;
@@ -418,6 +426,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         __syncthreads();
         }
 
+        ESTAMP(4);   // ranking
         // ---- window_slide (rafft/rafft.py:36-83).  Small regions: one lane per ranked lag.  Big regions:
         // each diagonal is cut into C chunks handled by different lanes; a lane first walks back to the last
         // zero cell before its chunk and replays the recurrence from there (same fp64 operation order, so
@@ -565,9 +574,39 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         }
         __syncthreads();
 
+        ESTAMP(5);   // window_slide
         // ---- dE of every candidate stem: only the loops it changes, from the branch list
-        const int par_dcal = d.nd_pdcal[nid];
         const double par_e = dcal_to_energy(par_dcal);
+        // prefix sums of the branches' stem terms (region A is free now except, when nothing was ranked, the
+        // lag values at its head), so that every loop below costs O(1) whatever its number of branches
+        int *pe_ext = (int *)(lds + lay.offA + (sorted ? 0 : 8 * P));
+        int *pe_ml = pe_ext + (nbr + 1);
+        uint16_t *psp = (uint16_t *)(pe_ml + (nbr + 1));
+        if (tid < 64) {
+            int c_e = 0, c_m = 0, c_s = 0;
+            for (int base = 0; base < nbr; base += 64) {
+                const int i = base + tid;
+                int ve = 0, vm = 0, vs = 0;
+                if (i < nbr) {
+                    const uint32_t u = brl[i];
+                    const int p = (int)(u & 0xffffu), q = (int)(u >> 16);
+                    const int tt = pair_type(Sl[p], Sl[q]);
+                    if (ci < 0) ve = e_stem(T, tt, p > 0 ? (int)Sl[p - 1] : -1, q < L - 1 ? (int)Sl[q + 1] : -1, true);
+                    vm = e_stem(T, tt, p > 0 ? (int)Sl[p - 1] : 0, q < L - 1 ? (int)Sl[q + 1] : 0, false);
+                    vs = q - p + 1;
+                }
+                int xe = ve, xm = vm, xs = vs;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int ye = __shfl_up(xe, o, 64), ym = __shfl_up(xm, o, 64), ys = __shfl_up(xs, o, 64);
+                    if (tid >= o) { xe += ye; xm += ym; xs += ys; }
+                }
+                if (i < nbr) { pe_ext[i] = c_e + xe - ve; pe_ml[i] = c_m + xm - vm; psp[i] = (uint16_t)(c_s + xs - vs); }
+                c_e += __shfl(xe, 63, 64); c_m += __shfl(xm, 63, 64); c_s += __shfl(xs, 63, 64);
+            }
+            if (tid == 0) { pe_ext[nbr] = c_e; pe_ml[nbr] = c_m; psp[nbr] = (uint16_t)c_s; }
+        }
+        __syncthreads();
+        const BrPrefix pf{pe_ext, pe_ml, psp};
         for (int rep_ = 0; rep_ < 1 + ((d.rep >> 3) & 1); rep_++)
             for (int r = tid; r < Kp; r += NT) {
                 const int nb = wnb[r];
@@ -577,13 +616,13 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                     const int mi = wmi[r], mj = wmj[r];
                     const int a0 = pos[mi], b0 = pos[mj], ao = pos[mi - nb + 1], bo = pos[mj + nb - 1];
                     BrList all{brl, 0, nbr, 0, 0, 0, 0, 0};
-                    const int e_old = loop_energy_br(T, B, Sl, L, ci, cj, all);
+                    const int e_old = loop_energy_pre(T, B, Sl, L, ci, cj, all, pf);
                     int lo = br_lower(brl, nbr, a0), hi = br_lower(brl, nbr, b0);
                     const int lo_o = br_lower(brl, nbr, ao), hi_o = br_lower(brl, nbr, bo);
                     BrList outer{brl, 0, lo_o, hi_o, nbr, 1, ao, bo};
-                    int e_new = loop_energy_br(T, B, Sl, L, ci, cj, outer);
+                    int e_new = loop_energy_pre(T, B, Sl, L, ci, cj, outer, pf);
                     BrList inner{brl, lo, hi, 0, 0, 0, 0, 0};
-                    e_new += loop_energy_br(T, B, Sl, L, a0, b0, inner);
+                    e_new += loop_energy_pre(T, B, Sl, L, a0, b0, inner, pf);
                     int pa = a0, pb = b0;
                     for (int t = 1; t < nb; t++) {
                         const int a = pos[mi - t], b = pos[mj + t];
@@ -592,7 +631,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                         else {
                             const int lo2 = br_lower(brl, nbr, a), hi2 = br_lower(brl, nbr, b);
                             BrList mid{brl, lo2, lo, hi, hi2, 1, pa, pb};
-                            e_new += loop_energy_br(T, B, Sl, L, a, b, mid);
+                            e_new += loop_energy_pre(T, B, Sl, L, a, b, mid, pf);
                             lo = lo2; hi = hi2;
                         }
                         pa = a; pb = b;
@@ -607,6 +646,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
             }
         __syncthreads();
 
+        ESTAMP(6);   // dE
         // ---- stable sort of the kept candidates by dE (ties keep lag-rank order), emit
         // compact the kept lags (keep[] becomes the list of their indices)
         int nkept = 0;
@@ -699,7 +739,10 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
             d.nd_ncand[nid] = ovf ? 0 : nkept;
             if (d.dbg.n_ranked) d.dbg.n_ranked[1] = nkept;
         }
+        ESTAMP(7);   // emit
     }
+    if (eprof) for (int k = 0; k < 8; k++) atomicAdd(&d.prof_e[cls * 16 + k], eacc[k]);
+#undef ESTAMP
     if (tid == 0 && st_items) {
         atomicAdd(&d.c->n_expand, st_items);
         atomicAdd(&d.c->sum_n, st_n);
