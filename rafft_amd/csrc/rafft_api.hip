@@ -679,6 +679,14 @@ int Wave::finish()
         unsigned long long pe[NCLS * 16];
         HIPCHK(hipMemcpy(pe, d.prof_e, sizeof pe, hipMemcpyDeviceToHost));
         static const char *nm[8] = {"fetch+header", "LDS fill", "FFT", "lag values", "ranking", "window_slide", "dE", "emit"};
+        {
+            static const char *mn[7] = {"header+list+digits", "pass 1 (sizes)", "allocation", "parent row", "pass 2 descriptors", "region copies", "row out"};
+            unsigned long long t = 0;
+            for (int k = 0; k < 7; k++) t += pe[k];
+            fprintf(stderr, "[rafft] materialize phase shares (%llu Mcycles):", t / 1000000);
+            for (int k = 0; k < 7; k++) fprintf(stderr, " %s %.1f%%", mn[k], t ? 100.0 * (double)pe[k] / (double)t : 0.0);
+            fprintf(stderr, "\n");
+        }
         for (int c = 1; c < NCLS; c++) {
             unsigned long long t = 0;
             for (int k = 0; k < 8; k++) t += pe[c * 16 + k];

@@ -22,6 +22,7 @@ struct SmallT {
     // the loop with its closing pair, tagged with the loop size in bits 28..; 0 = empty slot
     uint32_t sp_key[128]; int32_t sp_e[128];
 };
+static_assert(sizeof(SmallT) % 16 == 0, "SmallT is copied to LDS in 16-byte pieces");
 __host__ __device__ inline uint32_t sp_tag(int size) { return (uint32_t)(size == 3 ? 1 : size == 4 ? 2 : 3) << 28; }
 __host__ __device__ inline uint32_t sp_slot(uint32_t tagged) { return (tagged * 2654435761u) >> 25; }
 // Big, rarely hit tables stay in HBM/L2.

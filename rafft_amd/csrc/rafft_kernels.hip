@@ -1336,6 +1336,10 @@ __global__ __launch_bounds__(MAT_NT) void materialize_kernel(Dev d)
     __shared__ unsigned long long sh64[4];
     __shared__ int shi[8];
     const int tid = threadIdx.x;
+    // diagnostic phase stamps (RAFFT_TRACE=3) of every 64th workgroup, kept in the slots of class 0
+    const bool mprof = d.prof_e != nullptr && tid == 0 && (blockIdx.x & 63) == 0;
+    unsigned long long mt = mprof ? clock64() : 0, macc[7] = {0, 0, 0, 0, 0, 0, 0};
+#define MSTAMP(k) do { if (mprof) { const unsigned long long tn_ = clock64(); macc[k] += tn_ - mt; mt = tn_; } } while (0)
     const int sid = d.mat[blockIdx.x];
     const int par = d.st_parent[sid];
     const int sq = d.st_seq[sid];
@@ -1349,16 +1353,24 @@ __global__ __launch_bounds__(MAT_NT) void materialize_kernel(Dev d)
         for (int k = tid; k < mprod; k += MAT_NT) { prod_node[k] = pl[k].node; prod_cnt[k] = (int)pl[k].cnt; }
     }
     __syncthreads();
-    if (tid == 0) {
+    for (int k = tid; k < mprod; k += MAT_NT) sel[k] = 0;
+    __syncthreads();
+    if (tid == 0) {      // digits of the combo, last region fastest; high digits of a small index stay 0
         unsigned long long idx = d.st_combo[sid];
-        for (int k = mprod - 1; k >= 0; k--) {
-            unsigned long long c = (unsigned long long)prod_cnt[k], q = idx / c;
-            sel[k] = (int)(idx - q * c);
-            idx = q;
+        for (int k = mprod - 1; k >= 0 && idx; k--) {
+            const unsigned int c = (unsigned int)prod_cnt[k];
+            if (idx < (1ULL << 24)) {
+                const unsigned int v = (unsigned int)idx;
+                unsigned int q = (unsigned int)((float)v * __frcp_rn((float)c));       // off by one at most
+                int r = (int)(v - q * c);
+                if (r < 0) { q--; r += (int)c; } else if (r >= (int)c) { q++; r -= (int)c; }
+                sel[k] = r; idx = q;
+            } else { const unsigned long long q = idx / c; sel[k] = (int)(idx - q * c); idx = q; }
         }
     }
     __syncthreads();
 
+    MSTAMP(0);   // header, productive-region list, combo digits
     // pass 1: sizes
     int tot_nodes = 0, tot_pos = 0, tot_br = 0;
     for (int base = 0; base < mprod; base += MAT_NT) {
@@ -1384,6 +1396,7 @@ __global__ __launch_bounds__(MAT_NT) void materialize_kernel(Dev d)
         }
         tot_nodes += nnod; tot_pos += npos; tot_br += nbrr;
     }
+    MSTAMP(1);   // pass 1
     if (tid == 0) {
         // bump allocation from one of NSHARD sub-arenas (spreads the same-address atomics)
         const int shd = blockIdx.x & (NSHARD - 1);
@@ -1406,11 +1419,13 @@ __global__ __launch_bounds__(MAT_NT) void materialize_kernel(Dev d)
     if (!shi[0]) { if (tid == 0) { d.st_nnodes[sid] = 0; d.st_node0[sid] = 0; d.st_db[sid] = 0; } return; }
     const unsigned long long nbase = sh64[0], pbase = sh64[1], tbase = sh64[2], bbase = sh64[3];
 
+    MSTAMP(2);   // allocation
     // dot-bracket row: parent's row + the stems (rafft/rafft.py:97,127-128)
     const uint8_t *pdb = d.db + d.st_db[par];
     for (int x = tid; x < L; x += MAT_NT) sdb[x] = pdb[x];
     __syncthreads();
 
+    MSTAMP(3);   // parent's dot-bracket row
     // pass 2: per tile descriptors, prefix, copy
     int run_nodes = 0, run_pos = 0, run_br = 0;
     for (int base = 0; base < mprod; base += MAT_NT) {
@@ -1440,6 +1455,7 @@ __global__ __launch_bounds__(MAT_NT) void materialize_kernel(Dev d)
         const int tn = __shfl(xn, 63, 64), tp = __shfl(xp, 63, 64), tb = __shfl(xb, 63, 64);
         k_node[tid] = run_nodes + xn - nnod; k_pos[tid] = run_pos + xp - npos; k_br[tid] = run_br + xb - nbrr;
         __syncthreads();
+        MSTAMP(4);   // pass 2 descriptors
         const int kt = mprod - base < MAT_NT ? mprod - base : MAT_NT;
         for (int kk = 0; kk < kt; kk++) {
             const int pn = prod_node[base + kk];
@@ -1483,10 +1499,14 @@ __global__ __launch_bounds__(MAT_NT) void materialize_kernel(Dev d)
         }
         run_nodes += tn; run_pos += tp; run_br += tb;
         __syncthreads();
+        MSTAMP(5);   // region copies
     }
     uint8_t *odb = d.db + tbase;
     for (int x = tid; x < L; x += MAT_NT) odb[x] = sdb[x];
     if (tid == 0) { d.st_node0[sid] = (int)nbase; d.st_nnodes[sid] = tot_nodes; d.st_db[sid] = tbase; }
+    MSTAMP(6);   // row out
+    if (mprof) for (int k = 0; k < 7; k++) atomicAdd(&d.prof_e[k], macc[k]);
+#undef MSTAMP
 }
 
 // ------------------------------------------------------------ dedupe kernel
