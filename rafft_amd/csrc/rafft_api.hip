@@ -241,6 +241,14 @@ hipEvent_t next_event(Workspace &w)
 
 struct Span { hipEvent_t a, b; int kind; };
 
+// base codes of rafft/utils.py:73-80 (N=0 A=1 C=2 G=3 U=4); bit 3 marks a character outside "AGCUN"
+struct BaseCodeTable {
+    uint8_t v[256];
+    BaseCodeTable() { for (int i = 0; i < 256; i++) v[i] = 8; v['N'] = 0; v['A'] = 1; v['C'] = 2; v['G'] = 3; v['U'] = 4; }
+    uint8_t operator[](unsigned char c) const { return v[c]; }
+};
+static const BaseCodeTable kBaseCode;
+
 struct Caps {
     size_t st, nd, pos, br, db, cand, seen, trec, tsid, work, mat, looptab;
     int ch_cap, sort_cap;
@@ -375,11 +383,12 @@ int Wave::setup()
     sumL = 0;
     for (size_t i = 0; i < S; i++) { off[i] = (int)sumL; len[i] = seqs[i].len; sumL += seqs[i].len; }
     std::vector<uint8_t> codes(sumL + 16, 0);
-    for (size_t i = 0; i < S; i++)
-        for (int x = 0; x < seqs[i].len; x++) {
-            char ch = seqs[i].s[x];
-            codes[off[i] + x] = ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : ch == 'U' ? 4 : 0;
-        }
+    for (size_t i = 0; i < S; i++) {
+        const unsigned char *src = (const unsigned char *)seqs[i].s;
+        uint8_t *dst = codes.data() + off[i];
+        for (int x = 0; x < seqs[i].len; x++) dst[x] = kBaseCode[src[x]] & 7;
+    }
+    const double ms_enc = since(tw0);
     int maxL = 0;
     for (size_t i = 0; i < S; i++) maxL = std::max(maxL, len[i]);
     if (int rc = class_cfg(p.nb_mode, maxL, cf)) return rc;
@@ -467,6 +476,7 @@ int Wave::setup()
     }
 
 
+    const double ms_plan = since(tw0);
     hipStream_t st = g.stream;
     HIPCHK(hipMemcpyAsync(g.codes.p, codes.data(), sumL + 16, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(g.seq_off.p, off.data(), S * 4, hipMemcpyHostToDevice, st));
@@ -486,6 +496,7 @@ int Wave::setup()
     }
     n_active = (unsigned)S;
     ms_setup = since(tw0);
+    if (getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] setup: encode %.3f ms, plan+buffers %.3f ms, copies+init %.3f ms\n", ms_enc, ms_plan - ms_enc, ms_setup - ms_plan);
     tw1 = std::chrono::steady_clock::now();
     return 0;
 }
@@ -612,29 +623,31 @@ int Wave::finish()
     }
 
 
+    const double tl_stats = since(tw2);
     // ---- gather the trajectory records and format rows on the device
     std::vector<int4> trec(hc.trec_n);
     if (hc.trec_n) HIPCHK(hipMemcpy(trec.data(), g.trec.p, hc.trec_n * sizeof(int4), hipMemcpyDeviceToHost));
-    std::vector<int> tsid(hc.tsid_top);
-    if (hc.tsid_top) HIPCHK(hipMemcpy(tsid.data(), g.tsid.p, hc.tsid_top * 4, hipMemcpyDeviceToHost));
-    std::vector<std::vector<int4>> per(S);
-    for (auto &r : trec) per[r.x].push_back(r);
-    std::vector<int> row_sid;
-    std::vector<long long> row_off;
-    std::vector<long long> seq_db_off(S);
+    // records in (sequence, step) order; rows are laid out record after record
+    std::sort(trec.begin(), trec.end(), [](const int4 &a, const int4 &b) { return a.x != b.x ? a.x < b.x : a.y < b.y; });
+    std::vector<OutRec> recs(trec.size());
+    std::vector<long long> seq_db_off(S, 0);
+    std::vector<int> seq_row0(S, 0), seq_rec0(S + 1, 0);
     long long tot_bytes = 0;
-    for (size_t i = 0; i < S; i++) {
-        auto &v = per[i];
-        std::sort(v.begin(), v.end(), [](const int4 &a, const int4 &b) { return a.y < b.y; });
-        seq_db_off[i] = tot_bytes;
-        for (auto &r : v)
-            for (int k = 0; k < r.z; k++) {
-                row_sid.push_back(tsid[r.w + k]);
-                row_off.push_back(tot_bytes);
-                tot_bytes += len[i] + 1;
+    size_t nrows = 0;
+    {
+        size_t ri = 0;
+        for (size_t i = 0; i < S; i++) {
+            seq_db_off[i] = tot_bytes; seq_row0[i] = (int)nrows; seq_rec0[i] = (int)ri;
+            for (; ri < trec.size() && (size_t)trec[ri].x == i; ri++) {
+                const int4 &r = trec[ri];
+                recs[ri] = OutRec{tot_bytes, (int)nrows, r.w, r.z, len[i]};
+                tot_bytes += (long long)r.z * (len[i] + 1);
+                nrows += (size_t)r.z;
             }
+        }
+        seq_rec0[S] = (int)ri;
     }
-    const size_t nrows = row_sid.size();
+    const double tl_gather = since(tw2);
     const size_t dcal_off = ((size_t)tot_bytes + 63) & ~(size_t)63;
     PinBuf chunk = pin_acquire(dcal_off + nrows * 4 + 64);
     if (!chunk.p) return fail(RAFFT_ERR_HIP, "hipHostMalloc failed for the result buffer");
@@ -642,17 +655,15 @@ int Wave::finish()
     char *all_db = (char *)chunk.p;
     int *all_dcal = (int *)((char *)chunk.p + dcal_off);
     if (nrows) {
-        if (int rc = ensure(g.row_sid, nrows * 4)) return rc;
-        if (int rc = ensure(g.row_off, nrows * 8)) return rc;
+        if (int rc = ensure(g.row_off, recs.size() * sizeof(OutRec))) return rc;
         if (int rc = ensure(g.out_db, (size_t)tot_bytes)) return rc;
         if (int rc = ensure(g.out_dcal, nrows * 4)) return rc;
-        HIPCHK(hipMemcpyAsync(g.row_sid.p, row_sid.data(), nrows * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(g.row_off.p, row_off.data(), nrows * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(g.row_off.p, recs.data(), recs.size() * sizeof(OutRec), hipMemcpyHostToDevice, st));
         Span sp{next_event(), next_event(), 3};
         HIPCHK(hipEventRecord(sp.a, st));
         unsigned grid = (unsigned)std::min<size_t>(nrows, 65536);
-        hipLaunchKernelGGL(output_kernel, dim3(grid), dim3(64), 0, st, d, (int)nrows, (const int *)g.row_sid.p,
-                           (const long long *)g.row_off.p, (char *)g.out_db.p, (int *)g.out_dcal.p);
+        hipLaunchKernelGGL(output_kernel, dim3(grid), dim3(64), 0, st, d, (int)nrows, (int)recs.size(), (const OutRec *)g.row_off.p,
+                           (char *)g.out_db.p, (int *)g.out_dcal.p);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(sp.b, st));
         spans.push_back(sp);
@@ -660,20 +671,19 @@ int Wave::finish()
         HIPCHK(hipMemcpyAsync(all_dcal, g.out_dcal.p, nrows * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
     }
-    size_t row = 0;
+    const double tl_copy = since(tw2);
     for (size_t i = 0; i < S; i++) {
         int gi = seqs[i].idx;
-        auto &v = per[i];
-        int nst = 0;
-        for (auto &r : v) nst += r.z;
-        out.step_size[gi].clear(); out.step_off[gi].clear();
+        const int r0 = seq_rec0[i], r1 = seq_rec0[i + 1];
+        auto &ss = out.step_size[gi];
+        auto &so = out.step_off[gi];
+        ss.resize(r1 - r0); so.resize(r1 - r0);
         int o = 0;
-        for (auto &r : v) { out.step_size[gi].push_back(r.z); out.step_off[gi].push_back(o); o += r.z; }
-        out.dcal_ptr[gi] = all_dcal + row;
+        for (int r = r0; r < r1; r++) { ss[r - r0] = recs[r].cnt; so[r - r0] = o; o += recs[r].cnt; }
+        out.dcal_ptr[gi] = all_dcal + seq_row0[i];
         out.db_ptr[gi] = all_db + seq_db_off[i];
         rafft_seq_result &sr = out.seq[gi];
-        sr.status = RAFFT_OK; sr.length = len[i]; sr.n_steps = (int)v.size(); sr.n_structs = nst;
-        row += nst;
+        sr.status = RAFFT_OK; sr.length = len[i]; sr.n_steps = r1 - r0; sr.n_structs = o;
     }
     if (d.prof_e) {
         unsigned long long pe[NCLS * 16];
@@ -727,7 +737,8 @@ int Wave::finish()
                 br.first, (unsigned long long)d.br_shard_cap, br.second, db.first, (unsigned long long)d.db_shard_cap,
                 ca.first, (unsigned long long)d.cand_shard_cap, ca.second, pr.first, (unsigned long long)d.prod_shard_cap, hc.seen_top, c.seen, est);
     }
-    if (getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] wave S=%zu setup %.2f ms, loop %.2f ms (%d steps), tail %.2f ms\n", S, ms_setup, ms_loop, steps, since(tw2));
+    if (getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] wave S=%zu setup %.2f ms, loop %.2f ms (%d steps), tail %.2f ms (counters %.3f, records+gather %.3f, rows out %.3f incl. %.1f MB D2H)\n",
+                                       S, ms_setup, ms_loop, steps, since(tw2), tl_stats, tl_gather - tl_stats, tl_copy - tl_gather, (double)tot_bytes / 1e6);
     return result = 0;
 }
 
@@ -864,12 +875,10 @@ int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs, 
         memset(&sr, 0, sizeof sr);
         sr.length = L;
         if (L == 0) { sr.status = RAFFT_ERR_EMPTY; continue; }
-        bool ok = true;
-        for (int x = 0; x < L && ok; x++) {
-            char ch = seqs[i][x];
-            ok = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'U' || ch == 'N';
-        }
-        if (!ok) { sr.status = RAFFT_ERR_BAD_CHAR; continue; }
+        unsigned bad = 0;
+        const unsigned char *sp_ = (const unsigned char *)seqs[i];
+        for (int x = 0; x < L; x++) bad |= kBaseCode[sp_[x]];
+        if (bad & 8) { sr.status = RAFFT_ERR_BAD_CHAR; continue; }
         if (L > RAFFT_MAX_LEN) { sr.status = RAFFT_ERR_TOO_LONG; continue; }
         good.push_back({seqs[i], L, i});
     }

@@ -1620,13 +1620,20 @@ __global__ void init_roots_kernel(Dev d)
 
 // ----------------------------------------------------------- output kernel
 
-__global__ void output_kernel(Dev d, int nrows, const int *row_sid, const long long *row_off, char *out_db, int *out_dcal)
+// One record = the beam of one sequence at one step (all of them with traj, the last one otherwise); its rows
+// go out back to back, `off` bytes into the result buffer, row numbers from `row0`.
+struct OutRec { long long off; int row0, w, cnt, L; };
+__global__ void output_kernel(Dev d, int nrows, int nrec, const OutRec *recs, char *out_db, int *out_dcal)
 {
     for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
-        const int sid = row_sid[r];
-        const int L = d.seq_len[d.st_seq[sid]];
+        int lo = 0, hi = nrec - 1;                      // record holding row r
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (recs[mid].row0 <= r) lo = mid; else hi = mid - 1; }
+        const OutRec rc = recs[lo];
+        const int k = r - rc.row0;
+        const int sid = d.tsid[rc.w + k];
+        const int L = rc.L;
         const uint8_t *db = d.db + d.st_db[sid];
-        char *o = out_db + row_off[r];
+        char *o = out_db + rc.off + (long long)k * (L + 1);
         for (int x = threadIdx.x; x < L; x += blockDim.x) o[x] = (char)db[x];
         if (threadIdx.x == 0) { o[L] = 0; out_dcal[r] = d.st_dcal[sid]; }
     }
