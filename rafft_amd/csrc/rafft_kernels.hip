@@ -196,7 +196,10 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
             pos[t] = (uint16_t)p;
             code[t] = codes[p];
         }
-        for (int x = tid; x < L; x += NT) Sl[x] = codes[x];
+        {   // bases: only the span of this loop is ever looked at (closing pair, its neighbours inside, branches)
+            const int x0 = ci < 0 ? 0 : ci, x1 = ci < 0 ? L : cj + 1;
+            for (int x = x0 + tid; x < x1; x += NT) Sl[x] = codes[x];
+        }
         for (int t = tid; t < nbr; t += NT) brl[t] = brg[t];
         __syncthreads();
         }
