@@ -28,6 +28,9 @@ _OPTIONS = [
     (("-au", "--au_wei"), dict(type=float, default=2.0, help="AU weight")),
     (("-gu", "--gu_wei"), dict(type=float, default=1.0, help="GU weight")),
     (("--batch",), dict(action="store_true", help="every FASTA record / line of -sf is its own sequence (one GPU batch)")),
+    (("--sidecar",), dict(help="with --traj: also write the fast-folding graph as a binary side-car (exact dcal energies,\n"
+                               "no strings to re-parse) that `rafft_kin --sidecar` reads; with several sequences the\n"
+                               "files are <SIDECAR>.0, <SIDECAR>.1, ...")),
 ]
 
 
@@ -89,8 +92,11 @@ def main(argv=None, fold_batch=None):
         from .rafft import fold_batch
     results = fold_batch(seqs, args.n_mode, args.max_stack, args.max_branch, args.min_hp, args.min_nrj, args.traj,
                          args.temp, args.gc_wei, args.au_wei, args.gu_wei)
-    for s, r in zip(seqs, results):
+    for k, (s, r) in enumerate(zip(seqs, results)):
         print(format_result(s, r, args))
+        if args.sidecar and args.traj:
+            from .utils import write_sidecar
+            write_sidecar(args.sidecar if len(seqs) == 1 else f"{args.sidecar}.{k}", s, r[1])
 
 
 if __name__ == '__main__':

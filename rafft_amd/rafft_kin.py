@@ -91,9 +91,12 @@ def kinetics(fast_paths, max_time, n_steps, initial_pop=None):
 def main(argv=None):
     """bin/rafft_kin (bin/rafft_kin:15-55) without the matplotlib plot."""
     import argparse
-    from .utils import parse_rafft_output
+    from .utils import parse_rafft_output, read_sidecar
     parser = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawTextHelpFormatter)
-    parser.add_argument('rafft_out', help="rafft_output")
+    parser.add_argument('rafft_out', help="rafft_output (the --traj text, or the binary side-car with --sidecar)")
+    parser.add_argument('--sidecar', action="store_true", help="rafft_out is the binary side-car written by `rafft --traj --sidecar`")
+    parser.add_argument('--exact', action="store_true", help="with --sidecar: use the exact energies instead of the one decimal\n"
+                                                             "of the text format (changes the populations: rates are exponential in the energy)")
     parser.add_argument('--n_steps', '-ns', help="integration steps", type=int, default=100)
     parser.add_argument('--init_pop', '-ip', help="initialization of the population <POS>:<WEI>", nargs="*")
     parser.add_argument('--max_time', '-mt', help="max time (exp scale)", type=float, default=30)
@@ -101,7 +104,10 @@ def main(argv=None):
     init_population = None
     if args.init_pop is not None:     # the reference crashes here (None += ...); we accept the documented syntax
         init_population = [(int(el.split(":")[0]), float(el.split(":")[1])) for el in args.init_pop]
-    fast_paths, seq = parse_rafft_output(args.rafft_out)
+    if args.sidecar:
+        fast_paths, seq = read_sidecar(args.rafft_out, text_energies=not args.exact)
+    else:
+        fast_paths, seq = parse_rafft_output(args.rafft_out)
     trajectory, times, struct_list, equi_pop = kinetics(fast_paths, args.max_time, args.n_steps, init_population)
     equi_pop.sort(key=lambda el: el[2])
     for st, nrj, fp, si in equi_pop:

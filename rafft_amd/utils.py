@@ -91,3 +91,61 @@ def format_trajectory(sequence, trajectory):
         out.append("# {:-^20}".format(si))
         out.extend(f"{s.str_struct} {s.energy:6.1f}" for s in step)
     return "\n".join(out) + "\n"
+
+
+# ---- binary side-car of the fast-folding graph ---------------------
+# The `--traj` text (bin/rafft:73-79) prints energies with one decimal, so a reader of the text loses the
+# exact dcal values and has to re-parse every dot-bracket string.  The side-car keeps what the fold engine
+# returns: the dot-bracket rows and their integer energies, step by step.
+#   magic "RAFFTFFG" | u32 version=1 | u32 L | u32 n_steps | u32 n_structs
+#   | sequence (L bytes) | step sizes (n_steps x i32) | dcal (n_structs x i32) | rows (n_structs x L bytes)
+_SIDECAR_MAGIC = b"RAFFTFFG"
+
+
+def write_sidecar(path, sequence, trajectory):
+    import numpy as np
+    L = len(sequence)
+    sizes = np.array([len(step) for step in trajectory], dtype="<i4")
+    structs = [s for step in trajectory for s in step]
+    dcal = np.array([s.dcal for s in structs], dtype="<i4")
+    with open(path, "wb") as fh:
+        fh.write(_SIDECAR_MAGIC)
+        fh.write(np.array([1, L, len(sizes), len(structs)], dtype="<u4").tobytes())
+        fh.write(sequence.encode("ascii"))
+        fh.write(sizes.tobytes())
+        fh.write(dcal.tobytes())
+        for s in structs:
+            row = s.str_struct.encode("ascii")
+            assert len(row) == L
+            fh.write(row)
+
+
+def read_sidecar(path, text_energies=False):
+    """-> (fast_paths, sequence), the same shape parse_rafft_output returns, with exact dcal energies.
+    text_energies=True rounds `.energy` to the one decimal the `--traj` text carries (bin/rafft:77-78), which is
+    all the reference's rafft_kin ever sees; `.dcal` stays exact."""
+    import numpy as np
+    with open(path, "rb") as fh:
+        buf = fh.read()
+    if buf[:8] != _SIDECAR_MAGIC:
+        raise ValueError(f"{path}: not a RAFFT fast-folding-graph side-car")
+    version, L, n_steps, n_structs = (int(x) for x in np.frombuffer(buf, dtype="<u4", count=4, offset=8))
+    if version != 1:
+        raise ValueError(f"{path}: unsupported side-car version {version}")
+    o = 24
+    sequence = buf[o:o + L].decode("ascii"); o += L
+    sizes = np.frombuffer(buf, dtype="<i4", count=n_steps, offset=o); o += 4 * n_steps
+    dcal = np.frombuffer(buf, dtype="<i4", count=n_structs, offset=o); o += 4 * n_structs
+    if int(sizes.sum()) != n_structs or len(buf) != o + n_structs * L:
+        raise ValueError(f"{path}: truncated or inconsistent side-car")
+    fast_paths, k = [], 0
+    for n in sizes:
+        step = []
+        for _ in range(int(n)):
+            st = Structure(buf[o + k * L:o + (k + 1) * L].decode("ascii"), int(dcal[k]))
+            if text_energies:
+                st.energy = float(f"{st.energy:6.1f}")
+            step.append(st)
+            k += 1
+        fast_paths.append(step)
+    return fast_paths, sequence

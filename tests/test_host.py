@@ -161,6 +161,35 @@ def test_rafft_kin_cli_table(capsys):
     assert top[0].startswith("(((((.(((") and abs(float(top[1]) - 0.519) < 1e-3 and top[3] == "59"
 
 
+def test_fast_folding_graph_sidecar_roundtrip(tmp_path, capsys):
+    """`rafft --traj --sidecar` writes the graph in binary (exact dcal); `rafft_kin --sidecar`
+    reads it and prints the same population table as from the text"""
+    from rafft_amd import rafft_kin
+    side = tmp_path / "ffg.bin"
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        cli.main(["-s", EX, "-ms", "20", "--traj", "--sidecar", str(side)], fold_batch=_oracle_fold_batch)
+    assert buf.getvalue() == open(os.path.join(GOLD, "example_rafft_20.out")).read()
+    fp_bin, seq_bin = utils.read_sidecar(str(side))
+    fp_txt, seq_txt = utils.parse_rafft_output(os.path.join(GOLD, "example_rafft_20.out"))
+    assert seq_bin == seq_txt == EX
+    assert [[s.str_struct for s in st] for st in fp_bin] == [[s.str_struct for s in st] for st in fp_txt]
+    _, o = oracle.fold(EX, 100, 20, 1000, traj=True)
+    assert [[s.dcal for s in st] for st in fp_bin] == [[s.dcal for s in st] for st in o]       # exact, not 1 decimal
+    capsys.readouterr()
+    rafft_kin.main([os.path.join(GOLD, "example_rafft_20.out"), "-mt", "40"])
+    from_text = capsys.readouterr().out
+    rafft_kin.main([str(side), "--sidecar", "-mt", "40"])
+    from_bin = capsys.readouterr().out
+    t, b2 = from_text.strip().splitlines(), from_bin.strip().splitlines()
+    assert from_bin == from_text and len(t) == len(b2) == 68 and b2[-1].split()[3] == "59"   # same one-decimal energies by default
+    rafft_kin.main([str(side), "--sidecar", "--exact", "-mt", "40"])
+    assert len(capsys.readouterr().out.strip().splitlines()) == 68
+    (tmp_path / "bad.bin").write_bytes(b"nonsense")
+    with pytest.raises(ValueError):
+        utils.read_sidecar(str(tmp_path / "bad.bin"))
+
+
 def test_scoring_reproduces_reference_columns(bench_rows):
     """PPV / sensitivity of the reference's published structures against the known structures:
     the flexible-pair rule reproduces the pvv/sens columns of its *_scores.csv (2 decimals)"""
