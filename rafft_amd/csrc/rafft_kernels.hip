@@ -1327,15 +1327,61 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
 // One wavefront per new beam member.  Child regions are spliced from the parent's
 // regions: inner = positions/branches strictly inside the innermost stem pair, outer =
 // the rest of the parent's loop with the whole stem as one new branch.
+//
+// One lane describes one productive region of the parent (chosen stem, the branch indices it cuts the
+// loop at, sizes of the two child regions); the copies then run FLAT over all output elements of the
+// tile (binary search element -> child region), so every load of the wavefront is independent and in
+// flight at once instead of one dependent round trip per region.
+struct MatDesc {
+    unsigned long long srcpos, srcbr;
+    int pn, mi, mj, nb, n, nbr, ci, cj, lo0, hi0, loo, hio, a0, b0, ao, bo, flags;
+    int nnod, npos_in, npos_out, nbr_in, nbr_out;
+};
+__device__ inline MatDesc mat_describe(const Dev &d, int pn, int selk)
+{
+    MatDesc m;
+    m.pn = pn;
+    const unsigned long long coff = d.nd_cand[pn];
+    m.n = d.nd_n[pn]; m.nbr = d.nd_nbr[pn]; m.ci = d.nd_ci[pn]; m.cj = d.nd_cj[pn];
+    m.srcpos = d.nd_pos[pn]; m.srcbr = d.nd_br[pn];
+    const Cand cd = d.cand[coff + selk];
+    m.mi = cd.mi; m.mj = cd.mj; m.nb = cd.nb;
+    const uint16_t *pp = d.pos + m.srcpos;
+    const uint32_t *bb = d.br + m.srcbr;
+    m.a0 = pp[m.mi]; m.b0 = pp[m.mj]; m.ao = pp[m.mi - m.nb + 1]; m.bo = pp[m.mj + m.nb - 1];
+    // four lower bounds over the same branch list, advanced together (one round trip per halving)
+    int lo[4] = {0, 0, 0, 0}, len[4] = {m.nbr, m.nbr, m.nbr, m.nbr};
+    const int x[4] = {m.a0, m.b0, m.ao, m.bo};
+    while (len[0] | len[1] | len[2] | len[3]) {
+        uint32_t v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = len[q] > 0 ? bb[lo[q] + (len[q] >> 1)] : 0u;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (len[q] > 0) {
+                const int h = len[q] >> 1;
+                if ((int)(v[q] & 0xffffu) < x[q]) { lo[q] += h + 1; len[q] -= h + 1; } else len[q] = h;
+            }
+    }
+    m.lo0 = lo[0]; m.hi0 = lo[1]; m.loo = lo[2]; m.hio = lo[3];
+    m.flags = 0; m.nnod = 0; m.npos_in = m.npos_out = m.nbr_in = m.nbr_out = 0;
+    if (m.mj - m.mi > 1) { m.flags |= 1; m.nnod++; m.npos_in = m.mj - m.mi - 1; m.nbr_in = m.hi0 - m.lo0; }
+    if (m.mi - (m.nb - 1) > 0 || m.mj + m.nb < m.n) {
+        m.flags |= 2; m.nnod++; m.npos_out = (m.mi - m.nb + 1) + (m.n - (m.mj + m.nb)); m.nbr_out = m.loo + 1 + (m.nbr - m.hio);
+    }
+    return m;
+}
+
 __global__ __launch_bounds__(MAT_NT) void materialize_kernel(Dev d)
 {
     __shared__ uint8_t sdb[RAFFT_MAX_LEN];
     __shared__ int prod_node[MAX_PROD];
     __shared__ int prod_cnt[MAX_PROD];
     __shared__ int sel[MAX_PROD];
-    // per-tile descriptors (one lane per productive region)
-    __shared__ int k_mi[64], k_mj[64], k_nb[64], k_lo0[64], k_hi0[64], k_loo[64], k_hio[64], k_flags[64];
-    __shared__ int k_node[64], k_pos[64], k_br[64];
+    // per-tile descriptors (one lane per productive region) and the flat-copy prefix sums (two slots per region)
+    __shared__ unsigned long long k_srcpos[64], k_srcbr[64];
+    __shared__ int k_mi[64], k_mj[64], k_nb[64], k_lo0[64], k_loo[64], k_hio[64], k_newbr[64];
+    __shared__ int ps[129], bs[129], ns[65];
     __shared__ unsigned long long sh64[4];
     __shared__ int shi[8];
     const int tid = threadIdx.x;
@@ -1348,15 +1394,15 @@ __global__ __launch_bounds__(MAT_NT) void materialize_kernel(Dev d)
     const int sq = d.st_seq[sid];
     const int L = d.seq_len[sq];
     const int my_dcal = d.st_dcal[sid];
-    const int node0 = d.st_node0[par], nn = d.st_nnodes[par];
     int mprod = d.st_nprod[par];
     if (mprod > MAX_PROD) mprod = MAX_PROD;
     {
         const ProdEnt *pl = d.prod + d.st_prod[par];      // the parent's productive regions (beam_step prepass)
-        for (int k = tid; k < mprod; k += MAT_NT) { prod_node[k] = pl[k].node; prod_cnt[k] = (int)pl[k].cnt; }
+        for (int k = tid; k < mprod; k += MAT_NT) { prod_node[k] = pl[k].node; prod_cnt[k] = (int)pl[k].cnt; sel[k] = 0; }
     }
-    __syncthreads();
-    for (int k = tid; k < mprod; k += MAT_NT) sel[k] = 0;
+    // the parent's dot-bracket row (rafft/rafft.py:97,127-128); the stems are marked below
+    const uint8_t *pdb = d.db + d.st_db[par];
+    for (int x = tid; x < L; x += MAT_NT) sdb[x] = pdb[x];
     __syncthreads();
     if (tid == 0) {      // digits of the combo, last region fastest; high digits of a small index stay 0
         unsigned long long idx = d.st_combo[sid];
@@ -1372,27 +1418,19 @@ __global__ __launch_bounds__(MAT_NT) void materialize_kernel(Dev d)
         }
     }
     __syncthreads();
+    MSTAMP(0);   // header, productive-region list, parent row, combo digits
 
-    MSTAMP(0);   // header, productive-region list, combo digits
-    // pass 1: sizes
+    // pass 1: sizes (a single tile - the usual case - keeps its descriptors in registers for pass 2)
+    const bool one_tile = mprod <= MAT_NT;
+    MatDesc md;
+    md.flags = 0; md.nnod = 0; md.npos_in = md.npos_out = md.nbr_in = md.nbr_out = 0; md.nb = 0;
     int tot_nodes = 0, tot_pos = 0, tot_br = 0;
     for (int base = 0; base < mprod; base += MAT_NT) {
-        int k = base + tid, nnod = 0, npos = 0, nbrr = 0;
+        const int k = base + tid;
+        int nnod = 0, npos = 0, nbrr = 0;
         if (k < mprod) {
-            const int pn = prod_node[k];
-            const Cand cd = d.cand[d.nd_cand[pn] + sel[k]];
-            const int n = d.nd_n[pn], nbr = d.nd_nbr[pn];
-            const uint16_t *pp = d.pos + d.nd_pos[pn];
-            const uint32_t *bb = d.br + d.nd_br[pn];
-            const int mi = cd.mi, mj = cd.mj, nb = cd.nb;
-            if (mj - mi > 1) {
-                nnod++; npos += mj - mi - 1;
-                nbrr += br_lower(bb, nbr, pp[mj]) - br_lower(bb, nbr, pp[mi]);
-            }
-            if (mi - (nb - 1) > 0 || mj + nb < n) {
-                nnod++; npos += (mi - nb + 1) + (n - (mj + nb));
-                nbrr += br_lower(bb, nbr, pp[mi - nb + 1]) + 1 + (nbr - br_lower(bb, nbr, pp[mj + nb - 1]));
-            }
+            md = mat_describe(d, prod_node[k], sel[k]);
+            nnod = md.nnod; npos = md.npos_in + md.npos_out; nbrr = md.nbr_in + md.nbr_out;
         }
         for (int o = 32; o > 0; o >>= 1) {
             nnod += __shfl_xor(nnod, o, 64); npos += __shfl_xor(npos, o, 64); nbrr += __shfl_xor(nbrr, o, 64);
@@ -1400,105 +1438,102 @@ __global__ __launch_bounds__(MAT_NT) void materialize_kernel(Dev d)
         tot_nodes += nnod; tot_pos += npos; tot_br += nbrr;
     }
     MSTAMP(1);   // pass 1
-    if (tid == 0) {
-        // bump allocation from one of NSHARD sub-arenas (spreads the same-address atomics)
+    if (tid < 4) {
+        // bump allocation from one of NSHARD sub-arenas (spreads the same-address atomics); one lane per arena
         const int shd = blockIdx.x & (NSHARD - 1);
-        unsigned long long nb0 = atomicAdd(&d.c->node[shd].v, (unsigned long long)tot_nodes);
-        unsigned long long pb0 = atomicAdd(&d.c->pos[shd].v, (unsigned long long)tot_pos);
-        unsigned long long bb0 = atomicAdd(&d.c->br[shd].v, (unsigned long long)tot_br);
-        unsigned long long tb0 = atomicAdd(&d.c->db[shd].v, (unsigned long long)L);
-        int ok = 1;
-        if (nb0 + tot_nodes > d.nd_shard_cap) { atomicOr(&d.c->overflow, OVF_NODE); ok = 0; }
-        if (pb0 + tot_pos > d.pos_shard_cap) { atomicOr(&d.c->overflow, OVF_POS); ok = 0; }
-        if (bb0 + tot_br > d.br_shard_cap) { atomicOr(&d.c->overflow, OVF_BR); ok = 0; }
-        if (tb0 + L > d.db_shard_cap) { atomicOr(&d.c->overflow, OVF_DB); ok = 0; }
-        sh64[0] = d.nd_base + (unsigned long long)shd * d.nd_shard_cap + nb0;
-        sh64[1] = d.pos_base + (unsigned long long)shd * d.pos_shard_cap + pb0;
-        sh64[2] = d.db_base + (unsigned long long)shd * d.db_shard_cap + tb0;
-        sh64[3] = (unsigned long long)shd * d.br_shard_cap + bb0;
-        shi[0] = ok;
+        unsigned long long *ctr = tid == 0 ? &d.c->node[shd].v : tid == 1 ? &d.c->pos[shd].v : tid == 2 ? &d.c->db[shd].v : &d.c->br[shd].v;
+        const unsigned long long want = tid == 0 ? (unsigned long long)tot_nodes : tid == 1 ? (unsigned long long)tot_pos
+                                      : tid == 2 ? (unsigned long long)L : (unsigned long long)tot_br;
+        const unsigned long long cap = tid == 0 ? d.nd_shard_cap : tid == 1 ? d.pos_shard_cap : tid == 2 ? d.db_shard_cap : d.br_shard_cap;
+        const unsigned long long b0 = atomicAdd(ctr, want);
+        const bool bad = b0 + want > cap;
+        if (bad) atomicOr(&d.c->overflow, tid == 0 ? OVF_NODE : tid == 1 ? OVF_POS : tid == 2 ? OVF_DB : OVF_BR);
+        const unsigned long long origin = tid == 0 ? d.nd_base : tid == 1 ? d.pos_base : tid == 2 ? d.db_base : 0ULL;
+        sh64[tid] = origin + (unsigned long long)shd * cap + b0;
+        const unsigned long long anybad = __ballot(bad);
+        if (tid == 0) shi[0] = anybad ? 0 : 1;
     }
     __syncthreads();
     if (!shi[0]) { if (tid == 0) { d.st_nnodes[sid] = 0; d.st_node0[sid] = 0; d.st_db[sid] = 0; } return; }
     const unsigned long long nbase = sh64[0], pbase = sh64[1], tbase = sh64[2], bbase = sh64[3];
-
     MSTAMP(2);   // allocation
-    // dot-bracket row: parent's row + the stems (rafft/rafft.py:97,127-128)
-    const uint8_t *pdb = d.db + d.st_db[par];
-    for (int x = tid; x < L; x += MAT_NT) sdb[x] = pdb[x];
-    __syncthreads();
 
-    MSTAMP(3);   // parent's dot-bracket row
-    // pass 2: per tile descriptors, prefix, copy
+    // pass 2: per tile: descriptors -> LDS, prefix sums, region records, flat copies
     int run_nodes = 0, run_pos = 0, run_br = 0;
     for (int base = 0; base < mprod; base += MAT_NT) {
         const int k = base + tid;
-        int nnod = 0, npos = 0, nbrr = 0, flags = 0;
-        if (k < mprod) {
-            const int pn = prod_node[k];
-            const Cand cd = d.cand[d.nd_cand[pn] + sel[k]];
-            const int n = d.nd_n[pn], nbr = d.nd_nbr[pn];
-            const uint16_t *pp = d.pos + d.nd_pos[pn];
-            const uint32_t *bb = d.br + d.nd_br[pn];
-            const int mi = cd.mi, mj = cd.mj, nb = cd.nb;
-            k_mi[tid] = mi; k_mj[tid] = mj; k_nb[tid] = nb;
-            const int lo0 = br_lower(bb, nbr, pp[mi]), hi0 = br_lower(bb, nbr, pp[mj]);
-            const int loo = br_lower(bb, nbr, pp[mi - nb + 1]), hio = br_lower(bb, nbr, pp[mj + nb - 1]);
-            k_lo0[tid] = lo0; k_hi0[tid] = hi0; k_loo[tid] = loo; k_hio[tid] = hio;
-            if (mj - mi > 1) { flags |= 1; nnod++; npos += mj - mi - 1; nbrr += hi0 - lo0; }
-            if (mi - (nb - 1) > 0 || mj + nb < n) { flags |= 2; nnod++; npos += (mi - nb + 1) + (n - (mj + nb)); nbrr += loo + 1 + (nbr - hio); }
-            k_flags[tid] = flags;
-        }
-        // exclusive scans over the tile
-        int xn = nnod, xp = npos, xb = nbrr;
-        for (int o = 1; o < 64; o <<= 1) {
-            int yn = __shfl_up(xn, o, 64), yp = __shfl_up(xp, o, 64), yb = __shfl_up(xb, o, 64);
-            if (tid >= o) { xn += yn; xp += yp; xb += yb; }
-        }
-        const int tn = __shfl(xn, 63, 64), tp = __shfl(xp, 63, 64), tb = __shfl(xb, 63, 64);
-        k_node[tid] = run_nodes + xn - nnod; k_pos[tid] = run_pos + xp - npos; k_br[tid] = run_br + xb - nbrr;
-        __syncthreads();
-        MSTAMP(4);   // pass 2 descriptors
         const int kt = mprod - base < MAT_NT ? mprod - base : MAT_NT;
-        for (int kk = 0; kk < kt; kk++) {
-            const int pn = prod_node[base + kk];
-            const int n = d.nd_n[pn], nbr = d.nd_nbr[pn], pci = d.nd_ci[pn], pcj = d.nd_cj[pn];
-            const uint16_t *pp = d.pos + d.nd_pos[pn];
-            const uint32_t *bb = d.br + d.nd_br[pn];
-            const int mi = k_mi[kk], mj = k_mj[kk], nb = k_nb[kk], fl = k_flags[kk];
-            int nidx = k_node[kk];
-            unsigned long long poff = pbase + k_pos[kk], boff = bbase + k_br[kk];
-            for (int t = tid; t < nb; t += MAT_NT) { sdb[pp[mi - t]] = '('; sdb[pp[mj + t]] = ')'; }
-            if (fl & 1) {     // inner region (rafft/utils.py:148-152)
-                const int len = mj - mi - 1, lo0 = k_lo0[kk], nb_in = k_hi0[kk] - lo0;
-                for (int t = tid; t < len; t += MAT_NT) d.pos[poff + t] = pp[mi + 1 + t];
-                for (int t = tid; t < nb_in; t += MAT_NT) d.br[boff + t] = bb[lo0 + t];
-                if (tid == 0) {
-                    const int nid = (int)(nbase + nidx);
-                    d.nd_seq[nid] = sq; d.nd_pdcal[nid] = my_dcal; d.nd_pos[nid] = poff; d.nd_n[nid] = len;
-                    d.nd_ci[nid] = pp[mi]; d.nd_cj[nid] = pp[mj]; d.nd_br[nid] = boff; d.nd_nbr[nid] = nb_in;
-                    d.nd_ncand[nid] = -1; d.nd_cand[nid] = 0; d.nd_canon[nid] = nid;
-                }
-                nidx++; poff += len; boff += nb_in;
+        if (!one_tile) {
+            md.flags = 0; md.nnod = 0; md.npos_in = md.npos_out = md.nbr_in = md.nbr_out = 0; md.nb = 0;
+            if (k < mprod) md = mat_describe(d, prod_node[k], sel[k]);
+        }
+        const bool act = k < mprod;
+        // inclusive scans over the tile: nodes, pos elements, branch elements, stem pairs
+        int xn = act ? md.nnod : 0, xp = act ? md.npos_in + md.npos_out : 0, xb = act ? md.nbr_in + md.nbr_out : 0, xs = act ? md.nb : 0;
+        const int vn = xn, vp = xp, vb = xb, vs = xs;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int yn = __shfl_up(xn, o, 64), yp = __shfl_up(xp, o, 64), yb = __shfl_up(xb, o, 64), ys = __shfl_up(xs, o, 64);
+            if (tid >= o) { xn += yn; xp += yp; xb += yb; xs += ys; }
+        }
+        const int tn = __shfl(xn, 63, 64), tp = __shfl(xp, 63, 64), tb = __shfl(xb, 63, 64), ts = __shfl(xs, 63, 64);
+        const int p0 = xp - vp, b0 = xb - vb;          // exclusive
+        ps[2 * tid] = p0; ps[2 * tid + 1] = p0 + (act ? md.npos_in : 0);
+        bs[2 * tid] = b0; bs[2 * tid + 1] = b0 + (act ? md.nbr_in : 0);
+        ns[tid] = xs - vs;
+        if (tid == 0) { ps[128] = tp; bs[128] = tb; ns[64] = ts; }
+        if (act) {
+            k_srcpos[tid] = md.srcpos; k_srcbr[tid] = md.srcbr;
+            k_mi[tid] = md.mi; k_mj[tid] = md.mj; k_nb[tid] = md.nb; k_lo0[tid] = md.lo0; k_loo[tid] = md.loo; k_hio[tid] = md.hio;
+            k_newbr[tid] = (int)((uint32_t)md.ao | ((uint32_t)md.bo << 16));
+            // region records (rafft/utils.py:141-152): inner, then outer
+            int nid = (int)(nbase + run_nodes + (xn - vn));
+            const unsigned long long poff = pbase + run_pos + p0, boff = bbase + run_br + b0;
+            if (md.flags & 1) {
+                d.nd_seq[nid] = sq; d.nd_pdcal[nid] = my_dcal; d.nd_pos[nid] = poff; d.nd_n[nid] = md.npos_in;
+                d.nd_ci[nid] = md.a0; d.nd_cj[nid] = md.b0; d.nd_br[nid] = boff; d.nd_nbr[nid] = md.nbr_in;
+                d.nd_ncand[nid] = -1; d.nd_cand[nid] = 0; d.nd_canon[nid] = nid;
+                nid++;
             }
-            if (fl & 2) {     // outer region (rafft/utils.py:141-145)
-                const int left = mi - nb + 1, right = mj + nb, len = left + (n - right);
-                const int loo = k_loo[kk], hio = k_hio[kk], nb_out = loo + 1 + (nbr - hio);
-                for (int t = tid; t < len; t += MAT_NT) d.pos[poff + t] = t < left ? pp[t] : pp[right + (t - left)];
-                for (int t = tid; t < nb_out; t += MAT_NT) {
-                    uint32_t v;
-                    if (t < loo) v = bb[t];
-                    else if (t == loo) v = (uint32_t)pp[mi - nb + 1] | ((uint32_t)pp[mj + nb - 1] << 16);
-                    else v = bb[hio + (t - loo - 1)];
-                    d.br[boff + t] = v;
-                }
-                if (tid == 0) {
-                    const int nid = (int)(nbase + nidx);
-                    d.nd_seq[nid] = sq; d.nd_pdcal[nid] = my_dcal; d.nd_pos[nid] = poff; d.nd_n[nid] = len;
-                    d.nd_ci[nid] = pci; d.nd_cj[nid] = pcj; d.nd_br[nid] = boff; d.nd_nbr[nid] = nb_out;
-                    d.nd_ncand[nid] = -1; d.nd_cand[nid] = 0; d.nd_canon[nid] = nid;
-                }
+            if (md.flags & 2) {
+                d.nd_seq[nid] = sq; d.nd_pdcal[nid] = my_dcal; d.nd_pos[nid] = poff + md.npos_in; d.nd_n[nid] = md.npos_out;
+                d.nd_ci[nid] = md.ci; d.nd_cj[nid] = md.cj; d.nd_br[nid] = boff + md.nbr_in; d.nd_nbr[nid] = md.nbr_out;
+                d.nd_ncand[nid] = -1; d.nd_cand[nid] = 0; d.nd_canon[nid] = nid;
             }
+        }
+        __syncthreads();
+        MSTAMP(4);   // pass 2 descriptors + records
+        // unpaired positions of the child regions
+        for (int f = tid; f < tp; f += MAT_NT) {
+            int lo = 0, hi = 2 * kt - 1;                 // last slot starting at or before f (empty slots share starts)
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (ps[mid] <= f) lo = mid; else hi = mid - 1; }
+            const int kk = lo >> 1, off = f - ps[lo];
+            const uint16_t *pp = d.pos + k_srcpos[kk];
+            int src;
+            if (!(lo & 1)) src = k_mi[kk] + 1 + off;
+            else { const int left = k_mi[kk] - k_nb[kk] + 1; src = off < left ? off : k_mj[kk] + k_nb[kk] + (off - left); }
+            d.pos[pbase + run_pos + f] = pp[src];
+        }
+        // branch helices of the child regions
+        for (int f = tid; f < tb; f += MAT_NT) {
+            int lo = 0, hi = 2 * kt - 1;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (bs[mid] <= f) lo = mid; else hi = mid - 1; }
+            const int kk = lo >> 1, off = f - bs[lo];
+            const uint32_t *bb = d.br + k_srcbr[kk];
+            uint32_t v;
+            if (!(lo & 1)) v = bb[k_lo0[kk] + off];
+            else {
+                const int loo = k_loo[kk];
+                v = off < loo ? bb[off] : off == loo ? (uint32_t)k_newbr[kk] : bb[k_hio[kk] + (off - loo - 1)];
+            }
+            d.br[bbase + run_br + f] = v;
+        }
+        // the stems in the dot-bracket row
+        for (int f = tid; f < ts; f += MAT_NT) {
+            int lo = 0, hi = kt - 1;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (ns[mid] <= f) lo = mid; else hi = mid - 1; }
+            const int t = f - ns[lo];
+            const uint16_t *pp = d.pos + k_srcpos[lo];
+            sdb[pp[k_mi[lo] - t]] = '('; sdb[pp[k_mj[lo] + t]] = ')';
         }
         run_nodes += tn; run_pos += tp; run_br += tb;
         __syncthreads();
