@@ -426,6 +426,8 @@ int Wave::setup()
     if (const char *e = getenv("RAFFT_NO_MEMO")) if (atoi(e)) d.memo = 0;
     if (const char *e = getenv("RAFFT_FORCE_FFT")) if (atoi(e)) d.force_fft = 1;   // tests: FFT path for short regions too
     d.rl_cap = RL_CAP;
+    d.mat_tile = 64;
+    if (const char *e = getenv("RAFFT_MAT_TILE")) d.mat_tile = std::max(1, std::min(atoi(e), 64));   // tests: several tiles per structure
     if (const char *e = getenv("RAFFT_RL_CAP")) d.rl_cap = std::max(0, std::min(atoi(e), RL_CAP));   // tests: region lists not resident in LDS
     d.beam = (int *)g.beam.p; d.beam_n = (int *)g.beam_n.p; d.done = (int *)g.done.p; d.nsteps = (int *)g.nsteps.p;
     d.ch_cap = c.ch_cap;

@@ -68,7 +68,7 @@ struct Dev {
     int S;
     const uint8_t *codes;
     const int *seq_off, *seq_len;
-    int K, B, max_branch, min_hp, traj, memo, force_fft, rl_cap;
+    int K, B, max_branch, min_hp, traj, memo, force_fft, rl_cap, mat_tile;
     double min_nrj, gc, au, gu;
     int *beam, *beam_n, *done, *nsteps;
     // children of the current step

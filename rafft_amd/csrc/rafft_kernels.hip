@@ -1421,14 +1421,15 @@ __global__ __launch_bounds__(MAT_NT) void materialize_kernel(Dev d)
     MSTAMP(0);   // header, productive-region list, parent row, combo digits
 
     // pass 1: sizes (a single tile - the usual case - keeps its descriptors in registers for pass 2)
-    const bool one_tile = mprod <= MAT_NT;
+    const int TILE = d.mat_tile;          // 64; smaller only in tests (several tiles per structure)
+    const bool one_tile = mprod <= TILE;
     MatDesc md;
     md.flags = 0; md.nnod = 0; md.npos_in = md.npos_out = md.nbr_in = md.nbr_out = 0; md.nb = 0;
     int tot_nodes = 0, tot_pos = 0, tot_br = 0;
-    for (int base = 0; base < mprod; base += MAT_NT) {
+    for (int base = 0; base < mprod; base += TILE) {
         const int k = base + tid;
         int nnod = 0, npos = 0, nbrr = 0;
-        if (k < mprod) {
+        if (k < mprod && tid < TILE) {
             md = mat_describe(d, prod_node[k], sel[k]);
             nnod = md.nnod; npos = md.npos_in + md.npos_out; nbrr = md.nbr_in + md.nbr_out;
         }
@@ -1460,14 +1461,14 @@ __global__ __launch_bounds__(MAT_NT) void materialize_kernel(Dev d)
 
     // pass 2: per tile: descriptors -> LDS, prefix sums, region records, flat copies
     int run_nodes = 0, run_pos = 0, run_br = 0;
-    for (int base = 0; base < mprod; base += MAT_NT) {
+    for (int base = 0; base < mprod; base += TILE) {
         const int k = base + tid;
-        const int kt = mprod - base < MAT_NT ? mprod - base : MAT_NT;
+        const int kt = mprod - base < TILE ? mprod - base : TILE;
         if (!one_tile) {
             md.flags = 0; md.nnod = 0; md.npos_in = md.npos_out = md.nbr_in = md.nbr_out = 0; md.nb = 0;
-            if (k < mprod) md = mat_describe(d, prod_node[k], sel[k]);
+            if (k < mprod && tid < TILE) md = mat_describe(d, prod_node[k], sel[k]);
         }
-        const bool act = k < mprod;
+        const bool act = k < mprod && tid < TILE;
         // inclusive scans over the tile: nodes, pos elements, branch elements, stem pairs
         int xn = act ? md.nnod : 0, xp = act ? md.npos_in + md.npos_out : 0, xb = act ? md.nbr_in + md.nbr_out : 0, xs = act ? md.nb : 0;
         const int vn = xn, vp = xp, vb = xb, vs = xs;

@@ -143,8 +143,10 @@ def test_gpu_beam_region_lists_not_resident(monkeypatch):
     seqs = ["".join(rng.choice(list("ACGU"), int(n))) for n in (70, 180, 333, 512, 900)]
     a = rafft_amd.fold_batch(seqs, 100, 30, 200, traj=True)
     monkeypatch.setenv("RAFFT_RL_CAP", "6")
+    monkeypatch.setenv("RAFFT_MAT_TILE", "3")      # and materialize_kernel in several tiles per structure
     b = rafft_amd.fold_batch(seqs, 100, 30, 200, traj=True)
     monkeypatch.delenv("RAFFT_RL_CAP")
+    monkeypatch.delenv("RAFFT_MAT_TILE")
     for s, (f1, t1), (f2, t2) in zip(seqs, a, b):
         assert as_lists(t1) == as_lists(t2)
         if len(s) <= 333:
