@@ -24,9 +24,20 @@
 
 struct alignas(16) Cand {
     int32_t ddcal;
-    uint16_t mi, mj, nb, pad;
-    uint32_t pad2;
-    uint64_t h1, h2;
+    uint16_t mi, mj, nb, cut_hi;      // stem: innermost pair (mi,mj) in region coordinates, nb stacked pairs
+    uint32_t cut_lo;                  // cut_hi:cut_lo = where the stem cuts the region's branch list, 4 x 11 bits
+    uint64_t h1, h2;                  // 128-bit hash of the stem's pairs
+    // number of branches starting before the innermost 5' / innermost 3' / outermost 5' / outermost 3' position
+    __host__ __device__ void set_cuts(int lo0, int hi0, int loo, int hio)
+    {
+        const unsigned long long v = (unsigned long long)lo0 | ((unsigned long long)hi0 << 11) | ((unsigned long long)loo << 22) | ((unsigned long long)hio << 33);
+        cut_lo = (uint32_t)v; cut_hi = (uint16_t)(v >> 32);
+    }
+    __host__ __device__ void get_cuts(int &lo0, int &hi0, int &loo, int &hio) const
+    {
+        const unsigned long long v = (unsigned long long)cut_lo | ((unsigned long long)cut_hi << 32);
+        lo0 = (int)(v & 2047); hi0 = (int)((v >> 11) & 2047); loo = (int)((v >> 22) & 2047); hio = (int)((v >> 33) & 2047);
+    }
 };
 static_assert(sizeof(Cand) == 32, "Cand must be 32 bytes");
 

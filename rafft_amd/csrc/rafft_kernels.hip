@@ -731,7 +731,8 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                     h1 += a; h2 += b;
                 }
                 Cand cd;
-                cd.ddcal = my; cd.mi = (uint16_t)mi; cd.mj = (uint16_t)mj; cd.nb = (uint16_t)nb; cd.pad = 0; cd.pad2 = 0;
+                cd.ddcal = my; cd.mi = (uint16_t)mi; cd.mj = (uint16_t)mj; cd.nb = (uint16_t)nb;
+                cd.set_cuts(br_lower(brl, nbr, pos[mi]), br_lower(brl, nbr, pos[mj]), br_lower(brl, nbr, pos[mi - nb + 1]), br_lower(brl, nbr, pos[mj + nb - 1]));
                 cd.h1 = h1; cd.h2 = h2;
                 d.cand[cbase + rank] = cd;
                 if (d.dbg.kept) d.dbg.kept[rank] = r;
@@ -1347,23 +1348,8 @@ __device__ inline MatDesc mat_describe(const Dev &d, int pn, int selk)
     const Cand cd = d.cand[coff + selk];
     m.mi = cd.mi; m.mj = cd.mj; m.nb = cd.nb;
     const uint16_t *pp = d.pos + m.srcpos;
-    const uint32_t *bb = d.br + m.srcbr;
     m.a0 = pp[m.mi]; m.b0 = pp[m.mj]; m.ao = pp[m.mi - m.nb + 1]; m.bo = pp[m.mj + m.nb - 1];
-    // four lower bounds over the same branch list, advanced together (one round trip per halving)
-    int lo[4] = {0, 0, 0, 0}, len[4] = {m.nbr, m.nbr, m.nbr, m.nbr};
-    const int x[4] = {m.a0, m.b0, m.ao, m.bo};
-    while (len[0] | len[1] | len[2] | len[3]) {
-        uint32_t v[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) v[q] = len[q] > 0 ? bb[lo[q] + (len[q] >> 1)] : 0u;
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (len[q] > 0) {
-                const int h = len[q] >> 1;
-                if ((int)(v[q] & 0xffffu) < x[q]) { lo[q] += h + 1; len[q] -= h + 1; } else len[q] = h;
-            }
-    }
-    m.lo0 = lo[0]; m.hi0 = lo[1]; m.loo = lo[2]; m.hio = lo[3];
+    cd.get_cuts(m.lo0, m.hi0, m.loo, m.hio);      // where the stem cuts the branch list (found by expand_kernel)
     m.flags = 0; m.nnod = 0; m.npos_in = m.npos_out = m.nbr_in = m.nbr_out = 0;
     if (m.mj - m.mi > 1) { m.flags |= 1; m.nnod++; m.npos_in = m.mj - m.mi - 1; m.nbr_in = m.hi0 - m.lo0; }
     if (m.mi - (m.nb - 1) > 0 || m.mj + m.nb < m.n) {
