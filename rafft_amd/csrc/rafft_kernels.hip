@@ -273,6 +273,16 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
 
         ESTAMP(2);   // FFTs
         // ---- lag values (exact integer pair counts, IEEE fp64 divide) and ranking
+        // Which lags are searched (rafft/rafft.py:117-118 takes the nb_mode best by (value desc, lag desc)):
+        //  - all of them when 2n-1 <= nb_mode: nothing to rank;
+        //  - otherwise the best nb_mode are SELECTED exactly (byte-wise radix select on the order-preserving bit
+        //    pattern of the fp64 value, ties: larger lag first) - their order is not needed, because the only
+        //    place it shows is the stable dE sort of the candidates, and that breaks ties from (value, lag) itself;
+        //  - tiny FFT sizes (P <= 128) and the debug seam, which reports the ranking, sort all keys in place.
+        const bool dbgrank = d.dbg.lag != nullptr;
+        const bool ranked = m > Kp;
+        const bool selected = ranked && P >= 256;
+        const bool inplace = (ranked && !selected) || (dbgrank && !selected);    // keys sorted in place, rk[] in rank order
         double *keyv = (double *)(lds + lay.offA);
         uint16_t *lagk = (uint16_t *)(lds + lay.offA + 8 * P);
         if (direct) {
@@ -296,7 +306,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                 keyv[k] = v;
             }
             __syncthreads();
-            if (m > Kp || d.dbg.lag != nullptr) {           // lag column of the sort; unused when nothing is ranked
+            if (inplace) {                                  // lag column of the in-place sort
                 for (int k = tid; k < P; k += NT) lagk[k] = (uint16_t)k;
                 __syncthreads();
             }
@@ -317,19 +327,12 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                 keyv[k] = v;
             }
             __syncthreads();
-            if (m > Kp || d.dbg.lag != nullptr) {           // lag column of the sort; unused when nothing is ranked
+            if (inplace) {                                  // lag column of the in-place sort
                 for (int k = tid; k < P; k += NT) lagk[k] = (uint16_t)k;
                 __syncthreads();
             }
         }
         ESTAMP(3);   // lag values
-        // When every lag is searched anyway (2n-1 <= nb_mode) the ranking only breaks dE ties
-        // later on, so the sort is skipped and ties are resolved from (value, lag) directly.
-        const bool sorted = (m > Kp) || d.dbg.lag != nullptr;
-        // Big regions (P >= 1024): the nb_mode best lags are SELECTED exactly with a byte-wise radix select
-        // on the order-preserving bit pattern of the fp64 value (ties: larger lag first) and only those
-        // are sorted; keyv stays indexed by lag.  Small regions sort all P keys (cheaper there).
-        const bool selected = sorted && NT > 64 && P >= 1024 && Kp < m;
         if (selected) {
             int *hist = (int *)(lds + lay.offA + 10 * P);          // 256 bins in the slack of region A
             int *shs = hist + 256;                                   // scan scratch [32]
@@ -351,10 +354,16 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                 __syncthreads();
                 // largest byte b with count(bytes > b) < kk <= count(bytes >= b): suffix scan over the bins
                 {
-                    const int b = 255 - tid;
-                    const int h = tid < 256 ? hist[b] : 0;
-                    int tot, ex = block_exscan<NT>(h, shs, &tot);
-                    if (tid < 256 && ex < kk && kk <= ex + h) { shs[28] = b; shs[29] = kk - ex; }
+                    constexpr int BPT = NT >= 256 ? 1 : 256 / NT;      // bins per thread, from the top bin down
+                    int hs[BPT], mine = 0;
+#pragma unroll
+                    for (int j = 0; j < BPT; j++) { const int bi = tid * BPT + j; hs[j] = bi < 256 ? hist[255 - bi] : 0; mine += hs[j]; }
+                    int tot, ex = block_exscan<NT>(mine, shs, &tot);
+#pragma unroll
+                    for (int j = 0; j < BPT; j++) {
+                        if (ex < kk && kk <= ex + hs[j] && hs[j] > 0) { shs[28] = 255 - (tid * BPT + j); shs[29] = kk - ex; }
+                        ex += hs[j];
+                    }
                     __syncthreads();
                 }
                 prefix |= (unsigned long long)(unsigned)shs[28] << (8 * pass);
@@ -375,7 +384,8 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                 outn += gtot; tie_run += ttot;
                 __syncthreads();
             }
-            // sort the selected lags by (value desc, lag desc)
+            // the debug seam reports the ranking: sort the selected lags by (value desc, lag desc)
+            if (dbgrank) {
             int M2 = 2; while (M2 < Kp) M2 <<= 1;
             for (int i = Kp + tid; i < M2; i += NT) rk[i] = 0xFFFF;
             __syncthreads();
@@ -396,12 +406,13 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                     __syncthreads();
                 }
             }
+            }
             for (int r = tid; r < Kp; r += NT)
                 if (d.dbg.lag) { d.dbg.lag[r] = rk[r]; d.dbg.corval[r] = keyv[rk[r]]; }
             if (tid == 0 && d.dbg.n_ranked) *d.dbg.n_ranked = Kp;
             __syncthreads();
         } else {
-        if (sorted)
+        if (inplace)
         for (int rep_ = 0; rep_ < 1 + ((d.rep >> 1) & 1); rep_++)
             for (int k2 = 2; k2 <= P; k2 <<= 1) {
                 for (int j = k2 >> 1; j > 0; j >>= 1) {
@@ -422,7 +433,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                 }
             }
         for (int r = tid; r < Kp; r += NT) {
-            rk[r] = sorted ? lagk[r] : (uint16_t)r;
+            rk[r] = inplace ? lagk[r] : (uint16_t)r;
             if (d.dbg.lag) { d.dbg.lag[r] = lagk[r]; d.dbg.corval[r] = keyv[r]; }   // (debug seam always sorts)
         }
         if (tid == 0 && d.dbg.n_ranked) *d.dbg.n_ranked = Kp;
@@ -434,10 +445,10 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         // each diagonal is cut into C chunks handled by different lanes; a lane first walks back to the last
         // zero cell before its chunk and replays the recurrence from there (same fp64 operation order, so
         // values are bit-identical), then the chunk results are merged with the reference's `>=` rule.
-        // (chunking only for regions ranked by selection: their region A no longer holds anything live)
+        // (chunking only for regions ranked by selection; the partial results go behind the lag values)
         const int C = (NT >= 256 && selected) ? max(1, min(8, NT / max(Kp, 1))) : 1;
         struct WsPart { double score; int nb, mi, mj, any; };
-        WsPart *parts = (WsPart *)(lds + lay.offA);       // big regions only: region A is free by now
+        WsPart *parts = (WsPart *)(lds + lay.offA + 8 * P);       // big regions only: behind the lag values
         // One-wavefront regions (n <= 256): the diagonal of a lag is a bit mask of pairing cells per pair type
         // (base masks AND shifted reversed base masks, up to four 64-bit words), contiguity is a mask too, and
         // only the pairing cells are visited - zero cells never change the result.  Same fp64 recurrence on the
@@ -446,7 +457,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         if (ws_masks) {
             // forward masks F[0..3] = A,C,G,U, F[4] = contiguity with the previous position; R[] = reversed strings
             // (region A: the sort keys are dead once rk[] exists; in unsorted mode keyv/lagk stay live, masks go past them)
-            unsigned long long *F = (unsigned long long *)(lds + lay.offA + (sorted ? 0 : ((10 * P + 15) & ~15)));
+            unsigned long long *F = (unsigned long long *)(lds + lay.offA + (inplace ? 0 : ((10 * P + 15) & ~15)));
             unsigned long long *R = F + 5 * 4;
             const int W = (n + 63) >> 6;
             for (int rep_ = 0; rep_ < 1 + ((d.rep >> 7) & 1); rep_++) {
@@ -582,7 +593,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         const double par_e = dcal_to_energy(par_dcal);
         // prefix sums of the branches' stem terms (region A is free now except, when nothing was ranked, the
         // lag values at its head), so that every loop below costs O(1) whatever its number of branches
-        int *pe_ext = (int *)(lds + lay.offA + (sorted ? 0 : 8 * P));
+        int *pe_ext = (int *)(lds + lay.offA + (inplace ? 0 : 8 * P));
         int *pe_ml = pe_ext + (nbr + 1);
         uint16_t *psp = (uint16_t *)(pe_ml + (nbr + 1));
         if (tid < 64) {
@@ -709,16 +720,17 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                 const int r = (int)(kx & 0xFFFFFFFFu);
                 const int my = dd[r];
                 int rank = 0;
-                if (sorted) {
+                if (inplace) {                                   // r is the lag's rank
                     for (int y = 0; y < nkept; y++) rank += ck[y] < kx ? 1 : 0;
-                } else {
-                    const double myv = keyv[r];
+                } else {                                         // rk[] is in no particular order: compare (value, lag)
+                    const int lagr = rk[r];
+                    const double myv = keyv[lagr];
                     for (int y = 0; y < nkept; y++) {
                         const unsigned long long ky = ck[y];
                         if ((ky >> 32) == (kx >> 32)) {          // dE tie: (value desc, lag desc)
-                            const int q = (int)(ky & 0xFFFFFFFFu);
-                            const double qv = keyv[q];
-                            rank += (q != r && ((qv > myv) || (qv == myv && q > r))) ? 1 : 0;
+                            const int q = (int)(ky & 0xFFFFFFFFu), lagq = rk[q];
+                            const double qv = keyv[lagq];
+                            rank += (q != r && ((qv > myv) || (qv == myv && lagq > lagr))) ? 1 : 0;
                         } else
                             rank += ky < kx ? 1 : 0;
                     }
@@ -1596,7 +1608,11 @@ __global__ __launch_bounds__(256) void dedupe_kernel(Dev d)
                     if (probe > d.looptab_cap) { atomicOr(&d.c->overflow, OVF_LOOPTAB); break; }
                 }
             }
-            if (canon == nid) cls = node_class(d.nd_n[nid], d.seq_len[d.nd_seq[nid]], d.nd_nbr[nid]);
+            if (canon == nid) {
+                // a stem needs two unpaired positions: a lone position (bulge remnant) has no candidates
+                if (d.nd_n[nid] < 2) d.nd_ncand[nid] = 0;
+                else cls = node_class(d.nd_n[nid], d.seq_len[d.nd_seq[nid]], d.nd_nbr[nid]);
+            }
             else { d.nd_canon[nid] = canon; aliases++; }
         }
         for (int c = 0; c < NCLS; c++) {
