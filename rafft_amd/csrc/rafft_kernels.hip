@@ -281,7 +281,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         //  - tiny FFT sizes (P <= 128) and the debug seam, which reports the ranking, sort all keys in place.
         const bool dbgrank = d.dbg.lag != nullptr;
         const bool ranked = m > Kp;
-        const bool selected = ranked && P >= 256;
+        const bool selected = ranked && P >= 128;
         const bool inplace = (ranked && !selected) || (dbgrank && !selected);    // keys sorted in place, rk[] in rank order
         double *keyv = (double *)(lds + lay.offA);
         uint16_t *lagk = (uint16_t *)(lds + lay.offA + 8 * P);
