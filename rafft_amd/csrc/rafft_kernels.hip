@@ -621,6 +621,8 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         }
         __syncthreads();
         const BrPrefix pf{pe_ext, pe_ml, psp};
+        const BrList all_br{brl, 0, nbr, 0, 0, 0, 0, 0};
+        const int e_old = loop_energy_pre(T, B, Sl, L, ci, cj, all_br, pf);      // the loop as it is (same for every stem)
         for (int rep_ = 0; rep_ < 1 + ((d.rep >> 3) & 1); rep_++)
             for (int r = tid; r < Kp; r += NT) {
                 const int nb = wnb[r];
@@ -629,26 +631,25 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                 if (nb > 0) {
                     const int mi = wmi[r], mj = wmj[r];
                     const int a0 = pos[mi], b0 = pos[mj], ao = pos[mi - nb + 1], bo = pos[mj + nb - 1];
-                    BrList all{brl, 0, nbr, 0, 0, 0, 0, 0};
-                    const int e_old = loop_energy_pre(T, B, Sl, L, ci, cj, all, pf);
                     int lo = br_lower(brl, nbr, a0), hi = br_lower(brl, nbr, b0);
                     const int lo_o = br_lower(brl, nbr, ao), hi_o = br_lower(brl, nbr, bo);
                     BrList outer{brl, 0, lo_o, hi_o, nbr, 1, ao, bo};
                     int e_new = loop_energy_pre(T, B, Sl, L, ci, cj, outer, pf);
                     BrList inner{brl, lo, hi, 0, 0, 0, 0, 0};
                     e_new += loop_energy_pre(T, B, Sl, L, a0, b0, inner, pf);
-                    int pa = a0, pb = b0;
+                    int pa = a0, pb = b0, ty_in = pair_type(Sl[a0], Sl[b0]);
                     for (int t = 1; t < nb; t++) {
                         const int a = pos[mi - t], b = pos[mj + t];
+                        const int ty = pair_type(Sl[a], Sl[b]);
                         if (pa == a + 1 && pb == b - 1)
-                            e_new += T->stack[pair_type(Sl[a], Sl[b])][rtype(pair_type(Sl[pa], Sl[pb]))];
+                            e_new += T->stack[ty][rtype(ty_in)];
                         else {
                             const int lo2 = br_lower(brl, nbr, a), hi2 = br_lower(brl, nbr, b);
                             BrList mid{brl, lo2, lo, hi, hi2, 1, pa, pb};
                             e_new += loop_energy_pre(T, B, Sl, L, a, b, mid, pf);
                             lo = lo2; hi = hi2;
                         }
-                        pa = a; pb = b;
+                        pa = a; pb = b; ty_in = ty;
                     }
                     const int ddc = e_new - e_old;
                     dd[r] = ddc;
