@@ -196,6 +196,10 @@ int class_cfg(int K, int maxL, ClsCfg out[NCLS])
         int nmax = P[c] / 2;
         int Kmax = std::max(1, std::min(K, P[c] - 1));
         ExpandLds l = expand_lds(P[c], LM[c], nmax, BR[c], Kmax, TAB[c]);
+        // region A is time-shared: behind the fp64 lag values (8 P bytes) it must still hold the branch prefix sums
+        // (10 bytes per branch), the select histogram and the window_slide scratch of this class
+        if (c >= 1 && (10 * (BR[c] + 1) + 16 > 8 * P[c] || 2 * P[c] + 1152 + 16 > 8 * P[c] || (NT[c] > 64 && NT[c] * 24 > 8 * P[c])))
+            return fail(RAFFT_ERR_PARAM, "internal: expand LDS plan does not fit its size class");
         int per_cu = std::max(1, std::min(32 / (NT[c] / 64), (160 * 1024) / l.total));
         out[c] = {NT[c], P[c], LM[c], nmax, BR[c], Kmax, l.total, g.n_cu * per_cu, TAB[c]};
         // a size class that no region of this batch can reach need not fit (class 3 needs n > 1024)

@@ -221,18 +221,40 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                 z2[t] = make_float2(c == 4 ? 1.f : 0.f, c == 2 ? 1.f : 0.f); // U + iC
             }
             __syncthreads();
-            for (int s = P >> 1; s >= 1; s >>= 1) {       // DIF, natural in -> bit-reversed out
-                const int tws = (twN / 2) / s;
+            // DIF, natural in -> bit-reversed out.  Two radix-2 stages (spans s and s/2) are done per pass on four
+            // elements held in registers: the same operations in the same order as stage by stage (bit-identical
+            // results), half the LDS traffic and barriers.
+            auto add2 = [](float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); };
+            auto sub2 = [](float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); };
+            int s = P >> 1;
+            for (; s >= 2; s >>= 2) {
+                const int h = s >> 1, tws = (twN / 2) / s;
+                for (int b = tid; b < (P >> 2); b += NT) {
+                    const int off = b & (h - 1);
+                    const int j = ((b - off) << 2) + off;          // j mod 2s < s/2
+                    const float2 w1a = tw[off * tws], w1b = tw[(off + h) * tws], w2 = tw[off * 2 * tws];
+                    {
+                        const float2 x0 = z1[j], x1 = z1[j + h], x2 = z1[j + s], x3 = z1[j + s + h];
+                        const float2 a0 = add2(x0, x2), a2 = cmul(sub2(x0, x2), w1a), a1 = add2(x1, x3), a3 = cmul(sub2(x1, x3), w1b);
+                        z1[j] = add2(a0, a1); z1[j + h] = cmul(sub2(a0, a1), w2);
+                        z1[j + s] = add2(a2, a3); z1[j + s + h] = cmul(sub2(a2, a3), w2);
+                    }
+                    {
+                        const float2 x0 = z2[j], x1 = z2[j + h], x2 = z2[j + s], x3 = z2[j + s + h];
+                        const float2 a0 = add2(x0, x2), a2 = cmul(sub2(x0, x2), w1a), a1 = add2(x1, x3), a3 = cmul(sub2(x1, x3), w1b);
+                        z2[j] = add2(a0, a1); z2[j + h] = cmul(sub2(a0, a1), w2);
+                        z2[j + s] = add2(a2, a3); z2[j + s + h] = cmul(sub2(a2, a3), w2);
+                    }
+                }
+                __syncthreads();
+            }
+            if (s == 1) {                                           // odd number of stages: the last one alone
                 for (int b = tid; b < (P >> 1); b += NT) {
-                    int off = b & (s - 1);
-                    int j = ((b - off) << 1) + off;
-                    float2 w = tw[off * tws];
-                    float2 a = z1[j], bb = z1[j + s];
-                    z1[j] = make_float2(a.x + bb.x, a.y + bb.y);
-                    z1[j + s] = cmul(make_float2(a.x - bb.x, a.y - bb.y), w);
-                    a = z2[j]; bb = z2[j + s];
-                    z2[j] = make_float2(a.x + bb.x, a.y + bb.y);
-                    z2[j + s] = cmul(make_float2(a.x - bb.x, a.y - bb.y), w);
+                    const int j = b << 1;
+                    float2 a = z1[j], bb = z1[j + 1];
+                    z1[j] = add2(a, bb); z1[j + 1] = cmul(sub2(a, bb), tw[0]);
+                    a = z2[j]; bb = z2[j + 1];
+                    z2[j] = add2(a, bb); z2[j + 1] = cmul(sub2(a, bb), tw[0]);
                 }
                 __syncthreads();
             }
@@ -254,18 +276,39 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                 }
             }
             __syncthreads();
-            for (int s = 1; s < P; s <<= 1) {             // DIT inverse, bit-reversed in -> natural out
-                const int tws = (twN / 2) / s;
+            // DIT inverse, bit-reversed in -> natural out; again two stages (spans s and 2s) per pass
+            int si = 1;
+            if (logP & 1) {                                         // odd number of stages: the first one alone
                 for (int b = tid; b < (P >> 1); b += NT) {
-                    int off = b & (s - 1);
-                    int j = ((b - off) << 1) + off;
-                    float2 w = tw[off * tws];
-                    float2 a = z1[j], bb = cmulc(z1[j + s], w);
-                    z1[j] = make_float2(a.x + bb.x, a.y + bb.y);
-                    z1[j + s] = make_float2(a.x - bb.x, a.y - bb.y);
-                    a = z2[j]; bb = cmulc(z2[j + s], w);
-                    z2[j] = make_float2(a.x + bb.x, a.y + bb.y);
-                    z2[j + s] = make_float2(a.x - bb.x, a.y - bb.y);
+                    const int j = b << 1;
+                    float2 a = z1[j], bb = cmulc(z1[j + 1], tw[0]);
+                    z1[j] = add2(a, bb); z1[j + 1] = sub2(a, bb);
+                    a = z2[j]; bb = cmulc(z2[j + 1], tw[0]);
+                    z2[j] = add2(a, bb); z2[j + 1] = sub2(a, bb);
+                }
+                __syncthreads();
+                si = 2;
+            }
+            for (; si < P; si <<= 2) {
+                const int s1 = si, s2 = si << 1, tws = (twN / 2) / s1;
+                for (int b = tid; b < (P >> 2); b += NT) {
+                    const int off = b & (s1 - 1);
+                    const int j = ((b - off) << 2) + off;          // j mod 4 s1 < s1
+                    const float2 w1 = tw[off * tws], w2a = tw[off * (tws >> 1)], w2b = tw[(off + s1) * (tws >> 1)];
+                    {
+                        const float2 x0 = z1[j], x2 = z1[j + s2];
+                        const float2 t1 = cmulc(z1[j + s1], w1), t3 = cmulc(z1[j + s2 + s1], w1);
+                        const float2 y0 = add2(x0, t1), y1 = sub2(x0, t1), y2 = add2(x2, t3), y3 = sub2(x2, t3);
+                        const float2 u2 = cmulc(y2, w2a), u3 = cmulc(y3, w2b);
+                        z1[j] = add2(y0, u2); z1[j + s2] = sub2(y0, u2); z1[j + s1] = add2(y1, u3); z1[j + s2 + s1] = sub2(y1, u3);
+                    }
+                    {
+                        const float2 x0 = z2[j], x2 = z2[j + s2];
+                        const float2 t1 = cmulc(z2[j + s1], w1), t3 = cmulc(z2[j + s2 + s1], w1);
+                        const float2 y0 = add2(x0, t1), y1 = sub2(x0, t1), y2 = add2(x2, t3), y3 = sub2(x2, t3);
+                        const float2 u2 = cmulc(y2, w2a), u3 = cmulc(y3, w2b);
+                        z2[j] = add2(y0, u2); z2[j + s2] = sub2(y0, u2); z2[j + s1] = add2(y1, u3); z2[j + s2 + s1] = sub2(y1, u3);
+                    }
                 }
                 __syncthreads();
             }
