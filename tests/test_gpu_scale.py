@@ -119,3 +119,18 @@ def test_gpu_non_integer_weights_match_oracle():
     for s, (fin, traj) in zip(seqs, res):
         _, o = oracle.fold(s, 60, 10, 1000, gc_wei=2.7, au_wei=1.9, gu_wei=0.65, traj=True)
         assert [[(x.str_struct, x.dcal) for x in st] for st in traj] == [[(x.str_struct, x.dcal) for x in st] for st in o]
+
+
+def test_gpu_batch_composition_does_not_change_results(bench_rows):
+    """folds are independent: a sequence gives the same trajectory alone, inside a small batch, inside a batch that
+    holds every sequence twice, and in reversed batch order (region memoization, arena sharding and the flat
+    product walk must not leak between sequences)"""
+    seqs = [r["seq"] for r in bench_rows[::23]][:60]
+    base = rafft_amd.fold_batch(seqs, 100, 12, 300, traj=True)
+    twice = rafft_amd.fold_batch(seqs + seqs, 100, 12, 300, traj=True)
+    rev = rafft_amd.fold_batch(seqs[::-1], 100, 12, 300, traj=True)[::-1]
+    def key(res):
+        return [[[(s.str_struct, s.dcal) for s in st] for st in traj] for _, traj in res]
+    assert key(twice[:len(seqs)]) == key(base) and key(twice[len(seqs):]) == key(base) and key(rev) == key(base)
+    for k in (0, 17, 41):
+        assert key([rafft_amd.fold(seqs[k], 100, 12, 300, traj=True)]) == key(base[k:k + 1])
