@@ -79,7 +79,7 @@ struct Dev {
     int S;
     const uint8_t *codes;
     const int *seq_off, *seq_len;
-    int K, B, max_branch, min_hp, traj, memo, force_fft, rl_cap, mat_tile;
+    int K, B, max_branch, min_hp, traj, memo, force_fft, rl_cap, mat_tile, merge_cls;
     double min_nrj, gc, au, gu;
     int *beam, *beam_n, *done, *nsteps;
     // children of the current step
@@ -135,8 +135,12 @@ struct Dev {
 #define RL_CAP 1024        // beam_step_kernel: regions with >= 2 candidates of all beam members, kept in LDS
 
 __host__ __device__ inline int next_pow2_ge(int x) { int p = 2; while (p < x) p <<= 1; return p; }
-__host__ __device__ inline int node_class(int n, int L, int nbr)
+__host__ __device__ inline int node_class(int n, int L, int nbr, int merge_cls = 0)
 {
+    // few regions in this step (the tail of a batch): all of them go to one kernel, the widest one that is
+    // configured - one launch and one region per workgroup instead of three nearly empty kernels in a row
+    if (merge_cls == 3) return 3;
+    if (merge_cls == 2) return next_pow2_ge(2 * n - 1) <= CLS2_P ? 2 : 3;
     int P = next_pow2_ge(2 * n - 1);
     // class 0 is kept empty: measured on MI355X, running the tiny regions (P <= 128) in their own
     // persistent kernel beside class 1 oversubscribes the wave slots and is slower than one kernel

@@ -1655,7 +1655,7 @@ __global__ __launch_bounds__(256) void dedupe_kernel(Dev d)
             if (canon == nid) {
                 // a stem needs two unpaired positions: a lone position (bulge remnant) has no candidates
                 if (d.nd_n[nid] < 2) d.nd_ncand[nid] = 0;
-                else cls = node_class(d.nd_n[nid], d.seq_len[d.nd_seq[nid]], d.nd_nbr[nid]);
+                else cls = node_class(d.nd_n[nid], d.seq_len[d.nd_seq[nid]], d.nd_nbr[nid], d.merge_cls);
             }
             else { d.nd_canon[nid] = canon; aliases++; }
         }

@@ -19,6 +19,17 @@ def as_lists(traj):
     return [[[s.str_struct, s.dcal] for s in st] for st in traj]
 
 
+@pytest.fixture(autouse=True, params=["classes_by_size", "classes_merged"])
+def expand_class_routing(request, monkeypatch):
+    """Steps with few new structures send all their regions to one wide expand kernel (the tail of a big batch;
+    every step of the small batches in this file).  Each test runs both ways, so that the one-wavefront kernel
+    (popcount correlation, bit-mask window_slide) and the wide kernels see the same cases."""
+    if request.param == "classes_by_size":
+        monkeypatch.setenv("RAFFT_MERGE_BELOW", "0")
+        monkeypatch.setenv("RAFFT_MERGE2_BELOW", "0")
+    yield
+
+
 def test_gpu_energy_kats_exact(energy_kats):
     """Device Turner-2004 evaluator == the reference's 11 505 published energies (exact dcal)."""
     seqs = [k[0] for k in energy_kats]
