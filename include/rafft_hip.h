@@ -72,7 +72,10 @@ typedef struct {
 } rafft_result;
 
 /* Kernel timing / traffic counters of the last rafft_fold_batch() on this thread's
- * device (HIP events on the library's own stream). */
+ * device (HIP events on the library's own stream).  Timing events are not free (a pair around every
+ * kernel costs ~7 % of a benchmark batch), so by default only ms_total and ms_expand are measured;
+ * the other ms_* fields are filled when the environment has RAFFT_SPANS=2 (or RAFFT_TRACE) at the
+ * time of the call, and stay 0 otherwise.  RAFFT_SPANS=0 switches ms_expand off as well. */
 typedef struct {
     double ms_total;          /* wall time of the call, host side */
     double ms_expand;         /* sum of expand_kernel<64,false> durations (regions with FFT size P <= 512;
@@ -80,11 +83,12 @@ typedef struct {
     double ms_expand_c1;      /* experimental tiny-region class (receives no work) */
     double ms_expand_c2;      /* expand_kernel<256,false> (512 < P <= 2048), runs concurrently */
     double ms_expand_c3;      /* expand_kernel<512,false> (P > 2048), runs concurrently */
-    double ms_expand_wall;    /* fork->join wall time of the three concurrent expand launches */
+    double ms_expand_wall;    /* fork->join wall time of the concurrent expand launches of every step */
     double ms_beam;           /* sum of beam-step kernel durations */
     double ms_materialize;    /* sum of materialize kernel durations */
     double ms_output;         /* output formatting kernel */
-    int64_t n_expand_launches;
+    int64_t n_expand_launches; /* launches of the dominant kernel, expand_kernel<64,false> (steps with few new structures
+                                 send their regions to one of the wide kernels instead) */
     int64_t n_steps;          /* folding steps executed (max over sequences) */
     int64_t n_node_expansions;/* regions really expanded (identical loops are expanded once) */
     int64_t n_nodes_created;  /* (structure,node) pairs created, incl. aliases of known loops */

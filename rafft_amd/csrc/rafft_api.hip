@@ -244,6 +244,12 @@ hipEvent_t next_event(Workspace &w)
 }
 
 struct Span { hipEvent_t a, b; int kind; };
+// Timing events are not free: a pair around every kernel costs ~1.3 ms of the 17 ms benchmark batch (the markers
+// serialise the queues).  Level 1 (default) times only the dominant kernel - the one-wavefront expand class, what
+// the roofline is computed from; level 2 (RAFFT_SPANS=2 or RAFFT_TRACE) times every stage; level 0 none.
+static int g_span_level = 1;
+static inline bool span_on(int kind) { return g_span_level >= 2 || (g_span_level == 1 && kind == 11); }
+#define SPAN_REC(ev, st, kind) do { if (span_on(kind)) HIPCHK(hipEventRecord((ev), (st))); } while (0)
 
 // base codes of rafft/utils.py:73-80 (N=0 A=1 C=2 G=3 U=4); bit 3 marks a character outside "AGCUN"
 struct BaseCodeTable {
@@ -520,14 +526,15 @@ int Wave::issue_step()
     const size_t hot_len = offsetof(Counters, node);
     HIPCHK(hipEventRecord(g.ev_fork, st));
     Span wall{next_event(), next_event(), 4};
-    HIPCHK(hipEventRecord(wall.a, st));
+    SPAN_REC(wall.a, st, 4);
     for (int cls = NCLS - 1; cls >= 1; cls--) {   // big-LDS classes first; class 0 is unused (node_class)
         if (merged_now == 3 && cls != 3) continue;               // the dedupe of the last step sent everything to one class
         if (merged_now == 2 && cls == 1) continue;               // ... or the one-wavefront class to the 256-thread one
-        hipStream_t cs = serial ? st : g.cls_stream[cls];
-        if (!serial) HIPCHK(hipStreamWaitEvent(cs, g.ev_fork, 0));
+        const bool inline_ = serial || merged_now == 3;          // a single kernel: no fork/join through another stream
+        hipStream_t cs = inline_ ? st : g.cls_stream[cls];
+        if (!inline_) HIPCHK(hipStreamWaitEvent(cs, g.ev_fork, 0));
         Span sp{next_event(), next_event(), 10 + cls};
-        HIPCHK(hipEventRecord(sp.a, cs));
+        SPAN_REC(sp.a, cs, sp.kind);
         // persistent workgroups loop over the work list, so any grid is correct: when few structures were
         // materialized (the tail of a batch) a small grid avoids dispatching thousands of empty workgroups
         unsigned grid = (unsigned)cf[cls].grid;
@@ -536,26 +543,26 @@ int Wave::issue_step()
             if (bound < grid) grid = (unsigned)bound;
         }
         if (int rc = launch_expand_cls(d, cls, cf, grid, cs)) return rc;
-        HIPCHK(hipEventRecord(sp.b, cs));
+        if (cls == 1) ::g.stats.n_expand_launches++;       // launches of the dominant kernel (ms_expand is their sum)
+        SPAN_REC(sp.b, cs, sp.kind);
         spans.push_back(sp);
-        if (!serial) {
+        if (!inline_) {
             HIPCHK(hipEventRecord(g.ev_join[cls], cs));
             HIPCHK(hipStreamWaitEvent(st, g.ev_join[cls], 0));
         }
     }
-    HIPCHK(hipEventRecord(wall.b, st));
+    SPAN_REC(wall.b, st, 4);
     spans.push_back(wall);
-    ::g.stats.n_expand_launches++;
     HIPCHK(hipMemsetAsync((char *)g.counters.p + cnt_work_off, 0, cnt_work_len, st));
     {
         Span sp{next_event(), next_event(), 1};
-        HIPCHK(hipEventRecord(sp.a, st));
+        SPAN_REC(sp.a, st, sp.kind);
         // few sequences left (the long ones): a 1024-thread workgroup per sequence shortens the serial
         // chains (16 wavefronts for the prepass, 1024 combos per chunk); many sequences: 256 threads
         if (n_active < wide_below) hipLaunchKernelGGL(beam_step_kernel<1024>, dim3((unsigned)S), dim3(1024), bs_lds[1], st, d, c.sort_cap);
         else hipLaunchKernelGGL(beam_step_kernel<256>, dim3((unsigned)S), dim3(256), bs_lds[0], st, d, c.sort_cap);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(sp.b, st));
+        SPAN_REC(sp.b, st, sp.kind);
         spans.push_back(sp);
     }
     steps++;
@@ -576,7 +583,7 @@ int Wave::after_beam()
     last_mat = hc.n_mat;
     {
         Span sp{next_event(), next_event(), 2};
-        HIPCHK(hipEventRecord(sp.a, st));
+        SPAN_REC(sp.a, st, sp.kind);
         hipLaunchKernelGGL(materialize_kernel, dim3(hc.n_mat), dim3(MAT_NT), 0, st, d);
         HIPCHK(hipGetLastError());
         // tail of the batch: so few new structures that their regions fit one wave of workgroups of the widest class
@@ -587,7 +594,7 @@ int Wave::after_beam()
         merged_now = d.merge_cls;
         hipLaunchKernelGGL(dedupe_kernel, dim3(::g.n_cu * 4), dim3(256), 0, st, d);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(sp.b, st));
+        SPAN_REC(sp.b, st, sp.kind);
         spans.push_back(sp);
     }
     if (const char *tr = getenv("RAFFT_TRACE")) if (atoi(tr) >= 2) {
@@ -676,12 +683,12 @@ int Wave::finish()
         if (int rc = ensure(g.out_dcal, nrows * 4)) return rc;
         HIPCHK(hipMemcpyAsync(g.row_off.p, recs.data(), recs.size() * sizeof(OutRec), hipMemcpyHostToDevice, st));
         Span sp{next_event(), next_event(), 3};
-        HIPCHK(hipEventRecord(sp.a, st));
+        SPAN_REC(sp.a, st, sp.kind);
         unsigned grid = (unsigned)std::min<size_t>(nrows, 65536);
         hipLaunchKernelGGL(output_kernel, dim3(grid), dim3(64), 0, st, d, (int)nrows, (int)recs.size(), (const OutRec *)g.row_off.p,
                            (char *)g.out_db.p, (int *)g.out_dcal.p);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(sp.b, st));
+        SPAN_REC(sp.b, st, sp.kind);
         spans.push_back(sp);
         HIPCHK(hipMemcpyAsync(all_db, g.out_db.p, (size_t)tot_bytes, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(all_dcal, g.out_dcal.p, nrows * 4, hipMemcpyDeviceToHost, st));
@@ -881,6 +888,7 @@ int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs, 
     if (int rc = init_ctx(device)) return rc;
     auto t0 = std::chrono::steady_clock::now();
     memset(&g.stats, 0, sizeof g.stats);
+    g_span_level = getenv("RAFFT_TRACE") ? 2 : getenv("RAFFT_SPANS") ? atoi(getenv("RAFFT_SPANS")) : 1;
     HostOut *ho = new HostOut();
     ho->seq.resize(n_seq); ho->step_size.resize(n_seq); ho->step_off.resize(n_seq);
     ho->dcal_ptr.assign(n_seq, nullptr); ho->db_ptr.assign(n_seq, nullptr);
@@ -953,7 +961,7 @@ int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs, 
         int stepno = 0;
         for (auto &sp : spans) {
             float ms = 0;
-            if (hipEventElapsedTime(&ms, sp.a, sp.b) != hipSuccess) continue;
+            if (!span_on(sp.kind) || hipEventElapsedTime(&ms, sp.a, sp.b) != hipSuccess) continue;
             if (sp.kind < 16) acc[sp.kind] += ms;
             if (sp.kind == 1) {        // the beam step closes a folding step (materialize of it follows)
                 fprintf(stderr, "[rafft] t-step %2d: expand wall %.3f (c1 %.3f c2 %.3f c3 %.3f) beam %.3f  prev-materialize %.3f\n",
@@ -964,7 +972,7 @@ int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs, 
     }
     for (auto &sp : spans) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+        if (span_on(sp.kind) && hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
             if (sp.kind == 10) g.stats.ms_expand_c1 += ms;   /* class 0: unused */
             else if (sp.kind == 11) g.stats.ms_expand += ms;   /* dominant kernel: regions with P <= 512 */
             else if (sp.kind == 12) g.stats.ms_expand_c2 += ms;
