@@ -1,14 +1,16 @@
 // rafft_kernels.hip - the HIP kernels of the fold hot path (gfx950 / MI355X only).
 //
 //   expand_kernel       persistent workgroups (one wavefront for the common size class)
-//                       fetch unpaired regions from a work list: LDS-resident packed
-//                       complex FFT correlation (rafft/utils.py:115-132), lag ranking
-//                       (rafft/rafft.py:117-118,92), window_slide (rafft/rafft.py:36-83),
-//                       local Turner dE of every candidate stem from the loop's branch
-//                       list + filter/sort (rafft/rafft.py:86-109)
-//   beam_step_kernel    one workgroup per sequence: helix combination in product
-//                       order with `seen` dedupe and the max_branch rule, stable
-//                       energy sort and beam cut (rafft/rafft.py:176-214)
+//                       fetch unpaired regions from a work list: correlation of the region
+//                       with itself (rafft/utils.py:115-132; popcounts on bit masks for short
+//                       regions, LDS-resident packed complex FFTs otherwise), selection of the
+//                       nb_mode best lags (rafft/rafft.py:117-118,92), window_slide
+//                       (rafft/rafft.py:36-83), local Turner dE of every candidate stem from
+//                       prefix sums over the loop's branch list + filter/sort
+//                       (rafft/rafft.py:86-109)
+//   beam_step_kernel    one workgroup per sequence: helix combination in product order, flat
+//                       over all parents of the beam, with `seen` dedupe and the max_branch
+//                       rule, stable energy sort and beam cut (rafft/rafft.py:176-214)
 //   materialize_kernel  one wavefront per new beam member: dot-bracket row + child
 //                       regions (rafft/rafft.py:127-152, rafft/utils.py:141-152)
 //   dedupe_kernel       identical loops reached through different structures share one
