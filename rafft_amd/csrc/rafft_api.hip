@@ -521,8 +521,6 @@ int Wave::issue_step()
     hipStream_t st = g.stream;
     static const unsigned wide_below = getenv("RAFFT_WIDE_BELOW") ? (unsigned)atoi(getenv("RAFFT_WIDE_BELOW")) : 600u;
     static const bool serial = getenv("RAFFT_SERIAL") && atoi(getenv("RAFFT_SERIAL"));
-    const size_t cnt_work_off = offsetof(Counters, n_work);
-    const size_t cnt_work_len = offsetof(Counters, overflow) - cnt_work_off;   // n_work[], n_mat, next_work[]
     const size_t hot_len = offsetof(Counters, node);
     HIPCHK(hipEventRecord(g.ev_fork, st));
     Span wall{next_event(), next_event(), 4};
@@ -553,7 +551,6 @@ int Wave::issue_step()
     }
     SPAN_REC(wall.b, st, 4);
     spans.push_back(wall);
-    HIPCHK(hipMemsetAsync((char *)g.counters.p + cnt_work_off, 0, cnt_work_len, st));
     {
         Span sp{next_event(), next_event(), 1};
         SPAN_REC(sp.a, st, sp.kind);

@@ -154,6 +154,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         wtab[tid] = (tp == 5 || tp == 6) ? d.au : (tp == 1 || tp == 2) ? d.gc : (tp == 3 || tp == 4) ? d.gu : 0.0;
     }
     const unsigned n_items = d.c->n_work[cls];
+    if (blockIdx.x == 0 && tid == 0) d.c->n_mat = 0;           // the beam step that follows counts its new structures here
     const int shard = blockIdx.x & (NSHARD - 1);
     unsigned long long st_items = 0, st_n = 0, st_lags = 0, st_nbr = 0;   // per-block statistics
 
@@ -890,6 +891,8 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
     const int sq = blockIdx.x;
     // snapshot of the region allocators: whatever materialize adds after this kernel is "new"
     if (sq == 0 && tid < NSHARD) d.c->node_prev[tid].v = d.c->node[tid].v;
+    // the expand kernels of this step are done with their work lists: reset them for dedupe_kernel / the next step
+    if (sq == 0 && tid < NCLS) { d.c->n_work[tid] = 0; d.c->next_work[tid] = 0; }
     if (d.done[sq]) return;
     const bool prof = d.prof && sq == d.prof_seq && tid == 0;   // diagnostic stamps (RAFFT_TRACE=3)
     unsigned long long tprev = prof ? clock64() : 0;
