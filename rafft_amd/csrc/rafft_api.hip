@@ -585,8 +585,8 @@ int Wave::after_beam()
         HIPCHK(hipGetLastError());
         // tail of the batch: so few new structures that their regions fit one wave of workgroups of the widest class
         // (measured on the benchmark batch: 18.8 -> 17.3 ms; thresholds in new structures per step, per CU)
-        const unsigned merge_below = getenv("RAFFT_MERGE_BELOW") ? (unsigned)atoi(getenv("RAFFT_MERGE_BELOW")) : 8u * (unsigned)::g.n_cu;
-        const unsigned merge2_below = getenv("RAFFT_MERGE2_BELOW") ? (unsigned)atoi(getenv("RAFFT_MERGE2_BELOW")) : 32u * (unsigned)::g.n_cu;
+        const unsigned merge_below = getenv("RAFFT_MERGE_BELOW") ? (unsigned)atoi(getenv("RAFFT_MERGE_BELOW")) : 16u * (unsigned)::g.n_cu;
+        const unsigned merge2_below = getenv("RAFFT_MERGE2_BELOW") ? (unsigned)atoi(getenv("RAFFT_MERGE2_BELOW")) : 128u * (unsigned)::g.n_cu;
         d.merge_cls = seam ? 0 : hc.n_mat < merge_below ? merge_target : hc.n_mat < merge2_below ? 2 : 0;
         merged_now = d.merge_cls;
         hipLaunchKernelGGL(dedupe_kernel, dim3(::g.n_cu * 4), dim3(256), 0, st, d);
