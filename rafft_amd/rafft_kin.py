@@ -7,7 +7,6 @@ from copy import deepcopy
 
 import numpy as np
 from numpy import array, diag, exp, zeros
-from scipy.linalg import eig, inv
 
 from .utils import paired_positions
 
@@ -61,6 +60,7 @@ def kinetics(fast_paths, max_time, n_steps, initial_pop=None):
     """Master-equation populations on the fast-folding graph; same contract as the reference's
     `kinetics` (rafft_kin.py:94-150): returns (trajectory, times, struct_list, str_equi_pop) with
     trajectory[0] the initial population and n_steps rows at times exp(k * max_time / n_steps - 4)."""
+    from scipy.linalg import eig, inv      # imported here: SciPy costs 0.3 s at start-up, the fold CLI never needs it
     struct_list, index = unique_structures(fast_paths)
     struct_map = {st.str_struct: (index[st.str_struct], st.energy) for st in struct_list}
     nb_struct = len(struct_list)
