@@ -101,6 +101,7 @@ typedef struct {
     int64_t alg_bytes;        /* algorithmic HBM bytes, SURVEY.md section 8d formula */
     int64_t alg_bytes_expand; /* the part of the dominant kernel expand_kernel<64> (its regions; 3L per structure pro rata) */
     int64_t alg_bytes_expand_all; /* all three expand size classes */
+    int64_t n_regrows;        /* times a wave of the call overflowed its HBM arenas and was re-run with larger ones */
 } rafft_stats;
 
 /* Select the GPU (HIP ordinal) and upload the energy tables.  Optional: every other

@@ -368,7 +368,7 @@ struct Wave {
     bool finished = false;
     int result = 0;               // valid when finished: 0, RAFFT_ERR_CAPACITY (regrow) or a hard error
     std::chrono::steady_clock::time_point tw0, tw1;
-    double ms_setup = 0;
+    double ms_setup = 0, ms_issue = 0, ms_after = 0;   // host time inside issue_step / after_beam (trace)
 
     Wave(Workspace &w, const rafft_params &pp, std::vector<SeqIn> s, double e, HostOut &o, std::vector<Span> &sp, const SeamIn *sm = nullptr)
         : g(w), p(pp), seqs(std::move(s)), est(e), out(o), spans(sp), seam(sm) {}
@@ -518,6 +518,8 @@ int Wave::setup()
 // expand (three size classes on their own streams) -> beam step -> asynchronous read-back of the hot counters
 int Wave::issue_step()
 {
+    const auto t_in = std::chrono::steady_clock::now();
+    struct Acc { double &a; std::chrono::steady_clock::time_point t; ~Acc() { a += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); } } acc_{ms_issue, t_in};
     hipStream_t st = g.stream;
     static const unsigned wide_below = getenv("RAFFT_WIDE_BELOW") ? (unsigned)atoi(getenv("RAFFT_WIDE_BELOW")) : 600u;
     static const bool serial = getenv("RAFFT_SERIAL") && atoi(getenv("RAFFT_SERIAL"));
@@ -526,6 +528,7 @@ int Wave::issue_step()
     Span wall{next_event(), next_event(), 4};
     SPAN_REC(wall.a, st, 4);
     for (int cls = NCLS - 1; cls >= 1; cls--) {   // big-LDS classes first; class 0 is unused (node_class)
+        if (cls == 3 && merge_target == 2) continue;             // no sequence long enough for a region of that class
         if (merged_now == 3 && cls != 3) continue;               // the dedupe of the last step sent everything to one class
         if (merged_now == 2 && cls == 1) continue;               // ... or the one-wavefront class to the 256-thread one
         const bool inline_ = serial || merged_now == 3;          // a single kernel: no fork/join through another stream
@@ -571,6 +574,8 @@ int Wave::issue_step()
 // the beam step of this wave has finished: stop, or materialize the new beam members and go on
 int Wave::after_beam()
 {
+    const auto t_in = std::chrono::steady_clock::now();
+    struct Acc { double &a; std::chrono::steady_clock::time_point t; ~Acc() { a += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); } } acc_{ms_after, t_in};
     hipStream_t st = g.stream;
     const size_t hot_len = offsetof(Counters, node);
     memcpy(&hc, g.hot, hot_len);
@@ -757,6 +762,7 @@ int Wave::finish()
                 br.first, (unsigned long long)d.br_shard_cap, br.second, db.first, (unsigned long long)d.db_shard_cap,
                 ca.first, (unsigned long long)d.cand_shard_cap, ca.second, pr.first, (unsigned long long)d.prod_shard_cap, hc.seen_top, c.seen, est);
     }
+    if (getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] host time inside issue_step %.3f ms, inside after_beam (incl. nested issue_step and this tail) %.3f ms\n", ms_issue, ms_after);
     if (getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] wave S=%zu setup %.2f ms, loop %.2f ms (%d steps), tail %.2f ms (counters %.3f, records+gather %.3f, rows out %.3f incl. %.1f MB D2H)\n",
                                        S, ms_setup, ms_loop, steps, since(tw2), tl_stats, tl_gather - tl_stats, tl_copy - tl_gather, (double)tot_bytes / 1e6);
     return result = 0;
@@ -835,6 +841,7 @@ int run_pipelines(const rafft_params &p, std::vector<std::deque<Job>> &queues, H
                     if (rc == RAFFT_ERR_CAPACITY) {
                         if (curjob[i].depth >= 12)
                             return fail(RAFFT_ERR_CAPACITY, "HBM arena overflow after 12 regrowths (bits " + std::to_string(cur[i]->ovf) + ")");
+                        ::g.stats.n_regrows++;
                         Job again{std::move(curjob[i].seqs), curjob[i].est * (curjob[i].depth >= 2 ? 4.0 : 2.0), curjob[i].depth + 1};
                         queues[i].push_front(std::move(again));
                     } else if (rc)

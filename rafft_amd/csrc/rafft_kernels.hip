@@ -955,7 +955,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
                 // first visit of this structure: its productive regions (node order, rafft/rafft.py:166-171) are
                 // written once as a compact list that later product walks and materialize_kernel read back
                 if (gl == 0) {
-                    const int shd = sq & (NSHARD - 1);
+                    const int shd = (sq + b) & (NSHARD - 1);       // (members of one sequence spread over the sub-arenas)
                     pbase = atomicAdd(&d.c->prod[shd].v, (unsigned long long)nn);
                     if (pbase + nn > d.prod_shard_cap) { atomicOr(&d.c->overflow, OVF_PRODLIST); pbase = ~0ULL; }
                     else pbase += (unsigned long long)shd * d.prod_shard_cap;

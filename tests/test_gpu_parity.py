@@ -131,6 +131,16 @@ def test_gpu_arena_overflow_regrows_and_stays_exact(monkeypatch):
         assert as_lists(t1) == as_lists(t2)
 
 
+def test_gpu_single_sequences_need_no_regrowth():
+    """the arena planner must hold for the smallest batch too (one sequence lands on few sub-arenas): a lone
+    sequence of any length folds in one go - a regrowth would silently triple the latency of the CLI"""
+    rng = np.random.default_rng(8)
+    for L, ms in ((60, 50), (600, 50), (1500, 20), (2500, 50)):
+        s = "".join(rng.choice(list("ACGU"), L))
+        fin = rafft_amd.fold(s, 100, ms, 1000)
+        assert 1 <= len(fin) <= ms and rafft_amd.last_stats()["n_regrows"] == 0, (L, ms, rafft_amd.last_stats())
+
+
 def test_gpu_fft_and_direct_correlation_agree(monkeypatch, node_records):
     """short regions use the popcount form, long ones the LDS FFT; forcing the FFT everywhere must not
     change a single lag value, rank or trajectory"""
