@@ -389,6 +389,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
             };
             unsigned long long prefix = 0;
             int kk = Kp;
+            bool take_ge = false;          // every key >= prefix is selected (the threshold fell between two values)
             for (int pass = 7; pass >= 0; pass--) {
                 for (int i = tid; i < 256; i += NT) hist[i] = 0;
                 __syncthreads();
@@ -407,14 +408,16 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                     int tot, ex = block_exscan<NT>(mine, shs, &tot);
 #pragma unroll
                     for (int j = 0; j < BPT; j++) {
-                        if (ex < kk && kk <= ex + hs[j] && hs[j] > 0) { shs[28] = 255 - (tid * BPT + j); shs[29] = kk - ex; }
+                        if (ex < kk && kk <= ex + hs[j] && hs[j] > 0) { shs[28] = 255 - (tid * BPT + j); shs[29] = kk - ex; shs[30] = hs[j]; }
                         ex += hs[j];
                     }
                     __syncthreads();
                 }
                 prefix |= (unsigned long long)(unsigned)shs[28] << (8 * pass);
                 kk = shs[29];
-                __syncthreads();
+                const bool whole_bin = kk == shs[30];      // all keys of the threshold bin are wanted: no need to look
+                __syncthreads();                           // at the lower bytes (the usual case after two or three passes)
+                if (whole_bin) { take_ge = true; break; }
             }
             // take every lag with key > prefix and the kk largest lags among key == prefix (sweep from the top)
             int outn = 0, tie_run = 0;
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                 int tie = 0;
                 if (i >= 0 && i < m) { u = ukey(i); tie = (u == prefix) ? 1 : 0; }
                 int ttot, tex = block_exscan<NT>(tie, shs, &ttot);
-                const int g = (i >= 0 && i < m) && (u > prefix || (tie && tie_run + tex < kk)) ? 1 : 0;
+                const int g = (i >= 0 && i < m) && (take_ge ? u >= prefix : (u > prefix || (tie && tie_run + tex < kk))) ? 1 : 0;
                 int gtot, gex = block_exscan<NT>(g, shs, &gtot);
                 if (g) rk[outn + gex] = (uint16_t)i;
                 outn += gtot; tie_run += ttot;
