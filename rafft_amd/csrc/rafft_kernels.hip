@@ -497,36 +497,40 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         // (chunking only for regions ranked by selection; the partial results go behind the lag values)
         const int C = (NT >= 256 && selected) ? max(1, min(8, NT / max(Kp, 1))) : 1;
         struct WsPart { double score; int nb, mi, mj, any; };
-        WsPart *parts = (WsPart *)(lds + lay.offA + 8 * P);       // big regions only: behind the lag values
-        // One-wavefront regions (n <= 256): the diagonal of a lag is a bit mask of pairing cells per pair type
-        // (base masks AND shifted reversed base masks, up to four 64-bit words), contiguity is a mask too, and
-        // only the pairing cells are visited - zero cells never change the result.  Same fp64 recurrence on the
-        // visited cells in the same order, same `>=` rule.
-        const bool ws_masks = (NT == 64) && n <= 256 && d.gc >= 0.0 && d.au >= 0.0 && d.gu >= 0.0 && !d.force_fft;
+        WsPart *parts = (WsPart *)(lds + lay.offA + 8 * P);       // big regions only: behind the lag values (and the masks)
+        // The diagonal of a lag as bit masks: pairing cells per pair type (base masks AND shifted reversed base
+        // masks, 64 cells per word), contiguity with the previous cell as a mask too.  Only the pairing cells
+        // are visited - zero cells never change the result: same fp64 recurrence on the visited cells in the
+        // same order, same `>=` rule.  A chunk first walks back over the run of pairing cells that ends just
+        // before it and replays the recurrence over that run (zero cells reset it, so nothing older matters).
+        // (negative weights or the forced-FFT test mode take the cell-by-cell form below)
+        const bool ws_masks = d.gc >= 0.0 && d.au >= 0.0 && d.gu >= 0.0 && !d.force_fft;
         if (ws_masks) {
-            // forward masks F[0..3] = A,C,G,U, F[4] = contiguity with the previous position; R[] = reversed strings
-            // (region A: the sort keys are dead once rk[] exists; in unsorted mode keyv/lagk stay live, masks go past them)
-            unsigned long long *F = (unsigned long long *)(lds + lay.offA + (inplace ? 0 : ((10 * P + 15) & ~15)));
-            unsigned long long *R = F + 5 * 4;
+            // forward masks F[0..3] = A,C,G,U, F[4] = contiguity with the previous position; R[] = reversed strings.
+            // Region A: behind the lag values (8 P bytes) unless those were sorted in place and are dead; the
+            // partial results of chunked diagonals follow the masks.
             const int W = (n + 63) >> 6;
+            unsigned long long *F = (unsigned long long *)(lds + lay.offA + (inplace ? 0 : 8 * P));
+            unsigned long long *R = F + 5 * W;
+            parts = (WsPart *)(R + 5 * W);
             for (int rep_ = 0; rep_ < 1 + ((d.rep >> 7) & 1); rep_++) {
-            for (int wq = 0; wq < 4; wq++) {
-                const int t = wq * 64 + tid;
+            for (int wq = tid >> 6; wq < W; wq += NT / 64) {       // each wavefront ballots whole 64-bit words
+                const int t = wq * 64 + (tid & 63);
                 const int c0 = t < n ? code[t] : 0;
                 const unsigned long long bA = __ballot(c0 == 1), bC = __ballot(c0 == 2), bG = __ballot(c0 == 3), bU = __ballot(c0 == 4);
                 const unsigned long long bg = __ballot(t >= 1 && t < n && (int)pos[t] - (int)pos[t > 0 ? t - 1 : 0] == 1);
-                if (tid == 0) { F[0 * 4 + wq] = bA; F[1 * 4 + wq] = bC; F[2 * 4 + wq] = bG; F[3 * 4 + wq] = bU; F[4 * 4 + wq] = bg; }
+                if ((tid & 63) == 0) { F[0 * W + wq] = bA; F[1 * W + wq] = bC; F[2 * W + wq] = bG; F[3 * W + wq] = bU; F[4 * W + wq] = bg; }
             }
             __syncthreads();
-            // reversed strings: bit j of R = bit (n-1-j) of F
-            if (tid < 20) {
-                // Reverse the whole 256-bit string (word order and bit order), then shift the n live bits
-                // down: R bit j = T bit (j + 256 - n) with T[w] = brev(F[3 - w]); bits of F past n are zero.
-                const int which = tid >> 2, w = tid & 3;
-                const int s0 = 64 * w + 256 - n, q = s0 >> 6, bsh = s0 & 63;
-                const unsigned long long lo = q < 4 ? __brevll(F[which * 4 + 3 - q]) : 0ULL;
-                const unsigned long long hi = q + 1 < 4 ? __brevll(F[which * 4 + 2 - q]) : 0ULL;
-                R[which * 4 + w] = bsh ? (lo >> bsh) | (hi << (64 - bsh)) : lo;
+            // reversed strings: bit j of R = bit (n-1-j) of F.  Reverse the whole 64 W-bit string (word order and
+            // bit order), then shift the n live bits down: R bit j = T bit (j + 64 W - n) with T[w] = brev(F[W-1-w]);
+            // bits of F past n are zero.
+            for (int idx = tid; idx < 5 * W; idx += NT) {
+                const int which = idx / W, w = idx - which * W;
+                const int s0 = 64 * w + 64 * W - n, q = s0 >> 6, bsh = s0 & 63;
+                const unsigned long long lo = q < W ? __brevll(F[which * W + W - 1 - q]) : 0ULL;
+                const unsigned long long hi = q + 1 < W ? __brevll(F[which * W + W - 2 - q]) : 0ULL;
+                R[which * W + w] = bsh ? (lo >> bsh) | (hi << (64 - bsh)) : lo;
             }
             __syncthreads();
             }
@@ -538,8 +542,9 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                 const unsigned long long hi = (q + 1 >= 0 && q + 1 < W) ? X[q + 1] : 0ULL;
                 return bsh ? (lo >> bsh) | (hi << (64 - bsh)) : lo;
             };
-            for (int rep_ = 0; rep_ < 1 + ((d.rep >> 2) & 1); rep_++)
-            for (int r = tid; r < Kp; r += NT) {
+            for (int rep_ = 0; rep_ < 1 + ((d.rep >> 2) & 1); rep_++) {
+            for (int q = tid; q < Kp * C; q += NT) {
+                const int r = q / C, c = q - r * C;
                 const int lagp = rk[r];
                 const int len = lagp < n ? lagp + 1 : 2 * n - lagp - 1;
                 const int len2 = (len >> 1) + (len & 1);
@@ -550,25 +555,48 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                     if ((int)pos[jp0 - mid] - (int)pos[ip0 + mid] > d.min_hp) lo = mid + 1; else hi = mid;
                 }
                 const int lim = lo;
+                // this lane's share of the eligible cells [a, e), as positions ip
+                const int ipa = ip0 + (int)((long long)lim * c / C), ipe = ip0 + (int)((long long)lim * (c + 1) / C);
+                const int sft = n - 1 - lagp;                // bit ip of x? = base at position lagp - ip
+                // pairing cells of word w by pair type, and the contiguity mask
+                auto cells = [&](int w, unsigned long long &pGC, unsigned long long &pAU, unsigned long long &pGU, unsigned long long &cm) {
+                    const int wb = w << 6;
+                    const unsigned long long xA = window(R + 0 * W, wb + sft), xC = window(R + 1 * W, wb + sft),
+                                             xG = window(R + 2 * W, wb + sft), xU = window(R + 3 * W, wb + sft);
+                    const unsigned long long fA = F[0 * W + w], fC = F[1 * W + w], fG = F[2 * W + w], fU = F[3 * W + w];
+                    pGC = d.gc != 0.0 ? ((fG & xC) | (fC & xG)) : 0ULL;
+                    pAU = d.au != 0.0 ? ((fA & xU) | (fU & xA)) : 0ULL;
+                    pGU = d.gu != 0.0 ? ((fG & xU) | (fU & xG)) : 0ULL;
+                    cm = F[4 * W + w] & window(R + 4 * W, wb + sft - 1);   // contiguous with previous cell
+                    if (ip0 >= wb && ip0 < wb + 64) cm &= ~(1ULL << (ip0 - wb));          // never for the first cell
+                };
+                auto span = [](int lo_, int hi_, int wb) -> unsigned long long {             // bits of cells [lo_, hi_) inside word wb
+                    unsigned long long m_ = ~0ULL;
+                    if (lo_ > wb) m_ &= ~0ULL << (lo_ - wb);
+                    if (hi_ < wb + 64) m_ &= (1ULL << (hi_ - wb)) - 1;
+                    return m_;
+                };
                 double mx_s = 0.0, prev = 0.0;
                 int mx_nb = 0, mx_i = 0, mx_j = 0, last_ip = -2, runlen = 0;
                 bool found = false;
-                if (lim > 0) {
-                    const int sft = n - 1 - lagp;            // bit ip of x? = base at position lagp - ip
-                    const int ip_end = ip0 + lim;            // cells ip in [ip0, ip_end)
-                    for (int w = ip0 >> 6; w <= (ip_end - 1) >> 6; w++) {
+                if (ipe > ipa) {
+                    int z = ipa;                             // replay start: first cell of the run of pairing cells ending at ipa - 1
+                    if (ipa > ip0) {
+                        for (int wz = (ipa - 1) >> 6;; wz--) {
+                            const int wb = wz << 6;
+                            unsigned long long pGC, pAU, pGU, cm;
+                            cells(wz, pGC, pAU, pGU, cm);
+                            const unsigned long long zeros = ~(pGC | pAU | pGU) & span(ip0, ipa, wb);
+                            if (zeros) { z = wb + 64 - __clzll((long long)zeros); break; }
+                            if (wb <= ip0) { z = ip0; break; }
+                        }
+                    }
+                    for (int w = z >> 6; w <= (ipe - 1) >> 6; w++) {
                         const int wb = w << 6;
-                        const unsigned long long xA = window(R + 0 * 4, wb + sft), xC = window(R + 1 * 4, wb + sft),
-                                                 xG = window(R + 2 * 4, wb + sft), xU = window(R + 3 * 4, wb + sft);
-                        unsigned long long range = ~0ULL;
-                        if (ip0 > wb) range &= ~0ULL << (ip0 - wb);
-                        if (ip_end < wb + 64) range &= (1ULL << (ip_end - wb)) - 1;
-                        const unsigned long long fA = F[0 * 4 + w], fC = F[1 * 4 + w], fG = F[2 * 4 + w], fU = F[3 * 4 + w];
-                        const unsigned long long pGC = d.gc != 0.0 ? ((fG & xC) | (fC & xG)) & range : 0ULL;
-                        const unsigned long long pAU = d.au != 0.0 ? ((fA & xU) | (fU & xA)) & range : 0ULL;
-                        const unsigned long long pGU = d.gu != 0.0 ? ((fG & xU) | (fU & xG)) & range : 0ULL;
-                        unsigned long long cm = F[4 * 4 + w] & window(R + 4 * 4, wb + sft - 1);   // contiguous with previous cell
-                        if (ip0 >= wb && ip0 < wb + 64) cm &= ~(1ULL << (ip0 - wb));          // never for the first cell
+                        unsigned long long pGC, pAU, pGU, cm;
+                        cells(w, pGC, pAU, pGU, cm);
+                        const unsigned long long range = span(z, ipe, wb);
+                        pGC &= range; pAU &= range; pGU &= range;
                         unsigned long long any = pGC | pAU | pGU;
                         while (any) {
                             const int bi = __ffsll((long long)any) - 1;
@@ -580,14 +608,33 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                             double t = w8;
                             if (cm & bit) t = (prev + w8) * w8;
                             runlen++;
-                            if (t >= mx_s) { mx_s = t; mx_nb = runlen; mx_i = ip; mx_j = lagp - ip; found = true; }
+                            if (ip >= ipa && t >= mx_s) { mx_s = t; mx_nb = runlen; mx_i = ip; mx_j = lagp - ip; found = true; }
                             prev = t; last_ip = ip;
                         }
                     }
-                    if (!found) { mx_i = ip0 + lim - 1; mx_j = jp0 - (lim - 1); }   // last eligible (zero) cell, nb = 0
+                    if (!found) { mx_i = ipe - 1; mx_j = lagp - (ipe - 1); }   // last eligible (zero) cell of the share, nb = 0
                 }
-                wnb[r] = (uint16_t)mx_nb; wmi[r] = (uint16_t)mx_i; wmj[r] = (uint16_t)mx_j;
-                if (d.dbg.nb) { d.dbg.nb[r] = mx_nb; d.dbg.mi[r] = mx_i; d.dbg.mj[r] = mx_j; d.dbg.score[r] = mx_s; }
+                if (C == 1) {
+                    wnb[r] = (uint16_t)mx_nb; wmi[r] = (uint16_t)mx_i; wmj[r] = (uint16_t)mx_j;
+                    if (d.dbg.nb) { d.dbg.nb[r] = mx_nb; d.dbg.mi[r] = mx_i; d.dbg.mj[r] = mx_j; d.dbg.score[r] = mx_s; }
+                } else {
+                    WsPart wp; wp.score = mx_s; wp.nb = mx_nb; wp.mi = mx_i; wp.mj = mx_j; wp.any = ipe > ipa ? 1 : 0;
+                    parts[q] = wp;
+                }
+            }
+            if (C > 1) {
+                __syncthreads();
+                for (int r = tid; r < Kp; r += NT) {
+                    double mx_s = 0.0;
+                    int mx_nb = 0, mx_i = 0, mx_j = 0;
+                    for (int c = 0; c < C; c++) {
+                        const WsPart wp = parts[r * C + c];
+                        if (wp.any && wp.score >= mx_s) { mx_s = wp.score; mx_nb = wp.nb; mx_i = wp.mi; mx_j = wp.mj; }
+                    }
+                    wnb[r] = (uint16_t)mx_nb; wmi[r] = (uint16_t)mx_i; wmj[r] = (uint16_t)mx_j;
+                    if (d.dbg.nb) { d.dbg.nb[r] = mx_nb; d.dbg.mi[r] = mx_i; d.dbg.mj[r] = mx_j; d.dbg.score[r] = mx_s; }
+                }
+            }
             }
         } else
         for (int rep_ = 0; rep_ < 1 + ((d.rep >> 2) & 1); rep_++) {
