@@ -134,3 +134,22 @@ def test_gpu_batch_composition_does_not_change_results(bench_rows):
     assert key(twice[:len(seqs)]) == key(base) and key(twice[len(seqs):]) == key(base) and key(rev) == key(base)
     for k in (0, 17, 41):
         assert key([rafft_amd.fold(seqs[k], 100, 12, 300, traj=True)]) == key(base[k:k + 1])
+
+
+def test_gpu_stage_timers_are_opt_in(bench_rows, monkeypatch):
+    """timing events around every kernel cost ~7 % of a batch, so by default only the dominant kernel is timed;
+    RAFFT_SPANS=2 fills the per-stage fields of rafft_stats, RAFFT_SPANS=0 leaves only the wall time"""
+    seqs = [r["seq"] for r in bench_rows[::3]]
+    rafft_amd.fold_batch(seqs, 100, 50, 1000)
+    st = rafft_amd.last_stats()
+    assert st["ms_total"] > 0 and st["ms_expand"] > 0 and st["ms_beam"] == 0 and st["ms_materialize"] == 0
+    assert st["n_expand_launches"] >= 1 and st["n_regrows"] == 0
+    monkeypatch.setenv("RAFFT_SPANS", "2")
+    rafft_amd.fold_batch(seqs, 100, 50, 1000)
+    st2 = rafft_amd.last_stats()
+    assert st2["ms_beam"] > 0 and st2["ms_materialize"] > 0 and st2["ms_expand_wall"] >= st2["ms_expand"] > 0
+    assert st2["n_node_expansions"] == st["n_node_expansions"] and st2["n_structs"] == st["n_structs"]
+    monkeypatch.setenv("RAFFT_SPANS", "0")
+    rafft_amd.fold_batch(seqs, 100, 50, 1000)
+    st0 = rafft_amd.last_stats()
+    assert st0["ms_total"] > 0 and st0["ms_expand"] == 0 and st0["ms_beam"] == 0
