@@ -303,7 +303,7 @@ Caps plan_caps(size_t S, size_t sumL, const rafft_params &p, double est)
     int m2 = 2; while (m2 < p.max_stack) m2 <<= 1;
     c.sort_cap = std::max((need + 1) & ~1, m2);
     c.bytes = c.st * (4 * 7 + 8 * 8) + c.nd * (4 * 8 + 8 * 3 + 4 * 4 + 16) + c.pos * 2 + c.br * 4 + c.db + c.cand * 32 + c.seen * 16 +
-              c.looptab * 8 + c.trec * 16 + c.tsid * 4 + c.mat * 4 + S * (size_t)c.ch_cap * 32 + S * B * 4;
+              c.looptab * 8 + c.trec * 16 + c.tsid * 4 + c.mat * 48 + S * (size_t)c.ch_cap * 32 + S * B * 4;
     return c;
 }
 
@@ -422,7 +422,7 @@ int Wave::setup()
     ENS(pos, c.pos * 2); ENS(br, c.br * 4); ENS(db, c.db); ENS(cand, c.cand * 32);
     ENS(looptab, c.looptab * 8);
     ENS(trec, c.trec * 16); ENS(tsid, c.tsid * 4);
-    ENS(work0, c.work * 4); ENS(work1, c.work * 4); ENS(work2, c.work * 4); ENS(work3, c.work * 4); ENS(mat, c.mat * 4);
+    ENS(work0, c.work * 4); ENS(work1, c.work * 4); ENS(work2, c.work * 4); ENS(work3, c.work * 4); ENS(mat, c.mat * sizeof(MatRec));
     ENS(counters, sizeof(Counters));
 #undef ENS
 
@@ -462,7 +462,7 @@ int Wave::setup()
     d.cand = (Cand *)g.cand.p; d.cand_cap = c.cand;
     d.trec = (int4 *)g.trec.p; d.trec_cap = (uint32_t)c.trec; d.tsid = (int *)g.tsid.p; d.tsid_cap = c.tsid;
     d.work[0] = (int *)g.work0.p; d.work[1] = (int *)g.work1.p; d.work[2] = (int *)g.work2.p; d.work[3] = (int *)g.work3.p; d.work_cap = (uint32_t)c.work;
-    d.mat = (int *)g.mat.p; d.mat_cap = (uint32_t)c.mat;
+    d.mat = (MatRec *)g.mat.p; d.mat_cap = (uint32_t)c.mat;
     d.c = (Counters *)g.counters.p;
     d.nd_base = S; d.nd_shard_cap = (c.nd - S) / NSHARD;
     d.pos_base = sumL; d.pos_shard_cap = (c.pos - sumL) / NSHARD;

@@ -47,6 +47,8 @@ static_assert(sizeof(Cand) == 32, "Cand must be 32 bytes");
 struct ShardCtr { unsigned long long v; unsigned long long pad[7]; };   // one 64-byte line each
 
 struct ProdEnt { uint32_t cnt; int32_t node; uint64_t off; };   // one productive region of a structure
+// one new beam member to materialize: everything materialize_kernel needs to start, in one 48-byte read
+struct alignas(16) MatRec { int32_t sid, sq, L, dcal, nprod, pad; uint64_t combo, prod, pdb; };
 
 struct Counters {
     // hot part: read back by the host once per folding step (first 64 bytes)
@@ -112,7 +114,7 @@ struct Dev {
     int *tsid; uint64_t tsid_cap;
     // work lists
     int *work[NCLS]; uint32_t work_cap;
-    int *mat; uint32_t mat_cap;
+    MatRec *mat; uint32_t mat_cap;
     Counters *c;
     DebugOut dbg;
     unsigned long long *prof; int prof_seq;   // diagnostic stamps of beam_step_kernel (RAFFT_TRACE=3)

@@ -910,8 +910,9 @@ struct ParentInfo {         // filled by the parallel prepass, one entry per bea
     int sid, nprod;         // structure id; productive regions
     unsigned long long prod;              // productive-region list (global)
     int rl0, nrl;           // this member's regions with >= 2 candidates in the LDS list (rl0 < 0: not resident)
+    unsigned long long db;                // its dot-bracket row (handed to materialize_kernel with every child)
 };
-static_assert(sizeof(ParentInfo) == 64, "ParentInfo layout");
+static_assert(sizeof(ParentInfo) == 72, "ParentInfo layout");
 
 __device__ __forceinline__ unsigned long long sat_mul(unsigned long long a, unsigned long long b)
 {
@@ -988,7 +989,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
             const int b = b0 + wv * gpw + grp;
             if (b >= nbeam) continue;
             const int sid = oldbeam[b];
-            const unsigned long long cur0 = d.st_cursor[sid], tot0 = d.st_total[sid];
+            const unsigned long long cur0 = d.st_cursor[sid], tot0 = d.st_total[sid], dboff = d.st_db[sid];
             if (tot0 && cur0 >= tot0) { if (gl == 0) pinfo[b].flag = 1; continue; }
             const bool resumed = tot0 && cur0 > 0;
             unsigned long long pbase = 0, tot = 1, h1 = 0, h2 = 0;
@@ -1066,7 +1067,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
             }
             if (gl == 0) {
                 ParentInfo pi;
-                pi.sid = sid; pi.prod = pbase; pi.nprod = wpos; pi.rl0 = nm == 0 ? 0 : rl0; pi.nrl = nm;
+                pi.sid = sid; pi.prod = pbase; pi.nprod = wpos; pi.rl0 = nm == 0 ? 0 : rl0; pi.nrl = nm; pi.db = dboff;
                 if (resumed) {
                     pi.flag = 2; pi.total = tot0; pi.cur = cur0;
                     pi.h1 = d.st_c0h[2 * (size_t)sid]; pi.h2 = d.st_c0h[2 * (size_t)sid + 1]; pi.dcal0 = d.st_c0d[sid];
@@ -1417,7 +1418,13 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
                 d.st_cursor[sid] = 0;
                 d.st_total[sid] = 0;
                 d.st_nnodes[sid] = 0;
-                d.mat[mbase + run + ex] = sid;
+                {
+                    const ParentInfo &pp_ = pinfo[d.ch_parent[c]];
+                    MatRec mr;
+                    mr.sid = sid; mr.sq = sq; mr.L = d.seq_len[sq]; mr.dcal = d.ch_dcal[c]; mr.nprod = pp_.nprod; mr.pad = 0;
+                    mr.combo = d.ch_combo[c]; mr.prod = pp_.prod; mr.pdb = pp_.db;
+                    d.mat[mbase + run + ex] = mr;
+                }
                 beam[i] = sid;
             } else
                 beam[i] = oldbeam[ord - nchild];
@@ -1486,23 +1493,20 @@ __global__ __launch_bounds__(MAT_NT) void materialize_kernel(Dev d)
     const bool mprof = d.prof_e != nullptr && tid == 0 && (blockIdx.x & 63) == 0;
     unsigned long long mt = mprof ? clock64() : 0, macc[7] = {0, 0, 0, 0, 0, 0, 0};
 #define MSTAMP(k) do { if (mprof) { const unsigned long long tn_ = clock64(); macc[k] += tn_ - mt; mt = tn_; } } while (0)
-    const int sid = d.mat[blockIdx.x];
-    const int par = d.st_parent[sid];
-    const int sq = d.st_seq[sid];
-    const int L = d.seq_len[sq];
-    const int my_dcal = d.st_dcal[sid];
-    int mprod = d.st_nprod[par];
+    const MatRec rec = d.mat[blockIdx.x];              // written by the beam step: no chain of look-ups to get started
+    const int sid = rec.sid, sq = rec.sq, L = rec.L, my_dcal = rec.dcal;
+    int mprod = rec.nprod;
     if (mprod > MAX_PROD) mprod = MAX_PROD;
     {
-        const ProdEnt *pl = d.prod + d.st_prod[par];      // the parent's productive regions (beam_step prepass)
+        const ProdEnt *pl = d.prod + rec.prod;             // the parent's productive regions (beam_step prepass)
         for (int k = tid; k < mprod; k += MAT_NT) { prod_node[k] = pl[k].node; prod_cnt[k] = (int)pl[k].cnt; sel[k] = 0; }
     }
     // the parent's dot-bracket row (rafft/rafft.py:97,127-128); the stems are marked below
-    const uint8_t *pdb = d.db + d.st_db[par];
+    const uint8_t *pdb = d.db + rec.pdb;
     for (int x = tid; x < L; x += MAT_NT) sdb[x] = pdb[x];
     __syncthreads();
     if (tid == 0) {      // digits of the combo, last region fastest; high digits of a small index stay 0
-        unsigned long long idx = d.st_combo[sid];
+        unsigned long long idx = rec.combo;
         for (int k = mprod - 1; k >= 0 && idx; k--) {
             const unsigned int c = (unsigned int)prod_cnt[k];
             if (idx < (1ULL << 24)) {
