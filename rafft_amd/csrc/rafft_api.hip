@@ -108,9 +108,16 @@ uint32_t key_of(const char *s, int m)
 int init_ws(Workspace &w)
 {
     if (w.ready) return 0;
-    HIPCHK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+    // The second pipeline (the bulk of a batch cut by length, see rafft_fold_batch) gets the high stream priority:
+    // streams of another priority have HW queues of their own, so its kernels do not queue behind those of the
+    // first pipeline.  (Measured: bulk high or low 13.4 ms, no priorities 17.3 ms, the long tail high 15.4 ms.)
+    int plo = 0, phi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&plo, &phi));
+    const int prio_mode = getenv("RAFFT_PRIO") ? atoi(getenv("RAFFT_PRIO")) : 1;
+    const int prio = (&w == &g.ws[1]) ? (prio_mode > 0 ? phi : prio_mode < 0 ? plo : 0) : 0;
+    HIPCHK(hipStreamCreateWithPriority(&w.stream, hipStreamNonBlocking, prio));
     for (int c = 0; c < NCLS; c++) {
-        HIPCHK(hipStreamCreateWithFlags(&w.cls_stream[c], hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithPriority(&w.cls_stream[c], hipStreamNonBlocking, prio));
         HIPCHK(hipEventCreateWithFlags(&w.ev_join[c], hipEventDisableTiming));
     }
     HIPCHK(hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
@@ -911,25 +918,31 @@ int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs, 
         good.push_back({seqs[i], L, i});
     }
     std::vector<Span> spans;
-    // ---- pipelines.  Folds are independent, so how the batch is cut cannot change any result.  With enough
-    // sequences the batch is cut by length into two pipelines driven from this one thread: the long sequences
-    // need twice as many (latency-bound, nearly empty) folding steps as the short ones, and run beside them.
+    // ---- pipelines.  Folds are independent, so how the batch is cut cannot change any result.  The number of
+    // folding steps of a wave is set by its longest sequence, and the steps that only the long ones still need
+    // are latency-bound and nearly empty (the benchmark set: 24 steps for two 2.9-knt sequences, 12 for the rest).
+    // So a batch whose few longest sequences stand far out is cut in two waves driven from this one thread: the long
+    // tail starts first and runs beside the bulk.  The bulk's streams have a stream priority of their own, which
+    // gives them HW queues of their own - with all streams at one priority the two waves share the process's four
+    // queues and the cut is a loss (17.3 ms against 15.2 for the benchmark batch; with it: 13.3 ms).
+    // RAFFT_SPLIT: unset / -1 automatic, 0 never, > 0 cut at that length.
     int split_len = 0;
     {
         const char *sp = getenv("RAFFT_SPLIT");
-        // default: one pipeline.  Two pipelines in one process were measured SLOWER on MI355X (47-73 ms against
-        // 31 ms for the benchmark batch: the persistent grids of both pipelines compete for dispatch), although
-        // two processes sharing the GPU gain 27 %.  RAFFT_SPLIT=<len> (or -1 for an automatic cut) enables it.
-        int want = sp ? atoi(sp) : 0;
-        if (good.size() >= 512 && want != 0) {
+        const int want = sp ? atoi(sp) : -1;
+        if (good.size() >= 512 && want != 0 && (want > 0 || good.size() < 16384)) {     // (very large batches amortise the tail anyway)
             if (want > 0) split_len = want;
-            else {   // default cut: the length above which ~1/16 of the total length lies
+            else {   // the longest sequences holding up to 3 % of the total length, if they are at least twice the median
                 std::vector<int> ls;
                 size_t tot = 0;
                 for (auto &sq : good) { ls.push_back(sq.len); tot += sq.len; }
                 std::sort(ls.begin(), ls.end(), std::greater<int>());
+                const int median = ls[ls.size() / 2];
                 size_t acc = 0;
-                for (int L_ : ls) { acc += L_; split_len = L_; if (acc * 16 >= tot) break; }
+                int cut = 0;
+                for (int L_ : ls) { acc += L_; if (acc * 100 > tot * 3 || L_ < 2 * median) break; cut = L_; }
+                // (sequences of equal length stay together: `cut` is the shortest length wholly inside the 3 %)
+                split_len = cut;
             }
         }
     }
