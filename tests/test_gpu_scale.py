@@ -153,3 +153,23 @@ def test_gpu_stage_timers_are_opt_in(bench_rows, monkeypatch):
     rafft_amd.fold_batch(seqs, 100, 50, 1000)
     st0 = rafft_amd.last_stats()
     assert st0["ms_total"] > 0 and st0["ms_expand"] == 0 and st0["ms_beam"] == 0
+
+
+def test_gpu_long_tail_wave_gives_identical_results(monkeypatch):
+    """a batch whose few longest sequences stand far out is folded as two concurrent waves (the bulk's streams at a
+    stream priority of their own): same trajectories as in one wave, in input order, and equal to the oracle"""
+    rng = np.random.default_rng(91)
+    lens = [int(x) for x in rng.integers(30, 160, size=560)]
+    lens[17] = 1400; lens[300] = 1900; lens[559] = 1650
+    seqs = ["".join(rng.choice(list("ACGU"), n)) for n in lens]
+    two = rafft_amd.fold_batch(seqs, 100, 10, 200, traj=True)
+    monkeypatch.setenv("RAFFT_SPLIT", "0")
+    one = rafft_amd.fold_batch(seqs, 100, 10, 200, traj=True)
+    def key(res):
+        return [[[(s.str_struct, s.dcal) for s in st] for st in traj] for _, traj in res]
+    assert key(two) == key(one)
+    for k in (0, 16, 17, 18, 299, 558):
+        if lens[k] > 400:
+            continue
+        _, o = oracle.fold(seqs[k], 100, 10, 200, traj=True)
+        assert key(two[k:k + 1])[0] == [[(s.str_struct, s.dcal) for s in st] for st in o]
