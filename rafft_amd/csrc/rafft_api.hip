@@ -933,12 +933,13 @@ int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs, 
         const int want = sp ? atoi(sp) : -1;
         if (good.size() >= 32 && want != 0 && (want > 0 || good.size() < 16384)) {     // (very large batches amortise the tail anyway)
             if (want > 0) split_len = want;
-            else {   // the sequences at least twice as long as the 95th percentile of the batch (at most 5 % of it)
+            else {   // the sequences at least twice as long as the 99th percentile of the batch (leaving room for two)
                 std::vector<int> ls;
                 for (auto &sq : good) ls.push_back(sq.len);
                 std::sort(ls.begin(), ls.end());
-                const int p95 = ls[(ls.size() * 95) / 100 < ls.size() ? (ls.size() * 95) / 100 : ls.size() - 1];
-                if (ls.back() >= 2 * p95) split_len = 2 * p95;
+                const size_t top = std::max<size_t>(2, ls.size() / 100);
+                const int ref = ls[ls.size() - top - 1];
+                if (ls.back() >= 2 * ref) split_len = 2 * ref;
             }
         }
     }
