@@ -55,6 +55,7 @@ struct Workspace {
     bool ready = false;
     hipStream_t stream = nullptr;
     hipStream_t cls_stream[NCLS] = {};
+    hipStream_t copy_stream = nullptr;   // result rows of sequences that finish early leave while the others still fold
     hipEvent_t ev_fork = nullptr, ev_join[NCLS] = {}, ev_hot = nullptr;
     void *hot = nullptr;                 // pinned, 256 B
     // named device buffers (grow-only)
@@ -62,7 +63,7 @@ struct Workspace {
         seen_cap, seen_cnt, st_seq, st_dcal, st_node0, st_nnodes, st_parent, st_h, st_db, st_cursor, st_combo, st_total, st_prod, st_nprod, st_c0h, st_c0d, prod, nd_seq, nd_pdcal,
         nd_n, nd_ci, nd_cj, nd_nbr, nd_canon, nd_ncand, nd_pos, nd_br, nd_cand, pos, br, db, cand, looptab, trec, tsid,
         work0, work1, work2, work3, mat, counters,
-        row_sid, row_off, out_db, out_dcal, dbg;
+        row_sid, row_off, out_db, out_dcal, row_off2, out_db2, out_dcal2, dbg;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
 };
@@ -120,6 +121,7 @@ int init_ws(Workspace &w)
         HIPCHK(hipStreamCreateWithPriority(&w.cls_stream[c], hipStreamNonBlocking, prio));
         HIPCHK(hipEventCreateWithFlags(&w.ev_join[c], hipEventDisableTiming));
     }
+    HIPCHK(hipStreamCreateWithFlags(&w.copy_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&w.ev_hot, hipEventDisableTiming));
     HIPCHK(hipHostMalloc(&w.hot, 256, hipHostMallocDefault));
@@ -373,6 +375,10 @@ struct Wave {
     int merged_now = 0, merge_target = 0;   // size class that receives every region of the coming expand step (0: by size)
     int steps = 0;
     bool finished = false;
+    long long last_rows_bytes = 0;
+    std::vector<OutRec> early_recs, late_recs;
+    size_t harvested = 0;         // trajectory records whose rows already left through the copy stream (early harvest)
+    int emit_rows(size_t first, size_t count, bool early, double *t_gather);
     int result = 0;               // valid when finished: 0, RAFFT_ERR_CAPACITY (regrow) or a hard error
     std::chrono::steady_clock::time_point tw0, tw1;
     double ms_setup = 0, ms_issue = 0, ms_after = 0;   // host time inside issue_step / after_beam (trace)
@@ -590,6 +596,11 @@ int Wave::after_beam()
     if (hc.n_mat == 0) return finish();
     n_active = (unsigned)S - hc.n_done;
     last_mat = hc.n_mat;
+    // most sequences of the wave have finished: their rows leave now, beside the folding steps of the others
+    if (!p.traj && !seam && !harvested && S >= 256 && (size_t)hc.trec_n * 10 >= S * 7 && getenv("RAFFT_NO_HARVEST") == nullptr) {
+        if (int rc = emit_rows(0, (size_t)hc.trec_n, true, nullptr)) return rc;
+        harvested = (size_t)hc.trec_n;
+    }
     {
         Span sp{next_event(), next_event(), 2};
         SPAN_REC(sp.a, st, sp.kind);
@@ -615,6 +626,74 @@ int Wave::after_beam()
     return issue_step();
 }
 
+// Format the beams of trajectory records [first, first + count) as result rows on the device and copy them to a
+// pinned chunk of their own.  `early`: on the copy stream, while the wave goes on folding (only the records of
+// sequences that have finished are final, so this is used without --traj, where a sequence has one record).
+int Wave::emit_rows(size_t first, size_t count, bool early, double *t_gather)
+{
+    const auto t0_ = std::chrono::steady_clock::now();
+    hipStream_t st = early ? g.copy_stream : g.stream;
+    Buf &b_rec = early ? g.row_off2 : g.row_off, &b_db = early ? g.out_db2 : g.out_db, &b_dc = early ? g.out_dcal2 : g.out_dcal;
+    std::vector<int4> trec(count);
+    if (count) HIPCHK(hipMemcpy(trec.data(), (const int4 *)g.trec.p + first, count * sizeof(int4), hipMemcpyDeviceToHost));
+    // records in (sequence, step) order; rows are laid out record after record
+    std::sort(trec.begin(), trec.end(), [](const int4 &a, const int4 &b) { return a.x != b.x ? a.x < b.x : a.y < b.y; });
+    std::vector<OutRec> &recs = early ? early_recs : late_recs;     // (members: they outlive the asynchronous upload)
+    recs.assign(trec.size(), OutRec{});
+    long long tot_bytes = 0;
+    size_t nrows = 0;
+    for (size_t ri = 0; ri < trec.size(); ri++) {
+        const int4 &r = trec[ri];
+        recs[ri] = OutRec{tot_bytes, (int)nrows, r.w, r.z, len[r.x]};
+        tot_bytes += (long long)r.z * (len[r.x] + 1);
+        nrows += (size_t)r.z;
+    }
+    if (t_gather) *t_gather = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count();
+    last_rows_bytes = tot_bytes;
+    if (!nrows) return 0;
+    const size_t dcal_off = ((size_t)tot_bytes + 63) & ~(size_t)63;
+    PinBuf chunk;
+    chunk = pin_acquire(dcal_off + nrows * 4 + 64);
+    if (!chunk.p) return fail(RAFFT_ERR_HIP, "hipHostMalloc failed for the result buffer");
+    out.chunks.push_back(chunk);
+    char *all_db = (char *)chunk.p;
+    int *all_dcal = (int *)((char *)chunk.p + dcal_off);
+    if (int rc = ensure(b_rec, recs.size() * sizeof(OutRec))) return rc;
+    if (int rc = ensure(b_db, (size_t)tot_bytes)) return rc;
+    if (int rc = ensure(b_dc, nrows * 4)) return rc;
+    HIPCHK(hipMemcpyAsync(b_rec.p, recs.data(), recs.size() * sizeof(OutRec), hipMemcpyHostToDevice, st));
+    Span sp{next_event(), next_event(), 3};
+    SPAN_REC(sp.a, st, sp.kind);
+    unsigned grid = (unsigned)std::min<size_t>(nrows, 65536);
+    hipLaunchKernelGGL(output_kernel, dim3(grid), dim3(64), 0, st, d, (int)nrows, (int)recs.size(), (const OutRec *)b_rec.p,
+                       (char *)b_db.p, (int *)b_dc.p);
+    HIPCHK(hipGetLastError());
+    SPAN_REC(sp.b, st, sp.kind);
+    spans.push_back(sp);
+    HIPCHK(hipMemcpyAsync(all_db, b_db.p, (size_t)tot_bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(all_dcal, b_dc.p, nrows * 4, hipMemcpyDeviceToHost, st));
+    // `recs` was handed to an asynchronous copy from pageable memory: HIP stages such copies before returning
+    if (!early) HIPCHK(hipStreamSynchronize(st));
+    // per-sequence views into the chunk (the pointers are only read by the caller after the call has returned)
+    for (size_t r0 = 0; r0 < recs.size();) {
+        const int i = trec[r0].x;
+        size_t r1 = r0;
+        while (r1 < recs.size() && trec[r1].x == i) r1++;
+        const int gi = seqs[i].idx;
+        auto &ss = out.step_size[gi];
+        auto &so = out.step_off[gi];
+        ss.resize(r1 - r0); so.resize(r1 - r0);
+        int o = 0;
+        for (size_t r = r0; r < r1; r++) { ss[r - r0] = recs[r].cnt; so[r - r0] = o; o += recs[r].cnt; }
+        out.dcal_ptr[gi] = all_dcal + recs[r0].row0;
+        out.db_ptr[gi] = all_db + recs[r0].off;
+        rafft_seq_result &sr = out.seq[gi];
+        sr.status = RAFFT_OK; sr.length = len[i]; sr.n_steps = (int)(r1 - r0); sr.n_structs = o;
+        r0 = r1;
+    }
+    return 0;
+}
+
 int Wave::finish()
 {
     hipStream_t st = g.stream;
@@ -625,6 +704,7 @@ int Wave::finish()
     if (ovf && getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] wave S=%zu est %.1f overflowed (bits %u) after %d steps, %.1f ms\n", S, est, ovf, steps, since(tw0));
     if (ovf) {
         HIPCHK(hipStreamSynchronize(st));
+        if (harvested) HIPCHK(hipStreamSynchronize(g.copy_stream));
         if (ovf & (OVF_PROD | OVF_SORT))
             return result = fail(RAFFT_ERR_PARAM, "structure with more than 256 productive regions or sort capacity exceeded");
         return result = RAFFT_ERR_CAPACITY;
@@ -656,67 +736,13 @@ int Wave::finish()
 
 
     const double tl_stats = since(tw2);
-    // ---- gather the trajectory records and format rows on the device
-    std::vector<int4> trec(hc.trec_n);
-    if (hc.trec_n) HIPCHK(hipMemcpy(trec.data(), g.trec.p, hc.trec_n * sizeof(int4), hipMemcpyDeviceToHost));
-    // records in (sequence, step) order; rows are laid out record after record
-    std::sort(trec.begin(), trec.end(), [](const int4 &a, const int4 &b) { return a.x != b.x ? a.x < b.x : a.y < b.y; });
-    std::vector<OutRec> recs(trec.size());
-    std::vector<long long> seq_db_off(S, 0);
-    std::vector<int> seq_row0(S, 0), seq_rec0(S + 1, 0);
-    long long tot_bytes = 0;
-    size_t nrows = 0;
-    {
-        size_t ri = 0;
-        for (size_t i = 0; i < S; i++) {
-            seq_db_off[i] = tot_bytes; seq_row0[i] = (int)nrows; seq_rec0[i] = (int)ri;
-            for (; ri < trec.size() && (size_t)trec[ri].x == i; ri++) {
-                const int4 &r = trec[ri];
-                recs[ri] = OutRec{tot_bytes, (int)nrows, r.w, r.z, len[i]};
-                tot_bytes += (long long)r.z * (len[i] + 1);
-                nrows += (size_t)r.z;
-            }
-        }
-        seq_rec0[S] = (int)ri;
-    }
-    const double tl_gather = since(tw2);
-    const size_t dcal_off = ((size_t)tot_bytes + 63) & ~(size_t)63;
-    PinBuf chunk = pin_acquire(dcal_off + nrows * 4 + 64);
-    if (!chunk.p) return fail(RAFFT_ERR_HIP, "hipHostMalloc failed for the result buffer");
-    out.chunks.push_back(chunk);
-    char *all_db = (char *)chunk.p;
-    int *all_dcal = (int *)((char *)chunk.p + dcal_off);
-    if (nrows) {
-        if (int rc = ensure(g.row_off, recs.size() * sizeof(OutRec))) return rc;
-        if (int rc = ensure(g.out_db, (size_t)tot_bytes)) return rc;
-        if (int rc = ensure(g.out_dcal, nrows * 4)) return rc;
-        HIPCHK(hipMemcpyAsync(g.row_off.p, recs.data(), recs.size() * sizeof(OutRec), hipMemcpyHostToDevice, st));
-        Span sp{next_event(), next_event(), 3};
-        SPAN_REC(sp.a, st, sp.kind);
-        unsigned grid = (unsigned)std::min<size_t>(nrows, 65536);
-        hipLaunchKernelGGL(output_kernel, dim3(grid), dim3(64), 0, st, d, (int)nrows, (int)recs.size(), (const OutRec *)g.row_off.p,
-                           (char *)g.out_db.p, (int *)g.out_dcal.p);
-        HIPCHK(hipGetLastError());
-        SPAN_REC(sp.b, st, sp.kind);
-        spans.push_back(sp);
-        HIPCHK(hipMemcpyAsync(all_db, g.out_db.p, (size_t)tot_bytes, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(all_dcal, g.out_dcal.p, nrows * 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-    }
+    // ---- the rows that have not left yet: records of sequences that finished after the early harvest (or all)
+    double tl_gather = 0;
+    if (int rc = emit_rows(harvested, (size_t)hc.trec_n - harvested, false, &tl_gather)) return rc;
+    tl_gather += tl_stats;
+    if (harvested) HIPCHK(hipStreamSynchronize(g.copy_stream));
     const double tl_copy = since(tw2);
-    for (size_t i = 0; i < S; i++) {
-        int gi = seqs[i].idx;
-        const int r0 = seq_rec0[i], r1 = seq_rec0[i + 1];
-        auto &ss = out.step_size[gi];
-        auto &so = out.step_off[gi];
-        ss.resize(r1 - r0); so.resize(r1 - r0);
-        int o = 0;
-        for (int r = r0; r < r1; r++) { ss[r - r0] = recs[r].cnt; so[r - r0] = o; o += recs[r].cnt; }
-        out.dcal_ptr[gi] = all_dcal + seq_row0[i];
-        out.db_ptr[gi] = all_db + seq_db_off[i];
-        rafft_seq_result &sr = out.seq[gi];
-        sr.status = RAFFT_OK; sr.length = len[i]; sr.n_steps = r1 - r0; sr.n_structs = o;
-    }
+    const long long tot_bytes = last_rows_bytes;
     if (d.prof_e) {
         unsigned long long pe[NCLS * 16];
         HIPCHK(hipMemcpy(pe, d.prof_e, sizeof pe, hipMemcpyDeviceToHost));
