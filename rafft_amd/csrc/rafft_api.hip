@@ -374,6 +374,7 @@ struct Wave {
     unsigned n_active = 0, ovf = 0, last_mat = 0;
     int merged_now = 0, merge_target = 0;   // size class that receives every region of the coming expand step (0: by size)
     int steps = 0;
+    int depth = 0;                // regrowths of this job so far
     bool finished = false;
     long long last_rows_bytes = 0;
     std::vector<OutRec> early_recs, late_recs;
@@ -593,6 +594,8 @@ int Wave::after_beam()
     const size_t hot_len = offsetof(Counters, node);
     memcpy(&hc, g.hot, hot_len);
     if (hc.overflow) { ovf = hc.overflow; return finish(); }
+    // test hook: pretend an arena overflowed at this step of the first attempt (regrowth late in a wave)
+    if (const char *e = getenv("RAFFT_TEST_OVF_AT")) if (depth == 0 && steps == atoi(e)) { ovf = OVF_STRUCT; return finish(); }
     if (hc.n_mat == 0) return finish();
     n_active = (unsigned)S - hc.n_done;
     last_mat = hc.n_mat;
@@ -600,6 +603,7 @@ int Wave::after_beam()
     if (!p.traj && !seam && !harvested && S >= 256 && (size_t)hc.trec_n * 10 >= S * 7 && getenv("RAFFT_NO_HARVEST") == nullptr) {
         if (int rc = emit_rows(0, (size_t)hc.trec_n, true, nullptr)) return rc;
         harvested = (size_t)hc.trec_n;
+        if (getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] early harvest after step %d: %zu of %zu sequences\n", steps, harvested, S);
     }
     {
         Span sp{next_event(), next_event(), 2};
@@ -861,6 +865,7 @@ int run_pipelines(const rafft_params &p, std::vector<std::deque<Job>> &queues, H
                 }
                 if (int rc = init_ws(g.ws[i])) return rc;
                 cur[i].reset(new Wave(g.ws[i], p, job.seqs, job.est, out, spans));
+                cur[i]->depth = job.depth;
                 curjob[i] = std::move(job);
                 if (int rc = cur[i]->setup()) return rc;
                 if (int rc = cur[i]->issue_step()) return rc;

@@ -141,6 +141,22 @@ def test_gpu_single_sequences_need_no_regrowth():
         assert 1 <= len(fin) <= ms and rafft_amd.last_stats()["n_regrows"] == 0, (L, ms, rafft_amd.last_stats())
 
 
+def test_gpu_regrowth_after_early_harvest_stays_exact(monkeypatch):
+    """without --traj the rows of finished sequences leave early through a copy stream; an arena overflow after
+    that abandons the wave, and the re-run must replace every result"""
+    rng = np.random.default_rng(23)
+    lens = [int(n) for n in rng.integers(40, 120, size=300)] + [600, 700]
+    seqs = ["".join(rng.choice(list("ACGU"), n)) for n in lens]
+    want = rafft_amd.fold_batch(seqs, 100, 20, 1000)
+    assert rafft_amd.last_stats()["n_regrows"] == 0
+    monkeypatch.setenv("RAFFT_TEST_OVF_AT", "9")       # the early harvest of this batch happens after step 6
+    monkeypatch.setenv("RAFFT_SPLIT", "0")
+    got = rafft_amd.fold_batch(seqs, 100, 20, 1000)
+    assert rafft_amd.last_stats()["n_regrows"] == 1
+    for f1, f2 in zip(want, got):
+        assert [(s.str_struct, s.dcal) for s in f1] == [(s.str_struct, s.dcal) for s in f2]
+
+
 def test_gpu_fft_and_direct_correlation_agree(monkeypatch, node_records):
     """short regions use the popcount form, long ones the LDS FFT; forcing the FFT everywhere must not
     change a single lag value, rank or trajectory"""
