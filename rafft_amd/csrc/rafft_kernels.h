@@ -154,7 +154,7 @@ __host__ __device__ inline int node_class(int n, int L, int nbr, int merge_cls =
 // LDS layout of the expand kernel (bytes).  Region A is time-shared between the FFT
 // buffers and the sort keys; region B holds the loop itself.
 struct ExpandLds {
-    int offA, szA, off_pos, off_code, off_S, off_br, off_rk, off_nb, off_mi, off_mj, off_dd, off_keep, off_ck, off_w, off_misc,
+    int offA, szA, off_pos, off_code, off_S, off_br, off_rk, off_nb, off_mi, off_mj, off_dd, off_keep, off_w, off_misc,
         off_tab, off_tw, total;
 };
 __host__ __device__ inline ExpandLds expand_lds(int Pmax, int Lmax, int nmax, int brmax, int Kmax, bool tab_lds)
@@ -174,7 +174,6 @@ __host__ __device__ inline ExpandLds expand_lds(int Pmax, int Lmax, int nmax, in
     l.off_mj = o; o += al(2 * Kmax);
     l.off_dd = o; o += al(4 * Kmax);
     l.off_keep = o; o += al(2 * Kmax);
-    l.off_ck = o; o += al(8 * Kmax);
     l.off_w = o; o += al(25 * 8);
     l.off_misc = o; o += 128;
     l.off_tab = o; if (tab_lds) o += al((int)sizeof(SmallT));

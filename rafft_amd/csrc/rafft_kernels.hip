@@ -144,7 +144,6 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
     uint16_t *wmj = (uint16_t *)(lds + lay.off_mj);
     int *dd = (int *)(lds + lay.off_dd);
     uint16_t *keep = (uint16_t *)(lds + lay.off_keep);
-    unsigned long long *ck = (unsigned long long *)(lds + lay.off_ck);
     double *wtab = (double *)(lds + lay.off_w);
     int *misc = (int *)(lds + lay.off_misc);
 
@@ -806,7 +805,9 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         const bool ovf = misc[2] != 0;
         if (!ovf)
         for (int rep_ = 0; rep_ < 1 + ((d.rep >> 6) & 1); rep_++) {
-            // packed sort key of every kept candidate: (dE biased to unsigned) << 32 | lag rank
+            // packed sort key of every kept candidate: (dE biased to unsigned) << 32 | lag rank.  (They take the place of
+            // the branch prefix sums in region A, which dE is done with: 8 * Kp bytes behind the lag values.)
+            unsigned long long *ck = (unsigned long long *)(lds + lay.offA + (inplace ? 0 : 8 * P));
             for (int x = tid; x < nkept; x += NT) {
                 const int r = keep[x];
                 ck[x] = ((unsigned long long)((unsigned)dd[r] ^ 0x80000000u) << 32) | (unsigned)r;
