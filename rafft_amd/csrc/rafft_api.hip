@@ -60,8 +60,7 @@ struct Workspace {
     void *hot = nullptr;                 // pinned, 256 B
     // named device buffers (grow-only)
     Buf codes, seq_off, seq_len, beam, beam_n, done, nsteps, ch_parent, ch_combo, ch_dcal, ch_h, seen, seen_off,
-        seen_cap, seen_cnt, st_seq, st_dcal, st_node0, st_nnodes, st_parent, st_h, st_db, st_cursor, st_combo, st_total, st_prod, st_nprod, st_c0h, st_c0d, prod, nd_seq, nd_pdcal,
-        nd_n, nd_ci, nd_cj, nd_nbr, nd_canon, nd_ncand, nd_pos, nd_br, nd_cand, pos, br, db, cand, looptab, trec, tsid,
+        seen_cap, seen_cnt, st_seq, st_dcal, st_node0, st_nnodes, st_parent, st_h, st_db, st_cursor, st_combo, st_total, st_prod, st_nprod, st_c0h, st_c0d, prod, nd, nd_canon, pos, br, db, cand, looptab, trec, tsid,
         work0, work1, work2, work3, mat, counters,
         row_sid, row_off, out_db, out_dcal, row_off2, out_db2, out_dcal2, dbg;
     std::vector<hipEvent_t> ev_pool;
@@ -311,7 +310,7 @@ Caps plan_caps(size_t S, size_t sumL, const rafft_params &p, double est)
     // keys of one step: children + old beam; only the max_stack selected ones are sorted (padded to a power of two)
     int m2 = 2; while (m2 < p.max_stack) m2 <<= 1;
     c.sort_cap = std::max((need + 1) & ~1, m2);
-    c.bytes = c.st * (4 * 7 + 8 * 8) + c.nd * (4 * 8 + 8 * 3 + 4 * 4 + 16) + c.pos * 2 + c.br * 4 + c.db + c.cand * 32 + c.seen * 16 +
+    c.bytes = c.st * (4 * 7 + 8 * 8) + c.nd * (64 + 4 + 4 * 4 + 16) + c.pos * 2 + c.br * 4 + c.db + c.cand * 32 + c.seen * 16 +
               c.looptab * 8 + c.trec * 16 + c.tsid * 4 + c.mat * 48 + S * (size_t)c.ch_cap * 32 + S * B * 4;
     return c;
 }
@@ -430,9 +429,7 @@ int Wave::setup()
     ENS(seen, c.seen * 16); ENS(seen_off, S * 8); ENS(seen_cap, S * 4); ENS(seen_cnt, S * 4);
     ENS(st_seq, c.st * 4); ENS(st_dcal, c.st * 4); ENS(st_node0, c.st * 4); ENS(st_nnodes, c.st * 4); ENS(st_parent, c.st * 4);
     ENS(st_h, c.st * 16); ENS(st_db, c.st * 8); ENS(st_cursor, c.st * 8); ENS(st_combo, c.st * 8); ENS(st_total, c.st * 8); ENS(st_prod, c.st * 8); ENS(st_nprod, c.st * 4); ENS(st_c0h, c.st * 16); ENS(st_c0d, c.st * 4); ENS(prod, c.nd * 16);
-    ENS(nd_seq, c.nd * 4); ENS(nd_pdcal, c.nd * 4); ENS(nd_n, c.nd * 4); ENS(nd_ci, c.nd * 4); ENS(nd_cj, c.nd * 4);
-    ENS(nd_nbr, c.nd * 4); ENS(nd_canon, c.nd * 4); ENS(nd_ncand, c.nd * 4);
-    ENS(nd_pos, c.nd * 8); ENS(nd_br, c.nd * 8); ENS(nd_cand, c.nd * 8);
+    ENS(nd, c.nd * sizeof(NodeRec)); ENS(nd_canon, c.nd * 4);
     ENS(pos, c.pos * 2); ENS(br, c.br * 4); ENS(db, c.db); ENS(cand, c.cand * 32);
     ENS(looptab, c.looptab * 8);
     ENS(trec, c.trec * 16); ENS(tsid, c.tsid * 4);
@@ -467,9 +464,7 @@ int Wave::setup()
     d.st_c0h = (uint64_t *)g.st_c0h.p; d.st_c0d = (int *)g.st_c0d.p;
     d.prod = (ProdEnt *)g.prod.p; d.prod_shard_cap = c.nd / NSHARD;
     d.nd_cap = (uint32_t)c.nd;
-    d.nd_seq = (int *)g.nd_seq.p; d.nd_pdcal = (int *)g.nd_pdcal.p; d.nd_n = (int *)g.nd_n.p; d.nd_ci = (int *)g.nd_ci.p;
-    d.nd_cj = (int *)g.nd_cj.p; d.nd_nbr = (int *)g.nd_nbr.p; d.nd_canon = (int *)g.nd_canon.p; d.nd_ncand = (int *)g.nd_ncand.p;
-    d.nd_pos = (uint64_t *)g.nd_pos.p; d.nd_br = (uint64_t *)g.nd_br.p; d.nd_cand = (uint64_t *)g.nd_cand.p;
+    d.nd = (NodeRec *)g.nd.p; d.nd_canon = (int *)g.nd_canon.p;
     d.looptab = (unsigned long long *)g.looptab.p; d.looptab_cap = c.looptab;
     d.pos = (uint16_t *)g.pos.p; d.pos_cap = c.pos; d.br = (uint32_t *)g.br.p; d.br_cap = c.br;
     d.db = (uint8_t *)g.db.p; d.db_cap = c.db;
@@ -815,11 +810,12 @@ int run_seam(const rafft_params &p, const std::vector<SeqIn> &one, HostOut &ho, 
     HIPCHK(hipMemcpy(W.pos.p, sm.pos.data(), sm.pos.size() * 2, hipMemcpyHostToDevice));
     if (!sm.br.empty()) HIPCHK(hipMemcpy(W.br.p, sm.br.data(), sm.br.size() * 4, hipMemcpyHostToDevice));
     int n = (int)sm.pos.size(), nbr = (int)sm.br.size();
-    HIPCHK(hipMemcpy(W.nd_n.p, &n, 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(W.nd_nbr.p, &nbr, 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(W.nd_ci.p, &sm.ci, 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(W.nd_cj.p, &sm.cj, 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(W.nd_pdcal.p, &sm.pdcal, 4, hipMemcpyHostToDevice));
+    {
+        NodeRec root;                                       // region 0 as init_roots_kernel left it, with the given loop
+        HIPCHK(hipMemcpy(&root, W.nd.p, sizeof root, hipMemcpyDeviceToHost));
+        root.n = n; root.nbr = nbr; root.ci = sm.ci; root.cj = sm.cj; root.pdcal = sm.pdcal;
+        HIPCHK(hipMemcpy(W.nd.p, &root, sizeof root, hipMemcpyHostToDevice));
+    }
     int cls = node_class(n, one[0].len, nbr);
     int zero = 0;
     memset(&w.hc.n_work, 0, sizeof w.hc.n_work);

@@ -6,7 +6,7 @@
 //   struct table st_*   one row per beam survivor: energy (dcal), 128-bit pair-set hash,
 //                       dot-bracket row offset, node range, product cursor, lineage
 //   db arena            dot-bracket bytes of every survivor (L per structure)
-//   node table nd_*     one row per unpaired region.  A region is exactly one loop of
+//   node table nd[]     one 64-byte row per unpaired region.  A region is exactly one loop of
 //                       the structure: closing pair (ci,cj) (ci<0: exterior loop), the
 //                       ordered unpaired positions `pos` and the ordered branch helices
 //                       `br` hanging in that loop.  Its candidate stems depend on
@@ -45,6 +45,13 @@ static_assert(sizeof(Cand) == 32, "Cand must be 32 bytes");
 #define SEEN0 8192      // initial slots of a sequence's `seen` set (grows x2 by rehash)
 #define NCLS 4
 struct ShardCtr { unsigned long long v; unsigned long long pad[7]; };   // one 64-byte line each
+
+// region row: one loop of one structure (see the file header)
+struct alignas(64) NodeRec {
+    int32_t seq, pdcal, n, ci, cj, nbr, ncand, pad;
+    uint64_t pos, br, cand, pad2;
+};
+static_assert(sizeof(NodeRec) == 64, "NodeRec must be one cache line");
 
 struct ProdEnt { uint32_t cnt; int32_t node; uint64_t off; };   // one productive region of a structure
 // one new beam member to materialize: everything materialize_kernel needs to start, in one 48-byte read
@@ -100,8 +107,8 @@ struct Dev {
     // nodes
     uint32_t nd_cap;
     uint64_t nd_base, nd_shard_cap, pos_base, pos_shard_cap, br_shard_cap, db_base, db_shard_cap, cand_shard_cap;
-    int *nd_seq, *nd_pdcal, *nd_n, *nd_ci, *nd_cj, *nd_nbr, *nd_canon, *nd_ncand;
-    uint64_t *nd_pos, *nd_br, *nd_cand;
+    NodeRec *nd;                 // one 64-byte record per region (one cache line: header reads and writes are one transaction)
+    int *nd_canon;               // canonical region of every region (its own array: the beam step scans it along a structure)
     // loop table: open addressing, word = (hash tag << 32) | (node id + 1)
     unsigned long long *looptab; uint64_t looptab_cap;   // power of two
     // arenas

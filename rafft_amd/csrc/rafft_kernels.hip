@@ -179,12 +179,12 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         fetch_base++; fetch_left--;
         if (item >= n_items) break;
         const int nid = d.work[cls][item];
-        const int sq = d.nd_seq[nid];
+        const int sq = d.nd[nid].seq;
         const int L = d.seq_len[sq];
-        const int n = d.nd_n[nid], ci = d.nd_ci[nid], cj = d.nd_cj[nid], nbr = d.nd_nbr[nid];
-        const int par_dcal = d.nd_pdcal[nid];
-        const uint16_t *posg = d.pos + d.nd_pos[nid];
-        const uint32_t *brg = d.br + d.nd_br[nid];
+        const int n = d.nd[nid].n, ci = d.nd[nid].ci, cj = d.nd[nid].cj, nbr = d.nd[nid].nbr;
+        const int par_dcal = d.nd[nid].pdcal;
+        const uint16_t *posg = d.pos + d.nd[nid].pos;
+        const uint32_t *brg = d.br + d.nd[nid].br;
         const uint8_t *codes = d.codes + d.seq_off[sq];
         const int m = 2 * n - 1;
         const int P = next_pow2_ge(m);
@@ -849,8 +849,8 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
             }
         }
         if (tid == 0) {
-            d.nd_cand[nid] = cbase;
-            d.nd_ncand[nid] = ovf ? 0 : nkept;
+            d.nd[nid].cand = cbase;
+            d.nd[nid].ncand = ovf ? 0 : nkept;
             if (d.dbg.n_ranked) d.dbg.n_ranked[1] = nkept;
         }
         ESTAMP(7);   // emit
@@ -1018,9 +1018,9 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
                     unsigned long long coff = 0;
                     if (i < nn) {
                         cn = d.nd_canon[node0 + i];
-                        cnt = d.nd_ncand[cn];
+                        cnt = d.nd[cn].ncand;
                         if (cnt > 0) {
-                            coff = d.nd_cand[cn];
+                            coff = d.nd[cn].cand;
                             const Cand *cp = &d.cand[coff];
                             tot = sat_mul(tot, (unsigned long long)cnt);
                             dc += cp->ddcal; h1 += cp->h1; h2 += cp->h2; np++;
@@ -1461,9 +1461,9 @@ __device__ inline MatDesc mat_describe(const Dev &d, int pn, int selk)
 {
     MatDesc m;
     m.pn = pn;
-    const unsigned long long coff = d.nd_cand[pn];
-    m.n = d.nd_n[pn]; m.nbr = d.nd_nbr[pn]; m.ci = d.nd_ci[pn]; m.cj = d.nd_cj[pn];
-    m.srcpos = d.nd_pos[pn]; m.srcbr = d.nd_br[pn];
+    const unsigned long long coff = d.nd[pn].cand;
+    m.n = d.nd[pn].n; m.nbr = d.nd[pn].nbr; m.ci = d.nd[pn].ci; m.cj = d.nd[pn].cj;
+    m.srcpos = d.nd[pn].pos; m.srcbr = d.nd[pn].br;
     const Cand cd = d.cand[coff + selk];
     m.mi = cd.mi; m.mj = cd.mj; m.nb = cd.nb;
     const uint16_t *pp = d.pos + m.srcpos;
@@ -1592,15 +1592,15 @@ __global__ __launch_bounds__(MAT_NT) void materialize_kernel(Dev d)
             int nid = (int)(nbase + run_nodes + (xn - vn));
             const unsigned long long poff = pbase + run_pos + p0, boff = bbase + run_br + b0;
             if (md.flags & 1) {
-                d.nd_seq[nid] = sq; d.nd_pdcal[nid] = my_dcal; d.nd_pos[nid] = poff; d.nd_n[nid] = md.npos_in;
-                d.nd_ci[nid] = md.a0; d.nd_cj[nid] = md.b0; d.nd_br[nid] = boff; d.nd_nbr[nid] = md.nbr_in;
-                d.nd_ncand[nid] = -1; d.nd_cand[nid] = 0; d.nd_canon[nid] = nid;
+                d.nd[nid].seq = sq; d.nd[nid].pdcal = my_dcal; d.nd[nid].pos = poff; d.nd[nid].n = md.npos_in;
+                d.nd[nid].ci = md.a0; d.nd[nid].cj = md.b0; d.nd[nid].br = boff; d.nd[nid].nbr = md.nbr_in;
+                d.nd[nid].ncand = -1; d.nd[nid].cand = 0; d.nd_canon[nid] = nid;
                 nid++;
             }
             if (md.flags & 2) {
-                d.nd_seq[nid] = sq; d.nd_pdcal[nid] = my_dcal; d.nd_pos[nid] = poff + md.npos_in; d.nd_n[nid] = md.npos_out;
-                d.nd_ci[nid] = md.ci; d.nd_cj[nid] = md.cj; d.nd_br[nid] = boff + md.nbr_in; d.nd_nbr[nid] = md.nbr_out;
-                d.nd_ncand[nid] = -1; d.nd_cand[nid] = 0; d.nd_canon[nid] = nid;
+                d.nd[nid].seq = sq; d.nd[nid].pdcal = my_dcal; d.nd[nid].pos = poff + md.npos_in; d.nd[nid].n = md.npos_out;
+                d.nd[nid].ci = md.ci; d.nd[nid].cj = md.cj; d.nd[nid].br = boff + md.nbr_in; d.nd[nid].nbr = md.nbr_out;
+                d.nd[nid].ncand = -1; d.nd[nid].cand = 0; d.nd_canon[nid] = nid;
             }
         }
         __syncthreads();
@@ -1654,10 +1654,10 @@ __global__ __launch_bounds__(MAT_NT) void materialize_kernel(Dev d)
 
 __device__ inline bool same_loop(const Dev &d, int a, int b)
 {
-    if (d.nd_seq[a] != d.nd_seq[b] || d.nd_ci[a] != d.nd_ci[b] || d.nd_cj[a] != d.nd_cj[b] ||
-        d.nd_nbr[a] != d.nd_nbr[b] || d.nd_n[a] != d.nd_n[b]) return false;
-    const uint32_t *x = d.br + d.nd_br[a], *y = d.br + d.nd_br[b];
-    for (int i = 0, k = d.nd_nbr[a]; i < k; i++)
+    if (d.nd[a].seq != d.nd[b].seq || d.nd[a].ci != d.nd[b].ci || d.nd[a].cj != d.nd[b].cj ||
+        d.nd[a].nbr != d.nd[b].nbr || d.nd[a].n != d.nd[b].n) return false;
+    const uint32_t *x = d.br + d.nd[a].br, *y = d.br + d.nd[b].br;
+    for (int i = 0, k = d.nd[a].nbr; i < k; i++)
         if (x[i] != y[i]) return false;
     return true;
 }
@@ -1694,9 +1694,9 @@ __global__ __launch_bounds__(256) void dedupe_kernel(Dev d)
             nid = (int)(d.nd_base + (unsigned long long)lo * d.nd_shard_cap + prev[lo] + (f - pre[lo]));
             int canon = nid;
             if (d.memo) {
-                const uint32_t *bb = d.br + d.nd_br[nid];
-                const int nbr = d.nd_nbr[nid];
-                uint64_t h = mix64(((uint64_t)(uint32_t)d.nd_seq[nid] << 32) ^ ((uint64_t)(uint32_t)(d.nd_ci[nid] + 1) << 16) ^ (uint32_t)d.nd_cj[nid]);
+                const uint32_t *bb = d.br + d.nd[nid].br;
+                const int nbr = d.nd[nid].nbr;
+                uint64_t h = mix64(((uint64_t)(uint32_t)d.nd[nid].seq << 32) ^ ((uint64_t)(uint32_t)(d.nd[nid].ci + 1) << 16) ^ (uint32_t)d.nd[nid].cj);
                 for (int t = 0; t < nbr; t++) h += mix64((uint64_t)bb[t] ^ 0x5bd1e9955bd1e995ULL);
                 const unsigned long long tag = (h >> 32) | 0x80000000ULL;
                 const uint64_t mask = d.looptab_cap - 1;
@@ -1714,8 +1714,8 @@ __global__ __launch_bounds__(256) void dedupe_kernel(Dev d)
             }
             if (canon == nid) {
                 // a stem needs two unpaired positions: a lone position (bulge remnant) has no candidates
-                if (d.nd_n[nid] < 2) d.nd_ncand[nid] = 0;
-                else cls = node_class(d.nd_n[nid], d.seq_len[d.nd_seq[nid]], d.nd_nbr[nid], d.merge_cls);
+                if (d.nd[nid].n < 2) d.nd[nid].ncand = 0;
+                else cls = node_class(d.nd[nid].n, d.seq_len[d.nd[nid].seq], d.nd[nid].nbr, d.merge_cls);
             }
             else { d.nd_canon[nid] = canon; aliases++; }
         }
@@ -1749,9 +1749,9 @@ __global__ void init_roots_kernel(Dev d)
         d.st_seq[sq] = sq; d.st_dcal[sq] = 0; d.st_h[2 * (size_t)sq] = 0; d.st_h[2 * (size_t)sq + 1] = 0;
         d.st_db[sq] = off; d.st_node0[sq] = sq; d.st_nnodes[sq] = L > 0 ? 1 : 0; d.st_cursor[sq] = 0; d.st_total[sq] = 0;
         d.st_parent[sq] = -1; d.st_combo[sq] = 0;
-        d.nd_seq[sq] = sq; d.nd_pdcal[sq] = 0; d.nd_pos[sq] = off; d.nd_n[sq] = L; d.nd_ci[sq] = -1; d.nd_cj[sq] = L;
-        d.nd_br[sq] = 0; d.nd_nbr[sq] = 0; d.nd_canon[sq] = sq;
-        d.nd_ncand[sq] = -1; d.nd_cand[sq] = 0;
+        d.nd[sq].seq = sq; d.nd[sq].pdcal = 0; d.nd[sq].pos = off; d.nd[sq].n = L; d.nd[sq].ci = -1; d.nd[sq].cj = L;
+        d.nd[sq].br = 0; d.nd[sq].nbr = 0; d.nd_canon[sq] = sq;
+        d.nd[sq].ncand = -1; d.nd[sq].cand = 0;
         d.beam[(size_t)sq * d.B] = sq; d.beam_n[sq] = 1; d.nsteps[sq] = 0;
         d.done[sq] = L > 0 ? 0 : 1;
         d.seen_off[sq] = (uint64_t)sq * SEEN0; d.seen_cap[sq] = SEEN0; d.seen_cnt[sq] = 0;   // zeroed by the host memset
