@@ -60,7 +60,7 @@ struct Workspace {
     void *hot = nullptr;                 // pinned, 256 B
     // named device buffers (grow-only)
     Buf codes, seq_off, seq_len, beam, beam_n, done, nsteps, ch_parent, ch_combo, ch_dcal, ch_h, seen, seen_off,
-        seen_cap, seen_cnt, st_seq, st_dcal, st_node0, st_nnodes, st_parent, st_h, st_db, st_cursor, st_combo, st_total, st_prod, st_nprod, st_c0h, st_c0d, prod, nd, nd_canon, pos, br, db, cand, looptab, trec, tsid,
+        seen_cap, seen_cnt, st, prod, nd, nd_canon, pos, br, db, cand, looptab, trec, tsid,
         work0, work1, work2, work3, mat, counters,
         row_sid, row_off, out_db, out_dcal, row_off2, out_db2, out_dcal2, dbg;
     std::vector<hipEvent_t> ev_pool;
@@ -310,7 +310,7 @@ Caps plan_caps(size_t S, size_t sumL, const rafft_params &p, double est)
     // keys of one step: children + old beam; only the max_stack selected ones are sorted (padded to a power of two)
     int m2 = 2; while (m2 < p.max_stack) m2 <<= 1;
     c.sort_cap = std::max((need + 1) & ~1, m2);
-    c.bytes = c.st * (4 * 7 + 8 * 8) + c.nd * (64 + 4 + 4 * 4 + 16) + c.pos * 2 + c.br * 4 + c.db + c.cand * 32 + c.seen * 16 +
+    c.bytes = c.st * 128 + c.nd * (64 + 4 + 4 * 4 + 16) + c.pos * 2 + c.br * 4 + c.db + c.cand * 32 + c.seen * 16 +
               c.looptab * 8 + c.trec * 16 + c.tsid * 4 + c.mat * 48 + S * (size_t)c.ch_cap * 32 + S * B * 4;
     return c;
 }
@@ -427,8 +427,7 @@ int Wave::setup()
     ENS(beam, S * B * 4); ENS(beam_n, S * 4); ENS(done, S * 4); ENS(nsteps, S * 4);
     ENS(ch_parent, S * c.ch_cap * 2); ENS(ch_combo, S * c.ch_cap * 8); ENS(ch_dcal, S * c.ch_cap * 4); ENS(ch_h, S * c.ch_cap * 16);
     ENS(seen, c.seen * 16); ENS(seen_off, S * 8); ENS(seen_cap, S * 4); ENS(seen_cnt, S * 4);
-    ENS(st_seq, c.st * 4); ENS(st_dcal, c.st * 4); ENS(st_node0, c.st * 4); ENS(st_nnodes, c.st * 4); ENS(st_parent, c.st * 4);
-    ENS(st_h, c.st * 16); ENS(st_db, c.st * 8); ENS(st_cursor, c.st * 8); ENS(st_combo, c.st * 8); ENS(st_total, c.st * 8); ENS(st_prod, c.st * 8); ENS(st_nprod, c.st * 4); ENS(st_c0h, c.st * 16); ENS(st_c0d, c.st * 4); ENS(prod, c.nd * 16);
+    ENS(st, c.st * sizeof(StRec)); ENS(prod, c.nd * 16);
     ENS(nd, c.nd * sizeof(NodeRec)); ENS(nd_canon, c.nd * 4);
     ENS(pos, c.pos * 2); ENS(br, c.br * 4); ENS(db, c.db); ENS(cand, c.cand * 32);
     ENS(looptab, c.looptab * 8);
@@ -458,10 +457,7 @@ int Wave::setup()
     d.seen = (uint64_t *)g.seen.p; d.seen_cap_total = c.seen;
     d.seen_off = (uint64_t *)g.seen_off.p; d.seen_cap = (uint32_t *)g.seen_cap.p; d.seen_cnt = (uint32_t *)g.seen_cnt.p;
     d.st_cap = (uint32_t)c.st;
-    d.st_seq = (int *)g.st_seq.p; d.st_dcal = (int *)g.st_dcal.p; d.st_node0 = (int *)g.st_node0.p; d.st_nnodes = (int *)g.st_nnodes.p;
-    d.st_parent = (int *)g.st_parent.p; d.st_h = (uint64_t *)g.st_h.p; d.st_db = (uint64_t *)g.st_db.p;
-    d.st_cursor = (uint64_t *)g.st_cursor.p; d.st_combo = (uint64_t *)g.st_combo.p; d.st_total = (uint64_t *)g.st_total.p; d.st_prod = (uint64_t *)g.st_prod.p; d.st_nprod = (int *)g.st_nprod.p;
-    d.st_c0h = (uint64_t *)g.st_c0h.p; d.st_c0d = (int *)g.st_c0d.p;
+    d.st = (StRec *)g.st.p;
     d.prod = (ProdEnt *)g.prod.p; d.prod_shard_cap = c.nd / NSHARD;
     d.nd_cap = (uint32_t)c.nd;
     d.nd = (NodeRec *)g.nd.p; d.nd_canon = (int *)g.nd_canon.p;

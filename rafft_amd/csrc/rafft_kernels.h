@@ -3,7 +3,7 @@
 // Data layout in HBM (one batch = many independent sequences; SoA tables + bump
 // arenas, monotonic inside a batch so no kernel ever frees):
 //   codes[sum L]        uint8 base codes (N=0 A=1 C=2 G=3 U=4)
-//   struct table st_*   one row per beam survivor: energy (dcal), 128-bit pair-set hash,
+//   struct table st[]   one 128-byte row per beam survivor: energy (dcal), 128-bit pair-set hash,
 //                       dot-bracket row offset, node range, product cursor, lineage
 //   db arena            dot-bracket bytes of every survivor (L per structure)
 //   node table nd[]     one 64-byte row per unpaired region.  A region is exactly one loop of
@@ -45,6 +45,17 @@ static_assert(sizeof(Cand) == 32, "Cand must be 32 bytes");
 #define SEEN0 8192      // initial slots of a sequence's `seen` set (grows x2 by rehash)
 #define NCLS 4
 struct ShardCtr { unsigned long long v; unsigned long long pad[7]; };   // one 64-byte line each
+
+// structure row: one beam survivor (see the file header)
+struct alignas(128) StRec {
+    int32_t seq, dcal, node0, nnodes, parent, nprod;   // sequence, energy, region range, lineage, productive regions
+    int32_t c0d, pad;                                  // energy of its combo 0 (kept for resumed product walks)
+    uint64_t h1, h2;                                   // 128-bit pair-set hash
+    uint64_t db, cursor, combo, total, prod;           // dot-bracket row, product cursor, combo it came from, product size, productive-region list
+    uint64_t c0h1, c0h2;                               // hash of its combo 0
+    uint64_t pad2[3];
+};
+static_assert(sizeof(StRec) == 128, "StRec is two cache lines");
 
 // region row: one loop of one structure (see the file header)
 struct alignas(64) NodeRec {
@@ -99,10 +110,7 @@ struct Dev {
     uint64_t *seen_off; uint32_t *seen_cap, *seen_cnt;
     // structures
     uint32_t st_cap;
-    int *st_seq, *st_dcal, *st_node0, *st_nnodes, *st_parent;
-    uint64_t *st_h, *st_db, *st_cursor, *st_combo, *st_total, *st_prod;
-    int *st_nprod;
-    uint64_t *st_c0h; int *st_c0d;   // hash and energy of a structure's combo 0 (kept for resumed product walks)
+    StRec *st;                   // one 128-byte record per structure (two cache lines)
     ProdEnt *prod; uint64_t prod_shard_cap;
     // nodes
     uint32_t nd_cap;

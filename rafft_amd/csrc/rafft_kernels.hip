@@ -990,20 +990,20 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
             const int b = b0 + wv * gpw + grp;
             if (b >= nbeam) continue;
             const int sid = oldbeam[b];
-            const unsigned long long cur0 = d.st_cursor[sid], tot0 = d.st_total[sid], dboff = d.st_db[sid];
+            const unsigned long long cur0 = d.st[sid].cursor, tot0 = d.st[sid].total, dboff = d.st[sid].db;
             if (tot0 && cur0 >= tot0) { if (gl == 0) pinfo[b].flag = 1; continue; }
             const bool resumed = tot0 && cur0 > 0;
             unsigned long long pbase = 0, tot = 1, h1 = 0, h2 = 0;
             int dc = 0, np = 0, wpos = 0, nm = 0, rl0 = -1;
             if (resumed) {       // expanded in an earlier step: cursor, total and combo 0 are on record
-                pbase = d.st_prod[sid]; wpos = d.st_nprod[sid];
+                pbase = d.st[sid].prod; wpos = d.st[sid].nprod;
                 for (int base = 0; base < wpos; base += G) {
                     const int i = base + gl;
                     const int cnt = i < wpos ? (int)d.prod[pbase + i].cnt : 0;
                     nm += __popcll((__ballot(cnt >= 2) >> (grp * G)) & gmask);
                 }
             } else {
-                const int node0 = d.st_node0[sid], nn = d.st_nnodes[sid];
+                const int node0 = d.st[sid].node0, nn = d.st[sid].nnodes;
                 // first visit of this structure: its productive regions (node order, rafft/rafft.py:166-171) are
                 // written once as a compact list that later product walks and materialize_kernel read back
                 if (gl == 0) {
@@ -1042,7 +1042,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
                 }
                 if (pbase == ~0ULL) { pbase = 0; wpos = 0; nm = 0; }
                 if (wpos > MAX_PROD && gl == 0) atomicOr(&d.c->overflow, OVF_PROD);     // materialize_kernel's limit
-                if (gl == 0) { d.st_prod[sid] = pbase; d.st_nprod[sid] = wpos; }
+                if (gl == 0) { d.st[sid].prod = pbase; d.st[sid].nprod = wpos; }
                 if (gl == 0 && wpos > 64) atomicMax(&d.c->max_nprod, (unsigned int)wpos);
                 for (int o = G >> 1; o > 0; o >>= 1) {
                     tot = sat_mul(tot, __shfl_xor(tot, o, 64));
@@ -1051,7 +1051,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
                 }
                 if (nn > G) __threadfence_block();       // the list is read back below by other lanes of the group
             }
-            if (resumed || (!resumed && wpos > 0 && rl0 < 0 && nm > 0 && d.st_nnodes[sid] > G)) {
+            if (resumed || (!resumed && wpos > 0 && rl0 < 0 && nm > 0 && d.st[sid].nnodes > G)) {
                 // region list from the productive-region list in global memory
                 if (gl == 0) { const int o = atomicAdd(&sh[26], nm); rl0 = o + nm <= d.rl_cap ? o : -1; }
                 rl0 = __shfl(rl0, grp * G, 64);
@@ -1071,13 +1071,13 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
                 pi.sid = sid; pi.prod = pbase; pi.nprod = wpos; pi.rl0 = nm == 0 ? 0 : rl0; pi.nrl = nm; pi.db = dboff;
                 if (resumed) {
                     pi.flag = 2; pi.total = tot0; pi.cur = cur0;
-                    pi.h1 = d.st_c0h[2 * (size_t)sid]; pi.h2 = d.st_c0h[2 * (size_t)sid + 1]; pi.dcal0 = d.st_c0d[sid];
+                    pi.h1 = d.st[sid].c0h1; pi.h2 = d.st[sid].c0h2; pi.dcal0 = d.st[sid].c0d;
                 } else {
                     pi.flag = np == 0 ? 1 : 0; pi.total = tot; pi.cur = 0;
-                    pi.h1 = d.st_h[2 * (size_t)sid] + h1; pi.h2 = d.st_h[2 * (size_t)sid + 1] + h2;
-                    pi.dcal0 = d.st_dcal[sid] + dc;
-                    d.st_c0h[2 * (size_t)sid] = pi.h1; d.st_c0h[2 * (size_t)sid + 1] = pi.h2; d.st_c0d[sid] = pi.dcal0;
-                    if (np == 0) { d.st_total[sid] = 1; d.st_cursor[sid] = 1; }
+                    pi.h1 = d.st[sid].h1 + h1; pi.h2 = d.st[sid].h2 + h2;
+                    pi.dcal0 = d.st[sid].dcal + dc;
+                    d.st[sid].c0h1 = pi.h1; d.st[sid].c0h2 = pi.h2; d.st[sid].c0d = pi.dcal0;
+                    if (np == 0) { d.st[sid].total = 1; d.st[sid].cursor = 1; }
                 }
                 pinfo[b] = pi;
             }
@@ -1246,17 +1246,17 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
             // the reference stops walking after the combo that brings nb_branch to max_branch
             if (accepted && ex == need - 1) {
                 sh[21] = b; *(unsigned long long *)&sh[22] = pos;
-                d.st_cursor[sidb] = idx + 1; d.st_total[sidb] = totb;
+                d.st[sidb].cursor = idx + 1; d.st[sidb].total = totb;
             }
             __syncthreads();
             const unsigned long long hpos = *(unsigned long long *)&sh[22];
-            if (tid < chunk && last_combo && pos < hpos) { d.st_cursor[sidb] = totb; d.st_total[sidb] = totb; }
+            if (tid < chunk && last_combo && pos < hpos) { d.st[sidb].cursor = totb; d.st[sidb].total = totb; }
             nchild += need; nb_branch += need; scnt += need;
             single_from = sh[21] + 1;
             __syncthreads();
             break;
         }
-        if (tid < chunk && last_combo) { d.st_cursor[sidb] = totb; d.st_total[sidb] = totb; }   // product exhausted
+        if (tid < chunk && last_combo) { d.st[sidb].cursor = totb; d.st[sidb].total = totb; }   // product exhausted
         nchild += tot; nb_branch += tot; scnt += tot;
         W += (unsigned long long)chunk;
         for (int i = tid; i < 2 * BS_NT; i += BS_NT) wk_tab[i] = 0;
@@ -1321,7 +1321,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
                 } else atomicOr(&d.c->overflow, OVF_SORT);
                 seen_insert(stab, scap, h1, h2);
             }
-            if (b < nbeam && pinfo[b].flag == 0) { d.st_cursor[oldbeam[b]] = 1; d.st_total[oldbeam[b]] = pinfo[b].total; }
+            if (b < nbeam && pinfo[b].flag == 0) { d.st[oldbeam[b]].cursor = 1; d.st[oldbeam[b]].total = pinfo[b].total; }
             nchild += tot; nb_branch += tot; scnt += tot;
             __syncthreads();
         }
@@ -1336,7 +1336,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
     for (int i = tid; i < N; i += BS_NT) {
         unsigned long long key;
         if (i < nchild) key = ((unsigned long long)(uint32_t)(d.ch_dcal[chb + i] + 0x40000000) << 32) | (uint32_t)i;
-        else key = ((unsigned long long)(uint32_t)(d.st_dcal[oldbeam[i - nchild]] + 0x40000000) << 32) | (uint32_t)i;
+        else key = ((unsigned long long)(uint32_t)(d.st[oldbeam[i - nchild]].dcal + 0x40000000) << 32) | (uint32_t)i;
         skey[i] = key;
     }
     __syncthreads();
@@ -1410,15 +1410,15 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
             if (f) {
                 int sid = sbase + run + ex;
                 size_t c = chb + ord;
-                d.st_seq[sid] = sq;
-                d.st_dcal[sid] = d.ch_dcal[c];
-                d.st_h[2 * (size_t)sid] = d.ch_h[2 * c];
-                d.st_h[2 * (size_t)sid + 1] = d.ch_h[2 * c + 1];
-                d.st_parent[sid] = oldbeam[d.ch_parent[c]];
-                d.st_combo[sid] = d.ch_combo[c];
-                d.st_cursor[sid] = 0;
-                d.st_total[sid] = 0;
-                d.st_nnodes[sid] = 0;
+                d.st[sid].seq = sq;
+                d.st[sid].dcal = d.ch_dcal[c];
+                d.st[sid].h1 = d.ch_h[2 * c];
+                d.st[sid].h2 = d.ch_h[2 * c + 1];
+                d.st[sid].parent = oldbeam[d.ch_parent[c]];
+                d.st[sid].combo = d.ch_combo[c];
+                d.st[sid].cursor = 0;
+                d.st[sid].total = 0;
+                d.st[sid].nnodes = 0;
                 {
                     const ParentInfo &pp_ = pinfo[d.ch_parent[c]];
                     MatRec mr;
@@ -1557,7 +1557,7 @@ __global__ __launch_bounds__(MAT_NT) void materialize_kernel(Dev d)
         if (tid == 0) shi[0] = anybad ? 0 : 1;
     }
     __syncthreads();
-    if (!shi[0]) { if (tid == 0) { d.st_nnodes[sid] = 0; d.st_node0[sid] = 0; d.st_db[sid] = 0; } return; }
+    if (!shi[0]) { if (tid == 0) { d.st[sid].nnodes = 0; d.st[sid].node0 = 0; d.st[sid].db = 0; } return; }
     const unsigned long long nbase = sh64[0], pbase = sh64[1], tbase = sh64[2], bbase = sh64[3];
     MSTAMP(2);   // allocation
 
@@ -1644,7 +1644,7 @@ __global__ __launch_bounds__(MAT_NT) void materialize_kernel(Dev d)
     }
     uint8_t *odb = d.db + tbase;
     for (int x = tid; x < L; x += MAT_NT) odb[x] = sdb[x];
-    if (tid == 0) { d.st_node0[sid] = (int)nbase; d.st_nnodes[sid] = tot_nodes; d.st_db[sid] = tbase; }
+    if (tid == 0) { d.st[sid].node0 = (int)nbase; d.st[sid].nnodes = tot_nodes; d.st[sid].db = tbase; }
     MSTAMP(6);   // row out
     if (mprof) for (int k = 0; k < 7; k++) atomicAdd(&d.prof_e[k], macc[k]);
 #undef MSTAMP
@@ -1746,9 +1746,9 @@ __global__ void init_roots_kernel(Dev d)
     for (int x = tid; x < L; x += blockDim.x) { d.db[off + x] = '.'; d.pos[off + x] = (uint16_t)x; }
 
     if (tid == 0) {
-        d.st_seq[sq] = sq; d.st_dcal[sq] = 0; d.st_h[2 * (size_t)sq] = 0; d.st_h[2 * (size_t)sq + 1] = 0;
-        d.st_db[sq] = off; d.st_node0[sq] = sq; d.st_nnodes[sq] = L > 0 ? 1 : 0; d.st_cursor[sq] = 0; d.st_total[sq] = 0;
-        d.st_parent[sq] = -1; d.st_combo[sq] = 0;
+        d.st[sq].seq = sq; d.st[sq].dcal = 0; d.st[sq].h1 = 0; d.st[sq].h2 = 0;
+        d.st[sq].db = off; d.st[sq].node0 = sq; d.st[sq].nnodes = L > 0 ? 1 : 0; d.st[sq].cursor = 0; d.st[sq].total = 0;
+        d.st[sq].parent = -1; d.st[sq].combo = 0;
         d.nd[sq].seq = sq; d.nd[sq].pdcal = 0; d.nd[sq].pos = off; d.nd[sq].n = L; d.nd[sq].ci = -1; d.nd[sq].cj = L;
         d.nd[sq].br = 0; d.nd[sq].nbr = 0; d.nd_canon[sq] = sq;
         d.nd[sq].ncand = -1; d.nd[sq].cand = 0;
@@ -1777,10 +1777,10 @@ __global__ void output_kernel(Dev d, int nrows, int nrec, const OutRec *recs, ch
         const int k = r - rc.row0;
         const int sid = d.tsid[rc.w + k];
         const int L = rc.L;
-        const uint8_t *db = d.db + d.st_db[sid];
+        const uint8_t *db = d.db + d.st[sid].db;
         char *o = out_db + rc.off + (long long)k * (L + 1);
         for (int x = threadIdx.x; x < L; x += blockDim.x) o[x] = (char)db[x];
-        if (threadIdx.x == 0) { o[L] = 0; out_dcal[r] = d.st_dcal[sid]; }
+        if (threadIdx.x == 0) { o[L] = 0; out_dcal[r] = d.st[sid].dcal; }
     }
 }
 
