@@ -140,6 +140,8 @@ def test_gpu_stage_timers_are_opt_in(bench_rows, monkeypatch):
     """timing events around every kernel cost ~7 % of a batch, so by default only the dominant kernel is timed;
     RAFFT_SPANS=2 fills the per-stage fields of rafft_stats, RAFFT_SPANS=0 leaves only the wall time"""
     seqs = [r["seq"] for r in bench_rows[::3]]
+    monkeypatch.setenv("RAFFT_MERGE_BELOW", "0")       # regions routed by size in every step: the dominant kernel
+    monkeypatch.setenv("RAFFT_MERGE2_BELOW", "0")      # (one-wavefront class) is launched whatever the batch size
     rafft_amd.fold_batch(seqs, 100, 50, 1000)
     st = rafft_amd.last_stats()
     assert st["ms_total"] > 0 and st["ms_expand"] > 0 and st["ms_beam"] == 0 and st["ms_materialize"] == 0
