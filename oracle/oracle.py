@@ -15,7 +15,8 @@ _LIB = None
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
     src = os.path.join(_HERE, "rafft_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    tab = os.path.join(_HERE, "..", "params", "turner2004_tables.h")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(tab)):
         subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
     return so
 

@@ -7,7 +7,7 @@
 // (new beam members) -> ... until every sequence reached its fixed point.
 #include "../../include/rafft_hip.h"
 #include "rafft_kernels.h"
-#include "turner2004_tables.h"
+#include "../../params/turner2004_tables.h"
 
 #include <algorithm>
 #include <chrono>
@@ -130,7 +130,10 @@ int init_ws(Workspace &w)
 
 int init_ctx(int device)
 {
-    if (g.ready && (device < 0 || device == g.device)) return 0;
+    if (g.ready && (device < 0 || device == g.device)) {
+        HIPCHK(hipSetDevice(g.device));    // HIP's current device is per host thread: bind it on every entry
+        return 0;
+    }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0)
@@ -402,7 +405,6 @@ int Wave::setup()
 {
     S = seqs.size();
     tw0 = std::chrono::steady_clock::now();
-    g.ev_used = 0;
     off.resize(S); len.resize(S);
     sumL = 0;
     for (size_t i = 0; i < S; i++) { off[i] = (int)sumL; len[i] = seqs[i].len; sumL += seqs[i].len; }
@@ -923,6 +925,9 @@ int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs, 
     auto t0 = std::chrono::steady_clock::now();
     memset(&g.stats, 0, sizeof g.stats);
     g_span_level = getenv("RAFFT_TRACE") ? 2 : getenv("RAFFT_SPANS") ? atoi(getenv("RAFFT_SPANS")) : 1;
+    // timing events are handed out monotonically for the whole call: the spans of a wave stay valid when a later
+    // wave (HBM-budget split, regrowth re-run) uses the same workspace
+    for (int i = 0; i < MAX_PIPES; i++) g.ws[i].ev_used = 0;
     HostOut *ho = new HostOut();
     ho->seq.resize(n_seq); ho->step_size.resize(n_seq); ho->step_off.resize(n_seq);
     ho->dcal_ptr.assign(n_seq, nullptr); ho->db_ptr.assign(n_seq, nullptr);
@@ -989,7 +994,9 @@ int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs, 
     }
     int rc = good.empty() ? 0 : run_pipelines(*p, queues, *ho, spans);
     if (rc) {
-        for (int i = 0; i < MAX_PIPES; i++) if (g.ws[i].ready) { hipError_t e_ = hipStreamSynchronize(g.ws[i].stream); (void)e_; }
+        // early-harvest copies (copy_stream) or kernels of the other pipeline may still be in flight: the pinned
+        // result chunks return to the pool only once the whole device is idle
+        { hipError_t e_ = hipDeviceSynchronize(); (void)e_; }
         free_out(ho);
         return rc;
     }
