@@ -26,7 +26,7 @@ enum {
     RAFFT_ERR_BAD_CHAR = 1,      /* reference: KeyError from prep_sequence, rafft/utils.py:73-80 */
     RAFFT_ERR_EMPTY = 2,         /* reference: numpy AxisError from flip(), rafft/utils.py:83 */
     RAFFT_ERR_TOO_LONG = 3,      /* L > RAFFT_MAX_LEN (one node's FFT must fit one workgroup's LDS) */
-    RAFFT_ERR_TEMP = 4,          /* only 37 C tables exist (no ViennaRNA to rescale with) */
+    RAFFT_ERR_TEMP = 4,          /* temp != 37 with the built-in 37 C tables (no enthalpies): load a parameter file first */
     RAFFT_ERR_CAPACITY = 5,      /* an HBM arena overflowed even after regrowth */
     RAFFT_ERR_PARAM = 6,         /* unsupported parameter combination (e.g. max_branch+2*max_stack too large) */
     RAFFT_ERR_HIP = 7,           /* HIP runtime error; see rafft_last_error() */
@@ -46,7 +46,7 @@ typedef struct {
     double min_nrj;      /* -mn */
     int32_t traj;        /* 0: final beam only; 1: beam of every folding step */
     int32_t _pad;
-    double temp;         /* must be 37.0 */
+    double temp;         /* md.temperature (rafft/utils.py:18); != 37.0 needs rafft_load_params() (enthalpy tables) */
     double gc_wei, au_wei, gu_wei;
 } rafft_params;
 
@@ -125,6 +125,26 @@ const char *rafft_last_error(void);
 int rafft_eval_structure(const char *seq, const char *db, int *dcal_out);
 int rafft_eval_structures(int n, const char *const *seqs, const char *const *dbs, int *dcal_out,
                           int *status_out);
+/* the same at md.temperature = temp (rafft/utils.py:18) */
+int rafft_eval_structures_at(double temp, int n, const char *const *seqs, const char *const *dbs, int *dcal_out,
+                             int *status_out);
+
+/* Energy parameters.  Replaces: the parameter set behind RNA.md() / RNA.fold_compound(sequence, md)
+ * (rafft/utils.py:17-21) - ViennaRNA's compiled-in Turner 2004 set, or whatever the user loaded with
+ * RNA.params_load(), rescaled to md.temperature.  rafft_load_params() reads the file format ViennaRNA 2.x reads and
+ * writes ("## RNAfold parameter file v2.0": misc/rna_turner2004.par, RNA.params_save()), so ViennaRNA is touched
+ * once, up front, for the tables and never inside the fold.  Without it the built-in 37 C tables are used
+ * (DESIGN.md section 2 says how those are pinned).  Loading, inspecting and saving need no GPU; the device tables
+ * are rebuilt by the next fold/eval call.  Not thread-safe against a fold running in another thread of the process
+ * beyond the library's own lock (calls are serialised). */
+int rafft_load_params(const char *path);
+int rafft_load_params_text(const char *text, const char *source_name);
+int rafft_reset_params(void);                                   /* back to the built-in tables */
+int rafft_save_params(const char *path);                        /* counterpart of RNA.params_save(path) */
+int rafft_params_info(char *source, int source_cap, int *has_enthalpies);
+/* one entry of the current set: ViennaRNA table name ("stack", "int21", "mismatch_multi", "ml_closing", ...),
+ * 37 C value or enthalpy, flat row-major index in ViennaRNA's array shape (pair axes 0..7, base axes 0..4) */
+int rafft_param_value(const char *table, int enthalpy, long index, int *value_out);
 
 /* Kernel-level seam for parity tests; replaces create_childs' search part:
  * auto_cor (rafft/utils.py:125-132) + ranking (rafft/rafft.py:117-118,92) +

@@ -40,7 +40,9 @@ class Stats(C.Structure):
 
 
 EXPORTS = ["rafft_init", "rafft_fold_batch", "rafft_free_result", "rafft_last_error", "rafft_eval_structure",
-           "rafft_eval_structures", "rafft_expand_node", "rafft_get_stats", "rafft_version"]
+           "rafft_eval_structures", "rafft_eval_structures_at", "rafft_expand_node", "rafft_get_stats", "rafft_version",
+           "rafft_load_params", "rafft_load_params_text", "rafft_reset_params", "rafft_save_params", "rafft_params_info",
+           "rafft_param_value"]
 
 _lib = None
 
@@ -74,6 +76,12 @@ def lib():
                                     C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int),
                                     C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int),
                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.rafft_eval_structures_at.argtypes = [C.c_double] + L.rafft_eval_structures.argtypes
+    L.rafft_load_params.argtypes = [C.c_char_p]
+    L.rafft_load_params_text.argtypes = [C.c_char_p, C.c_char_p]
+    L.rafft_save_params.argtypes = [C.c_char_p]
+    L.rafft_params_info.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int)]
+    L.rafft_param_value.argtypes = [C.c_char_p, C.c_int, C.c_long, C.POINTER(C.c_int)]
     L.rafft_get_stats.argtypes = [C.POINTER(Stats)]
     _lib = L
     return L

@@ -7,7 +7,7 @@
 // (new beam members) -> ... until every sequence reached its fixed point.
 #include "../../include/rafft_hip.h"
 #include "rafft_kernels.h"
-#include "../../params/turner2004_tables.h"
+#include "rafft_params.h"
 
 #include <algorithm>
 #include <chrono>
@@ -72,6 +72,9 @@ struct Ctx {
     int device = -1;
     int n_cu = 256;
     EnergyTables *T = nullptr;
+    double T_temp = -1e300;            // temperature the device tables were scaled for
+    bool T_dirty = true;               // the parameter set changed since the last upload
+    rafft_par::ParamSet *P = nullptr;  // current parameter set (built-in until rafft_load_params)
     float2 *tw = nullptr;
     size_t hbm_total = 0;
     Workspace ws[MAX_PIPES];
@@ -95,14 +98,23 @@ int ensure(Buf &b, size_t bytes)
     return 0;
 }
 
-uint32_t key_of(const char *s, int m)
+rafft_par::ParamSet &param_set()
 {
-    uint32_t k = 0;
-    for (int t = 0; t < m; t++) {
-        int c = s[t] == 'A' ? 1 : s[t] == 'C' ? 2 : s[t] == 'G' ? 3 : s[t] == 'U' ? 4 : 0;
-        k |= (uint32_t)c << (3 * t);
-    }
-    return k;
+    if (!g.P) { g.P = new rafft_par::ParamSet(); rafft_par::builtin(*g.P); }
+    return *g.P;
+}
+
+// Device energy tables for `temp`: the current parameter set rescaled as ViennaRNA does for md.temperature
+// (rafft/utils.py:17-21).  Every C-ABI call is synchronous, so the device is idle when the tables are replaced.
+int ensure_tables(double temp)
+{
+    if (!g.T_dirty && g.T_temp == temp) return 0;
+    std::unique_ptr<EnergyTables> h(new EnergyTables());
+    std::string err;
+    if (!rafft_par::scaled_tables(param_set(), temp, h.get(), err)) return fail(RAFFT_ERR_TEMP, err);
+    HIPCHK(hipMemcpy(g.T, h.get(), sizeof(EnergyTables), hipMemcpyHostToDevice));
+    g.T_temp = temp; g.T_dirty = false;
+    return 0;
 }
 
 int init_ws(Workspace &w)
@@ -146,42 +158,8 @@ int init_ctx(int device)
     HIPCHK(hipGetDeviceProperties(&prop, device));
     g.hbm_total = prop.totalGlobalMem;
     g.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    // energy tables
-    EnergyTables *h = new EnergyTables();
-    memset(h, 0, sizeof *h);
-    memcpy(h->s.stack, t04_stack, sizeof h->s.stack);
-    memcpy(h->s.mmH, t04_mismatch_hairpin, sizeof h->s.mmH);
-    memcpy(h->s.mmI, t04_mismatch_interior, sizeof h->s.mmI);
-    memcpy(h->s.mm1n, t04_mismatch_interior_1n, sizeof h->s.mm1n);
-    memcpy(h->s.mm23, t04_mismatch_interior_23, sizeof h->s.mm23);
-    memcpy(h->s.mmM, t04_mismatch_multi, sizeof h->s.mmM);
-    memcpy(h->s.mmE, t04_mismatch_exterior, sizeof h->s.mmE);
-    memcpy(h->s.d5, t04_dangle5, sizeof h->s.d5);
-    memcpy(h->s.d3, t04_dangle3, sizeof h->s.d3);
-    memcpy(h->b.int11, t04_int11, sizeof h->b.int11);
-    memcpy(h->b.int21, t04_int21, sizeof h->b.int21);
-    memcpy(h->b.int22, t04_int22, sizeof h->b.int22);
-    memcpy(h->s.hairpin, t04_hairpin, sizeof h->s.hairpin);
-    memcpy(h->s.bulge, t04_bulge, sizeof h->s.bulge);
-    memcpy(h->s.interior, t04_interior, sizeof h->s.interior);
-    h->s.ml_base = T04_ML_BASE; h->s.ml_closing = T04_ML_CLOSING; h->s.ml_intern = T04_ML_INTERN;
-    h->s.ninio = T04_NINIO; h->s.max_ninio = T04_MAX_NINIO; h->s.term_au = T04_TERMINAL_AU;
-    {
-        auto put = [&](uint32_t key, int size, int e) {
-            const uint32_t k = key | sp_tag(size);
-            uint32_t sl = sp_slot(k);
-            while (h->s.sp_key[sl]) sl = (sl + 1) & 127u;
-            h->s.sp_key[sl] = k; h->s.sp_e[sl] = e;
-        };
-        static_assert(T04_N_TRILOOPS + T04_N_TETRALOOPS + T04_N_HEXALOOPS <= 64, "special hairpin table too full");
-        for (int i = 0; i < T04_N_TRILOOPS; i++) put(key_of(t04_triloops_seq[i], 5), 3, t04_triloops_e[i]);
-        for (int i = 0; i < T04_N_TETRALOOPS; i++) put(key_of(t04_tetraloops_seq[i], 6), 4, t04_tetraloops_e[i]);
-        for (int i = 0; i < T04_N_HEXALOOPS; i++) put(key_of(t04_hexaloops_seq[i], 8), 6, t04_hexaloops_e[i]);
-    }
-    for (int sz = 31; sz <= RAFFT_MAX_LEN + 1; sz++) h->b.logext[sz] = (int)(T04_LXC * log(sz / 30.));
     HIPCHK(hipMalloc((void **)&g.T, sizeof(EnergyTables)));
-    HIPCHK(hipMemcpy(g.T, h, sizeof(EnergyTables), hipMemcpyHostToDevice));
-    delete h;
+    g.T_dirty = true;
     std::vector<float2> tw(MAX_P / 2);
     for (int m = 0; m < MAX_P / 2; m++) {
         double a = -2.0 * M_PI * (double)m / (double)MAX_P;
@@ -905,7 +883,7 @@ extern "C" {
 
 const char *rafft_last_error(void) { return g_err.c_str(); }
 
-const char *rafft_version(void) { return "raffthip 0.1 (gfx950, HIP; Turner-2004 37C tables)"; }
+const char *rafft_version(void) { return "raffthip 0.2 (gfx950, HIP; built-in Turner-2004 37C tables or ViennaRNA parameter files)"; }
 
 int rafft_init(int device)
 {
@@ -918,10 +896,14 @@ int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs, 
     std::lock_guard<std::mutex> lk(g.mu);
     if (!p || !out_ || n_seq < 0) return fail(RAFFT_ERR_PARAM, "null argument");
     *out_ = nullptr;
-    if (p->temp != 37.0) return fail(RAFFT_ERR_TEMP, "only temp=37.0 is supported (no enthalpy tables to rescale with)");
+    if (!(p->temp > -273.15 && p->temp < 1000.0)) return fail(RAFFT_ERR_TEMP, "temp out of range");
+    if (p->temp != 37.0 && !param_set().has_dH)
+        return fail(RAFFT_ERR_TEMP, "temp != 37 needs the enthalpy tables of a ViennaRNA parameter file (rafft_load_params); "
+                                    "the built-in tables are 37 C only");
     if (p->max_stack < 1 || p->max_stack > 65535) return fail(RAFFT_ERR_PARAM, "max_stack must be in [1, 65535]");
     if (p->nb_mode < 0 || p->max_branch < 0) return fail(RAFFT_ERR_PARAM, "nb_mode/max_branch must be >= 0");
     if (int rc = init_ctx(device)) return rc;
+    if (int rc = ensure_tables(p->temp)) return rc;
     auto t0 = std::chrono::steady_clock::now();
     memset(&g.stats, 0, sizeof g.stats);
     g_span_level = getenv("RAFFT_TRACE") ? 2 : getenv("RAFFT_SPANS") ? atoi(getenv("RAFFT_SPANS")) : 1;
@@ -1068,9 +1050,10 @@ static int parse_db(const char *seq, const char *db, int L, std::vector<int16_t>
     return stk.empty() ? 0 : RAFFT_ERR_STRUCT;
 }
 
-static int eval_structures_impl(int n, const char *const *seqs, const char *const *dbs, int *dcal_out, int *status_out)
+static int eval_structures_impl(int n, const char *const *seqs, const char *const *dbs, int *dcal_out, int *status_out, double temp = 37.0)
 {
     if (int rc = init_ctx(-1)) return rc;
+    if (int rc = ensure_tables(temp)) return rc;
     std::vector<long long> off(n);
     std::vector<int> len(n), status(n, 0);
     long long tot = 0;
@@ -1131,6 +1114,109 @@ int rafft_eval_structure(const char *seq, const char *db, int *dcal_out)
     return rafft_eval_structures(1, &seq, &db, dcal_out, nullptr);
 }
 
+int rafft_eval_structures_at(double temp, int n, const char *const *seqs, const char *const *dbs, int *dcal_out, int *status_out)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    return eval_structures_impl(n, seqs, dbs, dcal_out, status_out, temp);
+}
+
+// ---- energy parameters (no GPU needed to load, inspect or save a parameter set; the upload happens with the next fold)
+
+static int set_params_from_text(const std::string &text, const std::string &source)
+{
+    std::unique_ptr<rafft_par::ParamSet> P(new rafft_par::ParamSet());
+    std::string err;
+    if (!rafft_par::parse(text, *P, err)) return fail(RAFFT_ERR_PARAM, "parameter file " + source + ": " + err);
+    P->source = source;
+    {   // every table must survive the conversion to the device layout at 37 C
+        std::unique_ptr<EnergyTables> h(new EnergyTables());
+        if (!rafft_par::scaled_tables(*P, 37.0, h.get(), err)) return fail(RAFFT_ERR_PARAM, "parameter file " + source + ": " + err);
+    }
+    delete g.P;
+    g.P = P.release();
+    g.T_dirty = true;
+    return 0;
+}
+
+int rafft_load_params(const char *path)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!path) return fail(RAFFT_ERR_PARAM, "null path");
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(RAFFT_ERR_PARAM, std::string("cannot open parameter file ") + path);
+    std::string text;
+    char buf[65536];
+    size_t k;
+    while ((k = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, k);
+    fclose(f);
+    return set_params_from_text(text, path);
+}
+
+int rafft_load_params_text(const char *text, const char *source_name)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!text) return fail(RAFFT_ERR_PARAM, "null text");
+    return set_params_from_text(text, source_name ? source_name : "<memory>");
+}
+
+int rafft_reset_params(void)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    delete g.P;
+    g.P = nullptr;
+    g.T_dirty = true;
+    return 0;
+}
+
+int rafft_save_params(const char *path)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!path) return fail(RAFFT_ERR_PARAM, "null path");
+    const std::string txt = rafft_par::format(param_set());
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(RAFFT_ERR_PARAM, std::string("cannot write ") + path);
+    const bool ok = fwrite(txt.data(), 1, txt.size(), f) == txt.size();
+    fclose(f);
+    return ok ? 0 : fail(RAFFT_ERR_PARAM, std::string("short write to ") + path);
+}
+
+int rafft_params_info(char *source, int source_cap, int *has_enthalpies)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    const rafft_par::ParamSet &P = param_set();
+    if (source && source_cap > 0) { strncpy(source, P.source.c_str(), (size_t)source_cap - 1); source[source_cap - 1] = 0; }
+    if (has_enthalpies) *has_enthalpies = P.has_dH ? 1 : 0;
+    return 0;
+}
+
+// The 37 C value of one table entry of the current parameter set, by ViennaRNA table name and flat row-major index in
+// ViennaRNA's own array shape (pairs 0..7, bases 0..4): lets a caller check what a file gave without a GPU.
+int rafft_param_value(const char *table, int enthalpy, long index, int *value_out)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    const rafft_par::ParamSet &P = param_set();
+    if (!table || !value_out) return fail(RAFFT_ERR_PARAM, "null argument");
+    const int w = enthalpy ? 1 : 0;
+    struct Ent { const char *n; const int *p; long cnt; };
+    const Ent ents[] = {
+        {"stack", &P.stack[w][0][0], 64}, {"hairpin", P.hairpin[w], 31}, {"bulge", P.bulge[w], 31}, {"interior", P.interior[w], 31},
+        {"mismatch_hairpin", &P.mmH[w][0][0][0], 200}, {"mismatch_interior", &P.mmI[w][0][0][0], 200},
+        {"mismatch_interior_1n", &P.mm1n[w][0][0][0], 200}, {"mismatch_interior_23", &P.mm23[w][0][0][0], 200},
+        {"mismatch_multi", &P.mmM[w][0][0][0], 200}, {"mismatch_exterior", &P.mmE[w][0][0][0], 200},
+        {"dangle5", &P.d5[w][0][0], 40}, {"dangle3", &P.d3[w][0][0], 40},
+        {"int11", &P.int11[w][0][0][0][0], 8 * 8 * 25}, {"int21", &P.int21[w][0][0][0][0][0], 8 * 8 * 125},
+        {"int22", &P.int22[w][0][0][0][0][0][0], 8 * 8 * 625},
+        {"ninio", &P.ninio[w], 1}, {"ml_base", &P.ml_base[w], 1}, {"ml_closing", &P.ml_closing[w], 1}, {"ml_intern", &P.ml_intern[w], 1},
+        {"terminal_au", &P.term_au[w], 1}, {"max_ninio", &P.max_ninio, 1}};
+    for (const Ent &e : ents)
+        if (!strcmp(e.n, table)) {
+            if (index < 0 || index >= e.cnt) return fail(RAFFT_ERR_PARAM, "index out of range");
+            *value_out = e.p[index];
+            return 0;
+        }
+    return fail(RAFFT_ERR_PARAM, std::string("unknown table ") + table);
+}
+
 int rafft_expand_node(const rafft_params *p, const char *seq, const char *db, const int *pos, int n,
                       int *n_ranked, int *lag, double *corval, int *nb, int *mi, int *mj,
                       double *score, int *ddcal, int *n_kept, int *kept)
@@ -1158,7 +1244,7 @@ int rafft_expand_node(const rafft_params *p, const char *seq, const char *db, co
     }
     sm.pos.assign(pos, pos + n);
     int par_dcal = 0;
-    if (int rc = eval_structures_impl(1, &seq, &db, &par_dcal, nullptr)) return rc;
+    if (int rc = eval_structures_impl(1, &seq, &db, &par_dcal, nullptr, p->temp)) return rc;   // (also scales the tables for p->temp)
     sm.pdcal = par_dcal;
     const int K = std::max(1, std::min(p->nb_mode, 2 * n - 1));
     if (int rc = ensure(g.ws[0].dbg, (size_t)K * (4 * 7 + 8 * 2) + 64)) return rc;

@@ -9,6 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _native as N
+from . import params as _params_mod
 from .utils import Structure, energies_from_dcal
 
 
@@ -37,6 +38,7 @@ def fold_batch(sequences, nb_mode=100, max_stack=1, max_branch=100, min_hp=3, mi
     """Fold many sequences in one GPU batch.  Returns one entry per input sequence:
     `structures` or `(structures, trajectory)` exactly as fold() does."""
     L = N.lib()
+    _params_mod.ensure_default_params()
     p = _params(nb_mode, max_stack, max_branch, min_hp, min_nrj, traj, temp, gc_wei, au_wei, gu_wei)
     n = len(sequences)
     enc = [s.encode("ascii", "replace") for s in sequences]
@@ -72,21 +74,23 @@ def fold(sequence, nb_mode=100, max_stack=1, max_branch=100, min_hp=3, min_nrj=0
     return fold_batch([sequence], nb_mode, max_stack, max_branch, min_hp, min_nrj, traj, temp, gc_wei, au_wei, gu_wei)[0]
 
 
-def eval_structures(seqs, dbs):
+def eval_structures(seqs, dbs, temp=37.0):
     """GPU evaluation of eval_one_struct (rafft/utils.py:135-138) for many structures; dcal ints."""
     L = N.lib()
+    _params_mod.ensure_default_params()
     n = len(seqs)
     a = (C.c_char_p * n)(*[s.encode() for s in seqs])
     b = (C.c_char_p * n)(*[s.encode() for s in dbs])
     out = (C.c_int * n)()
     st = (C.c_int * n)()
-    N.check(L.rafft_eval_structures(n, a, b, out, st))
+    N.check(L.rafft_eval_structures_at(float(temp), n, a, b, out, st))
     return list(out), list(st)
 
 
 def expand_node(seq, db, pos, nb_mode=100, min_hp=3, min_nrj=0.0, gc=3.0, au=2.0, gu=1.0):
     """Kernel-level seam (tests): same dict as oracle.expand_node."""
     L = N.lib()
+    _params_mod.ensure_default_params()
     n = len(pos)
     K = max(1, min(nb_mode, 2 * n - 1))
     p = _params(nb_mode, 1, 100, min_hp, min_nrj, False, 37.0, gc, au, gu)

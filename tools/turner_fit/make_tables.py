@@ -53,8 +53,10 @@ def int21_rule(t1, t2, a, b, c):
     return base
 
 
-def main():
-    ks = kats.load_fixture()
+def fit_tables(ks):
+    """the two-pass fit on the triples `ks` -> (theta, exercise count per key); leaves the priors of the unseen
+    int21/int22 entries installed in `prior` (P.int21_prior / P.int22_prior), so model.energy(.., theta) evaluates
+    any structure with exactly the tables main() would write"""
     P.int21_prior = int21_rule
     th1, cnt1 = fit.fitted_theta(ks)
     pred22 = additive_int22(th1, cnt1)
@@ -68,6 +70,12 @@ def main():
         return int21_rule(t1, t2, a, b, c)
     P.int21_prior = int21_p2
     th, cnt = fit.fitted_theta(ks)
+    return th, cnt
+
+
+def main():
+    ks = kats.load_fixture()
+    th, cnt = fit_tables(ks)
     # verify
     bad = sum(1 for s, st, d in ks if model.energy(s, st, th) != d)
     print("KAT mismatches after fit:", bad, "of", len(ks), file=sys.stderr)
