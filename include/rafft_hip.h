@@ -66,7 +66,7 @@ typedef struct {
 
 typedef struct {
     int32_t n_seq;
-    int32_t _pad;
+    int32_t n_failed;         /* sequences whose status != RAFFT_OK */
     rafft_seq_result *seq;    /* [n_seq] in input order */
     void *_owner;             /* private */
 } rafft_result;
@@ -115,6 +115,18 @@ int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs,
                      const int *lens, int device, rafft_result **out);
 
 void rafft_free_result(rafft_result *r);
+
+/* The same, asynchronously - continuous batching.  rafft_fold_submit() copies the sequences, queues the batch and
+ * returns at once; rafft_fold_wait() blocks until that batch is done and hands over its result (then the job
+ * handle is gone).  One library thread drives all batches in flight: the last folding steps of a batch - which only
+ * its longest sequences still need and which leave the GPU nearly idle - run beside the busy first steps of the
+ * next one.  rafft_fold_batch() is submit + wait.  The analogue in the reference is the process pool of
+ * benchmark_results/bench_fft.py:17-21, which also keeps several folds in flight.  Batches complete in any order;
+ * every job must be waited for exactly once. */
+typedef struct rafft_job rafft_job;
+int rafft_fold_submit(const rafft_params *p, int n_seq, const char *const *seqs, const int *lens, int device,
+                      rafft_job **job);
+int rafft_fold_wait(rafft_job *job, rafft_result **out);
 
 /* Thread-local message of the last failing call. */
 const char *rafft_last_error(void);

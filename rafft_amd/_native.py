@@ -22,7 +22,7 @@ class SeqResult(C.Structure):
 
 
 class Result(C.Structure):
-    _fields_ = [("n_seq", C.c_int32), ("_pad", C.c_int32), ("seq", C.POINTER(SeqResult)), ("_owner", C.c_void_p)]
+    _fields_ = [("n_seq", C.c_int32), ("n_failed", C.c_int32), ("seq", C.POINTER(SeqResult)), ("_owner", C.c_void_p)]
 
 
 class Stats(C.Structure):
@@ -39,7 +39,7 @@ class Stats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
-EXPORTS = ["rafft_init", "rafft_fold_batch", "rafft_free_result", "rafft_last_error", "rafft_eval_structure",
+EXPORTS = ["rafft_init", "rafft_fold_batch", "rafft_fold_submit", "rafft_fold_wait", "rafft_free_result", "rafft_last_error", "rafft_eval_structure",
            "rafft_eval_structures", "rafft_eval_structures_at", "rafft_expand_node", "rafft_get_stats", "rafft_version",
            "rafft_load_params", "rafft_load_params_text", "rafft_reset_params", "rafft_save_params", "rafft_params_info",
            "rafft_param_value"]
@@ -65,6 +65,9 @@ def lib():
     L.rafft_init.argtypes = [C.c_int]
     L.rafft_fold_batch.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int,
                                    C.POINTER(C.POINTER(Result))]
+    L.rafft_fold_submit.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int,
+                                    C.POINTER(C.c_void_p)]
+    L.rafft_fold_wait.argtypes = [C.c_void_p, C.POINTER(C.POINTER(Result))]
     L.rafft_free_result.argtypes = [C.POINTER(Result)]
     L.rafft_free_result.restype = None
     L.rafft_last_error.restype = C.c_char_p

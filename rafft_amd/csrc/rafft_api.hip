@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <deque>
 #include <memory>
@@ -48,9 +49,9 @@ struct Buf {
 };
 struct PinBuf { void *p = nullptr; size_t cap = 0; };
 
-#define MAX_PIPES 2
-// One workspace = one folding pipeline: own stream set, grow-only device buffers, event pool and a pinned
-// slot for the per-step read-back.
+#define MAX_PIPES 4
+// One workspace = one folding pipeline: own stream set, grow-only device buffers and a pinned slot for the
+// per-step read-back.  Even workspaces serve the long-tail lane of a batch, odd ones the bulk lane.
 struct Workspace {
     bool ready = false;
     hipStream_t stream = nullptr;
@@ -63,8 +64,16 @@ struct Workspace {
         seen_cap, seen_cnt, st, prod, nd, nd_canon, pos, br, db, cand, looptab, trec, tsid,
         work0, work1, work2, work3, mat, counters,
         row_sid, row_off, out_db, out_dcal, row_off2, out_db2, out_dcal2, dbg;
-    std::vector<hipEvent_t> ev_pool;
-    size_t ev_used = 0;
+    size_t bytes() const
+    {
+        size_t t = 0;
+        for (const Buf *b : {&codes, &seq_off, &seq_len, &beam, &beam_n, &done, &nsteps, &ch_parent, &ch_combo, &ch_dcal, &ch_h, &seen,
+                             &seen_off, &seen_cap, &seen_cnt, &st, &prod, &nd, &nd_canon, &pos, &br, &db, &cand, &looptab, &trec, &tsid,
+                             &work0, &work1, &work2, &work3, &mat, &counters, &row_sid, &row_off, &out_db, &out_dcal, &row_off2, &out_db2,
+                             &out_dcal2, &dbg})
+            t += b->cap;
+        return t;
+    }
 };
 
 struct Ctx {
@@ -79,10 +88,20 @@ struct Ctx {
     size_t hbm_total = 0;
     Workspace ws[MAX_PIPES];
     std::vector<PinBuf> pin_free;
-    rafft_stats stats{};
-    std::mutex mu;
+    std::mutex pin_mu;                 // the pinned-chunk pool is used by the scheduler thread and by rafft_free_result
+    std::vector<hipEvent_t> ev_free;   // timing events (scheduler thread only)
+    rafft_stats stats{};               // of the batch that was waited for last
+    std::mutex mu;                     // serialises the C-ABI entry points
+    // ---- scheduler: one thread drives every wave of every batch in flight (see `scheduler_main`)
+    std::mutex qmu;
+    std::condition_variable qcv_sched, qcv_done;
+    std::deque<std::shared_ptr<struct Batch>> submitted;
+    int n_inflight = 0;                // batches submitted and not yet finished
+    bool sched_started = false;
 };
-Ctx g;
+// Never destroyed: the scheduler thread sleeps on its condition variable for as long as the process lives, and a
+// condition variable must not be destroyed under a waiter (glibc's pthread_cond_destroy would block process exit).
+Ctx &g = *new Ctx();
 
 int ensure(Buf &b, size_t bytes)
 {
@@ -120,13 +139,15 @@ int ensure_tables(double temp)
 int init_ws(Workspace &w)
 {
     if (w.ready) return 0;
-    // The second pipeline (the bulk of a batch cut by length, see rafft_fold_batch) gets the high stream priority:
-    // streams of another priority have HW queues of their own, so its kernels do not queue behind those of the
-    // first pipeline.  (Measured: bulk high or low 13.4 ms, no priorities 17.3 ms, the long tail high 15.4 ms.)
+    // Stream priorities: streams of another priority have HW queues of their own, so the kernels of one wave do not
+    // queue behind those of another.  Workspaces 1 and 3 serve the bulk lane (of consecutive batches): high and low;
+    // 0 and 2 the long-tail lane: normal.  (Measured with two waves: bulk high or low 13.4 ms, no priorities 17.3 ms,
+    // the long tail high 15.4 ms.)  RAFFT_PRIO=0 switches priorities off.
     int plo = 0, phi = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&plo, &phi));
     const int prio_mode = getenv("RAFFT_PRIO") ? atoi(getenv("RAFFT_PRIO")) : 1;
-    const int prio = (&w == &g.ws[1]) ? (prio_mode > 0 ? phi : prio_mode < 0 ? plo : 0) : 0;
+    const int idx = (int)(&w - g.ws);
+    const int prio = prio_mode == 0 ? 0 : idx == 1 ? (prio_mode > 0 ? phi : plo) : idx == 3 ? (prio_mode > 0 ? plo : phi) : 0;
     HIPCHK(hipStreamCreateWithPriority(&w.stream, hipStreamNonBlocking, prio));
     for (int c = 0; c < NCLS; c++) {
         HIPCHK(hipStreamCreateWithPriority(&w.cls_stream[c], hipStreamNonBlocking, prio));
@@ -172,25 +193,34 @@ int init_ctx(int device)
     return init_ws(g.ws[0]);
 }
 
-struct ClsCfg { int nt, Pmax, Lmax, nmax, brmax, Kmax, lds, grid; bool tab; };
+struct ClsCfg { int nt, Pmax, Lmax, nmax, brmax, Kmax, lds, grid; bool tab; int wpb; };   // grid: teams (wavefronts of the packed one-wavefront class, workgroups otherwise)
+
+// limits of the one-wavefront class: its LDS per wavefront (hence its occupancy) follows from them
+static int cls1_P() { static const int v = getenv("RAFFT_CLS1_P") ? std::max(128, std::min(next_pow2_ge(atoi(getenv("RAFFT_CLS1_P"))), CLS1_P)) : CLS1_P; return v; }
+static int cls1_br() { return std::min(CLS1_BR, (8 * cls1_P() - 16) / 10 - 1); }
 
 int class_cfg(int K, int maxL, ClsCfg out[NCLS])
 {
-    const int P[NCLS] = {CLS0_P, CLS1_P, CLS2_P, MAX_P}, LM[NCLS] = {CLS01_L, CLS01_L, RAFFT_MAX_LEN, RAFFT_MAX_LEN};
-    const int NT[NCLS] = {64, 64, getenv("RAFFT_NT2") ? atoi(getenv("RAFFT_NT2")) : 256, 512}, BR[NCLS] = {CLS0_BR, CLS1_BR, MAX_BR, MAX_BR};
+    const int P[NCLS] = {CLS0_P, cls1_P(), CLS2_P, MAX_P}, LM[NCLS] = {CLS01_L, CLS01_L, RAFFT_MAX_LEN, RAFFT_MAX_LEN};
+    const int NT[NCLS] = {64, 64, getenv("RAFFT_NT2") ? atoi(getenv("RAFFT_NT2")) : 256, 512}, BR[NCLS] = {CLS0_BR, cls1_br(), MAX_BR, MAX_BR};
     // LDS-resident energy tables cost occupancy and measured slower on MI355X; class 0 (tiny regions in
     // their own kernel) is kept compiled for experiments but receives no work (see node_class)
-    const bool TAB[NCLS] = {true, getenv("RAFFT_TAB1") ? atoi(getenv("RAFFT_TAB1")) != 0 : false, false, false};
+    const int tabm = getenv("RAFFT_TAB") ? atoi(getenv("RAFFT_TAB")) : 0;      // bit c: energy tables of class c in LDS
+    // the one-wavefront class packs WPB wavefronts into a workgroup that shares one LDS copy of the energy tables
+    const int wpb1 = getenv("RAFFT_WPB") ? atoi(getenv("RAFFT_WPB")) : 1;
+    const int WPB[NCLS] = {1, (wpb1 == 4 || wpb1 == 8) ? wpb1 : 1, 1, 1};
+    const bool TAB[NCLS] = {true, (tabm & 2) != 0 || WPB[1] > 1, (tabm & 4) != 0, (tabm & 8) != 0};
     for (int c = 0; c < NCLS; c++) {
         int nmax = P[c] / 2;
         int Kmax = std::max(1, std::min(K, P[c] - 1));
-        ExpandLds l = expand_lds(P[c], LM[c], nmax, BR[c], Kmax, TAB[c]);
+        ExpandLds l = expand_lds(P[c], LM[c], nmax, BR[c], Kmax, TAB[c], WPB[c]);
         // region A is time-shared: behind the fp64 lag values (8 P bytes) it must still hold the branch prefix sums
         // (10 bytes per branch), the select histogram and the window_slide scratch of this class
         if (c >= 1 && (10 * (BR[c] + 1) + 16 > 8 * P[c] || 2 * P[c] + 1152 + 16 > 8 * P[c] || (NT[c] > 64 && NT[c] * 24 > 8 * P[c])))
             return fail(RAFFT_ERR_PARAM, "internal: expand LDS plan does not fit its size class");
-        int per_cu = std::max(1, std::min(32 / (NT[c] / 64), (160 * 1024) / l.total));
-        out[c] = {NT[c], P[c], LM[c], nmax, BR[c], Kmax, l.total, g.n_cu * per_cu, TAB[c]};
+        int per_cu = std::max(1, std::min(32 / (NT[c] / 64), WPB[c] * ((160 * 1024) / l.total)));      // teams per CU
+        if (c == 1 && getenv("RAFFT_C1_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(getenv("RAFFT_C1_PER_CU"))));
+        out[c] = {NT[c], P[c], LM[c], nmax, BR[c], Kmax, l.total, g.n_cu * per_cu, TAB[c], WPB[c]};
         // a size class that no region of this batch can reach need not fit (class 3 needs n > 1024)
         const bool reachable = c < 3 || maxL > CLS2_P / 2;
         if (l.total > 160 * 1024 && reachable)
@@ -201,15 +231,16 @@ int class_cfg(int K, int maxL, ClsCfg out[NCLS])
     return 0;
 }
 
-template <int NT, bool TAB>
-int launch_expand(const Dev &d, int cls, const ClsCfg &cf, unsigned n_blocks, hipStream_t st)
+template <int NT, bool TAB, int WPB = 1>
+int launch_expand(const Dev &d, int cls, const ClsCfg &cf, unsigned n_teams, hipStream_t st)
 {
     static int lds_set = 0;
     if (cf.lds > lds_set) {
-        HIPCHK(hipFuncSetAttribute((const void *)expand_kernel<NT, TAB>, hipFuncAttributeMaxDynamicSharedMemorySize, cf.lds));
+        HIPCHK(hipFuncSetAttribute((const void *)expand_kernel<NT, TAB, WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, cf.lds));
         lds_set = cf.lds;
     }
-    hipLaunchKernelGGL((expand_kernel<NT, TAB>), dim3(n_blocks), dim3(NT), cf.lds, st, d, cls, cf.Pmax, cf.Lmax, cf.nmax, cf.brmax, cf.Kmax);
+    const unsigned n_blocks = (n_teams + WPB - 1) / WPB;
+    hipLaunchKernelGGL((expand_kernel<NT, TAB, WPB>), dim3(n_blocks), dim3(NT * WPB), cf.lds, st, d, cls, cf.Pmax, cf.Lmax, cf.nmax, cf.brmax, cf.Kmax);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -217,19 +248,27 @@ int launch_expand(const Dev &d, int cls, const ClsCfg &cf, unsigned n_blocks, hi
 int launch_expand_cls(const Dev &d, int cls, const ClsCfg cf[NCLS], unsigned n_blocks, hipStream_t st)
 {
     if (cls == 0) return launch_expand<64, true>(d, 0, cf[0], n_blocks, st);
-    if (cls == 1) return cf[1].tab ? launch_expand<64, true>(d, 1, cf[1], n_blocks, st) : launch_expand<64, false>(d, 1, cf[1], n_blocks, st);
-    if (cls == 2) return cf[2].nt == 512 ? launch_expand<512, false>(d, 2, cf[2], n_blocks, st) : launch_expand<256, false>(d, 2, cf[2], n_blocks, st);
-    return launch_expand<512, false>(d, 3, cf[3], n_blocks, st);
+    if (cls == 1) {
+        if (cf[1].wpb == 4) return launch_expand<64, true, 4>(d, 1, cf[1], n_blocks, st);
+        if (cf[1].wpb == 8) return launch_expand<64, true, 8>(d, 1, cf[1], n_blocks, st);
+        return cf[1].tab ? launch_expand<64, true>(d, 1, cf[1], n_blocks, st) : launch_expand<64, false>(d, 1, cf[1], n_blocks, st);
+    }
+    if (cls == 2) {
+        if (cf[2].nt == 512) return cf[2].tab ? launch_expand<512, true>(d, 2, cf[2], n_blocks, st) : launch_expand<512, false>(d, 2, cf[2], n_blocks, st);
+        return cf[2].tab ? launch_expand<256, true>(d, 2, cf[2], n_blocks, st) : launch_expand<256, false>(d, 2, cf[2], n_blocks, st);
+    }
+    return cf[3].tab ? launch_expand<512, true>(d, 3, cf[3], n_blocks, st) : launch_expand<512, false>(d, 3, cf[3], n_blocks, st);
 }
 
-hipEvent_t next_event(Workspace &w)
+// timing events: handed out from a free list and returned when their batch has been finalised, so the spans of a
+// wave stay valid while later waves (of the same or of another batch) use the same workspace
+hipEvent_t next_event(std::vector<hipEvent_t> &used)
 {
-    if (w.ev_used == w.ev_pool.size()) {
-        hipEvent_t e;
-        if (hipEventCreate(&e) != hipSuccess) return nullptr;
-        w.ev_pool.push_back(e);
-    }
-    return w.ev_pool[w.ev_used++];
+    hipEvent_t e = nullptr;
+    if (!g.ev_free.empty()) { e = g.ev_free.back(); g.ev_free.pop_back(); }
+    else if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    used.push_back(e);
+    return e;
 }
 
 struct Span { hipEvent_t a, b; int kind; };
@@ -310,6 +349,7 @@ struct HostOut {   // owner of a rafft_result
 // small pool of pinned host buffers, recycled across calls (hipHostMalloc is slow)
 PinBuf pin_acquire(size_t bytes)
 {
+    std::lock_guard<std::mutex> lk(g.pin_mu);
     int best = -1;
     for (size_t i = 0; i < g.pin_free.size(); i++)
         if (g.pin_free[i].cap >= bytes && (best < 0 || g.pin_free[i].cap < g.pin_free[best].cap)) best = (int)i;
@@ -323,9 +363,30 @@ PinBuf pin_acquire(size_t bytes)
 void pin_release(PinBuf b)
 {
     if (!b.p) return;
+    std::lock_guard<std::mutex> lk(g.pin_mu);
     if (g.pin_free.size() < 8) g.pin_free.push_back(b);
     else { hipError_t e = hipHostFree(b.p); (void)e; }
 }
+
+struct Job { std::vector<SeqIn> seqs; double est; int depth; };
+
+// One rafft_fold_submit(): its sequences (copied), its result under construction, its jobs (lane 0: the long tail of
+// the batch, lane 1: the bulk - see rafft_fold_submit) and what the scheduler needs to finish it.
+struct Batch {
+    rafft_params p;
+    int n_seq = 0;
+    std::vector<char> seqbuf;                 // the caller's sequences, copied at submit
+    HostOut *ho = nullptr;
+    std::deque<Job> lane[2];
+    int running = 0;                          // waves of this batch on a workspace right now
+    int rc = 0;
+    std::string err;
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> events;           // timing events in use by `spans`
+    rafft_stats stats{};
+    std::chrono::steady_clock::time_point t0;
+    bool done = false;                        // under g.qmu
+};
 
 struct SeamIn {     // rafft_expand_node: one region of one given structure
     DebugOut dbg;
@@ -342,6 +403,7 @@ struct Wave {
     rafft_params p;
     std::vector<SeqIn> seqs;
     double est;
+    Batch &bt;
     HostOut &out;
     std::vector<Span> &spans;
     const SeamIn *seam;
@@ -364,14 +426,16 @@ struct Wave {
     std::chrono::steady_clock::time_point tw0, tw1;
     double ms_setup = 0, ms_issue = 0, ms_after = 0;   // host time inside issue_step / after_beam (trace)
 
-    Wave(Workspace &w, const rafft_params &pp, std::vector<SeqIn> s, double e, HostOut &o, std::vector<Span> &sp, const SeamIn *sm = nullptr)
-        : g(w), p(pp), seqs(std::move(s)), est(e), out(o), spans(sp), seam(sm) {}
+    Wave(Workspace &w, Batch &b, std::vector<SeqIn> s, double e, const SeamIn *sm = nullptr)
+        : g(w), p(b.p), seqs(std::move(s)), est(e), bt(b), out(*b.ho), spans(b.spans), seam(sm) {}
 
     double since(std::chrono::steady_clock::time_point t) const
     {
         return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
     }
-    hipEvent_t next_event() { return ::next_event(g); }
+    hipEvent_t next_event() { return ::next_event(bt.events); }
+    // a wave whose steps still create many structures keeps the whole GPU busy; afterwards it is latency-bound
+    bool heavy(unsigned below) const { return below != 0x7fffffffu && S >= 256 && !finished && (steps < 3 || last_mat >= below); }
     int setup();
     int issue_step();
     bool ready() { return hipEventQuery(g.ev_hot) == hipSuccess; }
@@ -428,6 +492,7 @@ int Wave::setup()
     if (const char *e = getenv("RAFFT_NO_MEMO")) if (atoi(e)) d.memo = 0;
     if (const char *e = getenv("RAFFT_FORCE_FFT")) if (atoi(e)) d.force_fft = 1;   // tests: FFT path for short regions too
     d.rl_cap = RL_CAP;
+    d.cls1_P = cls1_P(); d.cls1_br = cls1_br();
     d.mat_tile = 64;
     if (const char *e = getenv("RAFFT_MAT_TILE")) d.mat_tile = std::max(1, std::min(atoi(e), 64));   // tests: several tiles per structure
     if (const char *e = getenv("RAFFT_RL_CAP")) d.rl_cap = std::max(0, std::min(atoi(e), RL_CAP));   // tests: region lists not resident in LDS
@@ -529,7 +594,7 @@ int Wave::issue_step()
             if (bound < grid) grid = (unsigned)bound;
         }
         if (int rc = launch_expand_cls(d, cls, cf, grid, cs)) return rc;
-        if (cls == 1) ::g.stats.n_expand_launches++;       // launches of the dominant kernel (ms_expand is their sum)
+        if (cls == 1) bt.stats.n_expand_launches++;       // launches of the dominant kernel (ms_expand is their sum)
         SPAN_REC(sp.b, cs, sp.kind);
         spans.push_back(sp);
         if (!inline_) {
@@ -675,7 +740,7 @@ int Wave::finish()
     finished = true;
     const double ms_loop = since(tw1);
     auto tw2 = std::chrono::steady_clock::now();
-    ::g.stats.n_steps = std::max<int64_t>(::g.stats.n_steps, steps);
+    bt.stats.n_steps = std::max<int64_t>(bt.stats.n_steps, steps);
     if (ovf && getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] wave S=%zu est %.1f overflowed (bits %u) after %d steps, %.1f ms\n", S, est, ovf, steps, since(tw0));
     if (ovf) {
         HIPCHK(hipStreamSynchronize(st));
@@ -689,24 +754,24 @@ int Wave::finish()
     {
         unsigned long long nn = S;
         for (int i = 0; i < NSHARD; i++) nn += hc.node[i].v;
-        ::g.stats.n_nodes_created += (int64_t)nn;
+        bt.stats.n_nodes_created += (int64_t)nn;
     }
-    ::g.stats.n_node_expansions += hc.n_expand;
-    ::g.stats.n_nodes_aliased += (int64_t)hc.n_alias;
-    ::g.stats.sum_node_len += hc.sum_n;
-    ::g.stats.sum_lags += hc.sum_lags;
-    ::g.stats.n_structs += (int64_t)hc.n_struct;
-    ::g.stats.n_children += hc.n_children;
-    ::g.stats.sum_struct_len += (int64_t)(hc.sum_struct_len + sumL);
+    bt.stats.n_node_expansions += hc.n_expand;
+    bt.stats.n_nodes_aliased += (int64_t)hc.n_alias;
+    bt.stats.sum_node_len += hc.sum_n;
+    bt.stats.sum_lags += hc.sum_lags;
+    bt.stats.n_structs += (int64_t)hc.n_struct;
+    bt.stats.n_children += hc.n_children;
+    bt.stats.sum_struct_len += (int64_t)(hc.sum_struct_len + sumL);
     {
         int64_t ex = 3 * (int64_t)hc.sum_n + 16 * (int64_t)hc.sum_lags + 3 * (int64_t)(hc.sum_struct_len + sumL);
         // the dominant kernel (size class 1, P <= 512): its own regions, and the per-structure term in
         // proportion to the regions it expanded
         double share = hc.n_expand ? (double)hc.cls_items[1] / (double)hc.n_expand : 0.0;
-        ::g.stats.alg_bytes_expand += 3 * (int64_t)hc.cls_sum_n[1] + 16 * (int64_t)hc.cls_sum_lags[1] +
+        bt.stats.alg_bytes_expand += 3 * (int64_t)hc.cls_sum_n[1] + 16 * (int64_t)hc.cls_sum_lags[1] +
                                     (int64_t)(share * 3.0 * (double)(hc.sum_struct_len + sumL));
-        ::g.stats.alg_bytes_expand_all += ex;
-        ::g.stats.alg_bytes += ex + 2 * (int64_t)hc.sum_struct_len + 8 * (int64_t)(hc.n_struct - S);
+        bt.stats.alg_bytes_expand_all += ex;
+        bt.stats.alg_bytes += ex + 2 * (int64_t)hc.sum_struct_len + 8 * (int64_t)(hc.n_struct - S);
     }
 
 
@@ -777,9 +842,9 @@ int Wave::finish()
 }
 
 // rafft_expand_node: one region of one given structure through the expand kernel
-int run_seam(const rafft_params &p, const std::vector<SeqIn> &one, HostOut &ho, std::vector<Span> &spans, const SeamIn &sm)
+int run_seam(Batch &bt, const std::vector<SeqIn> &one, const SeamIn &sm)
 {
-    Wave w(g.ws[0], p, one, 4.0, ho, spans, &sm);
+    Wave w(g.ws[0], bt, one, 4.0, &sm);
     if (int rc = w.setup()) return rc;
     Workspace &W = g.ws[0];
     // overwrite the root region of sequence 0 with the given loop of the given structure
@@ -792,7 +857,7 @@ int run_seam(const rafft_params &p, const std::vector<SeqIn> &one, HostOut &ho, 
         root.n = n; root.nbr = nbr; root.ci = sm.ci; root.cj = sm.cj; root.pdcal = sm.pdcal;
         HIPCHK(hipMemcpy(W.nd.p, &root, sizeof root, hipMemcpyHostToDevice));
     }
-    int cls = node_class(n, one[0].len, nbr);
+    int cls = node_class(n, one[0].len, nbr, 0, w.d.cls1_P, w.d.cls1_br);
     int zero = 0;
     memset(&w.hc.n_work, 0, sizeof w.hc.n_work);
     w.hc.n_work[cls] = 1;
@@ -803,72 +868,206 @@ int run_seam(const rafft_params &p, const std::vector<SeqIn> &one, HostOut &ho, 
     return 0;
 }
 
-struct Job { std::vector<SeqIn> seqs; double est; int depth; };
+void free_out(HostOut *o);
 
-// Drive up to MAX_PIPES waves at once from this one host thread.  Each pipeline has its own workspace and
-// job queue; a job that does not fit the pipeline's share of HBM is split, one that overflows its arenas is
-// re-queued with larger ones.
-int run_pipelines(const rafft_params &p, std::vector<std::deque<Job>> &queues, HostOut &out, std::vector<Span> &spans)
+// ---------------------------------------------------------------------------------------------------- scheduler
+// ONE thread drives every wave of every batch in flight.  A wave is a small state machine (issue_step / after_beam
+// above): while the thread waits for one wave's 152-byte read-back the kernels of the others keep the GPU busy.
+// Batches queue up (rafft_fold_submit); a batch is cut in a long-tail job and a bulk job (lanes 0 and 1).  What runs
+// when - continuous batching:
+//   * every queued job is admitted as soon as a workspace is free: the bulk of the next batch starts while the running
+//     one is still folding, so the tail of a batch - and its long-tail wave - run beside the next batch's busy steps
+//     (measured on the benchmark batch, three batches in flight: 11.9 ms per batch against 13.1 for synchronous
+//     calls; holding the next bulk wave back until the running one has turned light - RAFFT_ADMIT_BELOW=<structures
+//     per step> - was 2-4 % slower);
+//   * a job that does not fit the HBM still free is split (or waits for running waves to release theirs).
+struct Slot { std::unique_ptr<Wave> wave; std::shared_ptr<Batch> owner; Job job; int lane = 0; };
+
+static unsigned admit_below()
 {
-    const int np = (int)queues.size();
-    std::vector<std::unique_ptr<Wave>> cur(np);
-    std::vector<Job> curjob(np);
-    const size_t budget = (size_t)((double)g.hbm_total * 0.55 / (double)std::max(np, 1));
-    for (;;) {
-        bool any = false, progressed = false;
-        for (int i = 0; i < np; i++) {
-            if (!cur[i]) {
-                if (queues[i].empty()) continue;
-                Job job = std::move(queues[i].front());
-                queues[i].pop_front();
-                progressed = true;
-                if (job.seqs.empty()) continue;
-                size_t sl = 0;
-                for (auto &s : job.seqs) sl += s.len;
-                Caps cc = plan_caps(job.seqs.size(), sl, p, job.est);
-                if (cc.bytes > budget && job.seqs.size() > 1) {
-                    size_t h = job.seqs.size() / 2;
-                    Job a{std::vector<SeqIn>(job.seqs.begin(), job.seqs.begin() + h), job.est, job.depth};
-                    Job b{std::vector<SeqIn>(job.seqs.begin() + h, job.seqs.end()), job.est, job.depth};
-                    queues[i].push_front(std::move(b));
-                    queues[i].push_front(std::move(a));
-                    any = true;
-                    continue;
+    static const unsigned v = getenv("RAFFT_ADMIT_BELOW") ? (unsigned)atoi(getenv("RAFFT_ADMIT_BELOW")) : 0u;
+    return v ? v : 0x7fffffffu;                 // default: no wave is ever held back
+}
+
+static void finalize_batch(const std::shared_ptr<Batch> &bp)
+{
+    Batch &b = *bp;
+    if (b.rc) {
+        // early-harvest copies or kernels of a sibling wave may still be in flight: the pinned result chunks return
+        // to the pool only once the device is idle
+        { hipError_t e_ = hipDeviceSynchronize(); (void)e_; }
+        free_out(b.ho);
+        b.ho = nullptr;
+    } else {
+        if (getenv("RAFFT_TRACE")) {       // per-step timeline: spans are recorded in step order
+            float acc[16] = {0};
+            int stepno = 0;
+            for (auto &sp : b.spans) {
+                float ms = 0;
+                if (!span_on(sp.kind) || hipEventElapsedTime(&ms, sp.a, sp.b) != hipSuccess) continue;
+                if (sp.kind < 16) acc[sp.kind] += ms;
+                if (sp.kind == 1) {        // the beam step closes a folding step (materialize of it follows)
+                    fprintf(stderr, "[rafft] t-step %2d: expand wall %.3f (c1 %.3f c2 %.3f c3 %.3f) beam %.3f  prev-materialize %.3f\n",
+                            ++stepno, acc[4], acc[11], acc[12], acc[13], acc[1], acc[2]);
+                    for (float &x : acc) x = 0;
                 }
-                if (int rc = init_ws(g.ws[i])) return rc;
-                cur[i].reset(new Wave(g.ws[i], p, job.seqs, job.est, out, spans));
-                cur[i]->depth = job.depth;
-                curjob[i] = std::move(job);
-                if (int rc = cur[i]->setup()) return rc;
-                if (int rc = cur[i]->issue_step()) return rc;
-            }
-            any = true;
-            if (cur[i]->ready()) {
-                progressed = true;
-                int rc = cur[i]->after_beam();
-                if (cur[i]->finished) {
-                    rc = cur[i]->result;
-                    if (rc == RAFFT_ERR_CAPACITY) {
-                        if (curjob[i].depth >= 12)
-                            return fail(RAFFT_ERR_CAPACITY, "HBM arena overflow after 12 regrowths (bits " + std::to_string(cur[i]->ovf) + ")");
-                        ::g.stats.n_regrows++;
-                        Job again{std::move(curjob[i].seqs), curjob[i].est * (curjob[i].depth >= 2 ? 4.0 : 2.0), curjob[i].depth + 1};
-                        queues[i].push_front(std::move(again));
-                    } else if (rc)
-                        return rc;
-                    cur[i].reset();
-                } else if (rc)
-                    return rc;
             }
         }
-        if (!any) {
-            bool left = false;
-            for (auto &q : queues) left = left || !q.empty();
-            if (!left) break;
+        for (auto &sp : b.spans) {
+            float ms = 0;
+            if (span_on(sp.kind) && hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+                if (sp.kind == 10) b.stats.ms_expand_c1 += ms;   /* class 0: unused */
+                else if (sp.kind == 11) b.stats.ms_expand += ms;   /* dominant kernel: regions with P <= 512 */
+                else if (sp.kind == 12) b.stats.ms_expand_c2 += ms;
+                else if (sp.kind == 13) b.stats.ms_expand_c3 += ms;
+                else if (sp.kind == 4) b.stats.ms_expand_wall += ms;
+                else if (sp.kind == 1) b.stats.ms_beam += ms;
+                else if (sp.kind == 2) b.stats.ms_materialize += ms;
+                else b.stats.ms_output += ms;
+            }
+        }
+        HostOut *ho = b.ho;
+        for (int i = 0; i < b.n_seq; i++) {
+            rafft_seq_result &sr = ho->seq[i];
+            sr.step_size = ho->step_size[i].data(); sr.step_off = ho->step_off[i].data();
+            sr.db = ho->db_ptr[i]; sr.dcal = ho->dcal_ptr[i];
+        }
+        ho->res.n_seq = b.n_seq; ho->res.seq = ho->seq.data(); ho->res._owner = ho;
+        ho->res.n_failed = 0;
+        for (int i = 0; i < b.n_seq; i++) ho->res.n_failed += ho->seq[i].status != RAFFT_OK;
+        b.stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - b.t0).count();
+    }
+    for (hipEvent_t e : b.events) g.ev_free.push_back(e);
+    b.events.clear(); b.spans.clear();
+    {
+        std::lock_guard<std::mutex> lk(g.qmu);
+        b.done = true;
+        g.n_inflight--;
+    }
+    g.qcv_done.notify_all();
+}
+
+static void scheduler_main()
+{
+    { hipError_t e_ = hipSetDevice(g.device); (void)e_; }
+    Slot slot[MAX_PIPES];
+    std::deque<std::shared_ptr<Batch>> active;
+    const int max_waves = std::max(1, std::min(getenv("RAFFT_MAX_WAVES") ? atoi(getenv("RAFFT_MAX_WAVES")) : MAX_PIPES, MAX_PIPES));
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(g.qmu);
+            if (active.empty() && g.submitted.empty()) g.qcv_sched.wait(lk, [] { return !g.submitted.empty(); });
+            while (!g.submitted.empty()) { active.push_back(g.submitted.front()); g.submitted.pop_front(); }
+        }
+        bool progressed = false;
+        // ---- advance the running waves
+        for (int i = 0; i < MAX_PIPES; i++) {
+            Slot &sl = slot[i];
+            if (!sl.wave || !sl.wave->ready()) continue;
+            progressed = true;
+            Batch &b = *sl.owner;
+            int rc = sl.wave->after_beam();
+            if (sl.wave->finished) {
+                rc = sl.wave->result;
+                if (rc == RAFFT_ERR_CAPACITY && !b.rc) {
+                    if (sl.job.depth >= 12) { b.rc = RAFFT_ERR_CAPACITY; b.err = "HBM arena overflow after 12 regrowths (bits " + std::to_string(sl.wave->ovf) + ")"; }
+                    else {
+                        b.stats.n_regrows++;
+                        b.lane[sl.lane].push_front(Job{std::move(sl.job.seqs), sl.job.est * (sl.job.depth >= 2 ? 4.0 : 2.0), sl.job.depth + 1});
+                    }
+                } else if (rc && !b.rc) { b.rc = rc; b.err = g_err; }
+                sl.wave.reset(); sl.owner.reset();
+                b.running--;
+            } else if (rc) {
+                if (!b.rc) { b.rc = rc; b.err = g_err; }
+                { hipError_t e_ = hipDeviceSynchronize(); (void)e_; }
+                sl.wave.reset(); sl.owner.reset();
+                b.running--;
+            }
+        }
+        // ---- admit queued jobs, batches in submission order, the long-tail lane of a batch before its bulk
+        int n_running = 0;
+        bool heavy_running = false;
+        for (int i = 0; i < MAX_PIPES; i++) if (slot[i].wave) { n_running++; heavy_running = heavy_running || slot[i].wave->heavy(admit_below()); }
+        for (auto &bp : active) {
+            Batch &b = *bp;
+            if (b.rc) { b.lane[0].clear(); b.lane[1].clear(); continue; }
+            for (int ln = 0; ln < 2; ln++) {
+                while (!b.lane[ln].empty() && n_running < max_waves) {
+                    Job &job = b.lane[ln].front();
+                    if (job.seqs.empty()) { b.lane[ln].pop_front(); continue; }
+                    const bool job_heavy = job.seqs.size() >= 256;
+                    if (job_heavy && heavy_running) break;
+                    int w = -1;                                       // a free workspace, this lane's parity first
+                    for (int k = 0; k < MAX_PIPES && w < 0; k++) if (!slot[k].wave && (k & 1) == ln) w = k;
+                    for (int k = 0; k < MAX_PIPES && w < 0; k++) if (!slot[k].wave) w = k;
+                    if (w < 0) break;
+                    size_t sl_ = 0;
+                    for (auto &sq : job.seqs) sl_ += sq.len;
+                    const Caps cc = plan_caps(job.seqs.size(), sl_, b.p, job.est);
+                    size_t others = 0;
+                    for (int k = 0; k < MAX_PIPES; k++) if (k != w) others += g.ws[k].bytes();
+                    const size_t budget = (size_t)((double)g.hbm_total * 0.55 / 2.0);
+                    const bool fits_now = std::max(cc.bytes, g.ws[w].bytes()) + others <= (size_t)((double)g.hbm_total * 0.85);
+                    if ((cc.bytes > budget || (!fits_now && n_running == 0)) && job.seqs.size() > 1) {
+                        const size_t h = job.seqs.size() / 2;          // too big for one wave: two jobs, one after the other
+                        Job a{std::vector<SeqIn>(job.seqs.begin(), job.seqs.begin() + h), job.est, job.depth};
+                        Job c{std::vector<SeqIn>(job.seqs.begin() + h, job.seqs.end()), job.est, job.depth};
+                        b.lane[ln].pop_front();
+                        b.lane[ln].push_front(std::move(c));
+                        b.lane[ln].push_front(std::move(a));
+                        progressed = true;
+                        continue;
+                    }
+                    if (!fits_now && n_running > 0) break;            // wait for running waves to finish (their workspaces stay, but...)
+                    Slot &sl = slot[w];
+                    sl.job = std::move(job);
+                    b.lane[ln].pop_front();
+                    sl.lane = ln; sl.owner = bp;
+                    int rc = init_ws(g.ws[w]);
+                    if (!rc) {
+                        sl.wave.reset(new Wave(g.ws[w], b, sl.job.seqs, sl.job.est));
+                        sl.wave->depth = sl.job.depth;
+                        rc = sl.wave->setup();
+                        if (!rc) rc = sl.wave->issue_step();
+                    }
+                    progressed = true;
+                    if (rc) {
+                        if (!b.rc) { b.rc = rc; b.err = g_err; }
+                        { hipError_t e_ = hipDeviceSynchronize(); (void)e_; }
+                        sl.wave.reset(); sl.owner.reset();
+                        break;
+                    }
+                    b.running++; n_running++;
+                    heavy_running = heavy_running || job_heavy;
+                }
+            }
+        }
+        // ---- batches with nothing queued and nothing running are complete
+        for (auto it = active.begin(); it != active.end();) {
+            Batch &b = **it;
+            if (b.running == 0 && ((b.lane[0].empty() && b.lane[1].empty()) || b.rc)) {
+                finalize_batch(*it);
+                it = active.erase(it);
+                progressed = true;
+            } else ++it;
         }
         if (!progressed) std::this_thread::yield();
     }
-    return 0;
+}
+
+static void start_scheduler()
+{
+    if (g.sched_started) return;
+    g.sched_started = true;
+    std::thread(scheduler_main).detach();     // lives as long as the process
+}
+
+// no batch may be in flight when the device tables change or a seam call borrows workspace 0
+static void drain()
+{
+    std::unique_lock<std::mutex> lk(g.qmu);
+    g.qcv_done.wait(lk, [] { return g.n_inflight == 0; });
 }
 
 void free_out(HostOut *o)
@@ -891,11 +1090,13 @@ int rafft_init(int device)
     return init_ctx(device);
 }
 
-int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs, const int *lens, int device, rafft_result **out_)
+struct rafft_job { std::shared_ptr<Batch> b; };
+
+// (holds g.mu)
+static int submit_locked(const rafft_params *p, int n_seq, const char *const *seqs, const int *lens, int device, rafft_job **job_)
 {
-    std::lock_guard<std::mutex> lk(g.mu);
-    if (!p || !out_ || n_seq < 0) return fail(RAFFT_ERR_PARAM, "null argument");
-    *out_ = nullptr;
+    if (!p || !job_ || n_seq < 0 || (n_seq > 0 && !seqs)) return fail(RAFFT_ERR_PARAM, "null argument");
+    *job_ = nullptr;
     if (!(p->temp > -273.15 && p->temp < 1000.0)) return fail(RAFFT_ERR_TEMP, "temp out of range");
     if (p->temp != 37.0 && !param_set().has_dH)
         return fail(RAFFT_ERR_TEMP, "temp != 37 needs the enthalpy tables of a ViennaRNA parameter file (rafft_load_params); "
@@ -903,40 +1104,46 @@ int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs, 
     if (p->max_stack < 1 || p->max_stack > 65535) return fail(RAFFT_ERR_PARAM, "max_stack must be in [1, 65535]");
     if (p->nb_mode < 0 || p->max_branch < 0) return fail(RAFFT_ERR_PARAM, "nb_mode/max_branch must be >= 0");
     if (int rc = init_ctx(device)) return rc;
-    if (int rc = ensure_tables(p->temp)) return rc;
-    auto t0 = std::chrono::steady_clock::now();
-    memset(&g.stats, 0, sizeof g.stats);
+    if (g.T_dirty || g.T_temp != p->temp) {       // other tables: the batches in flight finish with theirs first
+        drain();
+        if (int rc = ensure_tables(p->temp)) return rc;
+    }
     g_span_level = getenv("RAFFT_TRACE") ? 2 : getenv("RAFFT_SPANS") ? atoi(getenv("RAFFT_SPANS")) : 1;
-    // timing events are handed out monotonically for the whole call: the spans of a wave stay valid when a later
-    // wave (HBM-budget split, regrowth re-run) uses the same workspace
-    for (int i = 0; i < MAX_PIPES; i++) g.ws[i].ev_used = 0;
-    HostOut *ho = new HostOut();
+    std::shared_ptr<Batch> bp(new Batch());
+    Batch &b = *bp;
+    b.p = *p; b.n_seq = n_seq; b.t0 = std::chrono::steady_clock::now();
+    HostOut *ho = b.ho = new HostOut();
     ho->seq.resize(n_seq); ho->step_size.resize(n_seq); ho->step_off.resize(n_seq);
     ho->dcal_ptr.assign(n_seq, nullptr); ho->db_ptr.assign(n_seq, nullptr);
+    // the sequences are copied: the caller's buffers may go away before rafft_fold_wait
+    std::vector<int> L(n_seq);
+    size_t tot = 0;
+    for (int i = 0; i < n_seq; i++) { L[i] = lens ? lens[i] : (int)strlen(seqs[i]); tot += (size_t)std::max(L[i], 0); }
+    b.seqbuf.resize(tot + 1);
     std::vector<SeqIn> good;
+    size_t o = 0;
     for (int i = 0; i < n_seq; i++) {
-        int L = lens ? lens[i] : (int)strlen(seqs[i]);
         rafft_seq_result &sr = ho->seq[i];
         memset(&sr, 0, sizeof sr);
-        sr.length = L;
-        if (L == 0) { sr.status = RAFFT_ERR_EMPTY; continue; }
+        sr.length = L[i];
+        if (L[i] <= 0) { sr.status = RAFFT_ERR_EMPTY; continue; }
+        char *dst = b.seqbuf.data() + o;
+        memcpy(dst, seqs[i], (size_t)L[i]);
+        o += (size_t)L[i];
         unsigned bad = 0;
-        const unsigned char *sp_ = (const unsigned char *)seqs[i];
-        for (int x = 0; x < L; x++) bad |= kBaseCode[sp_[x]];
+        for (int x = 0; x < L[i]; x++) bad |= kBaseCode[(unsigned char)dst[x]];
         if (bad & 8) { sr.status = RAFFT_ERR_BAD_CHAR; continue; }
-        if (L > RAFFT_MAX_LEN) { sr.status = RAFFT_ERR_TOO_LONG; continue; }
-        good.push_back({seqs[i], L, i});
+        if (L[i] > RAFFT_MAX_LEN) { sr.status = RAFFT_ERR_TOO_LONG; continue; }
+        good.push_back({dst, L[i], i});
     }
-    std::vector<Span> spans;
-    // ---- pipelines.  Folds are independent, so how the batch is cut cannot change any result.  The number of
+    // ---- lanes.  Folds are independent, so how the batch is cut cannot change any result.  The number of
     // folding steps of a wave is set by its longest sequence, and the steps that only the long ones still need
     // are latency-bound and nearly empty (the benchmark set: 24 steps for two 2.9-knt sequences, 12 for the rest).
-    // So a batch whose few longest sequences stand far out is cut in two waves driven from this one thread: the long
-    // tail starts first and runs beside the bulk.  The bulk's streams have a stream priority of their own, which
-    // gives them HW queues of their own - with all streams at one priority the two waves share the process's four
-    // queues and the cut is a loss (17.3 ms against 15.2 for the benchmark batch; with it: 13.3 ms).
-    // RAFFT_SPLIT: unset / -1 automatic, 0 never, > 0 cut at that length.  (Measured: benchmark batch 15.3 -> 13.6 ms;
-    // 64-400 short sequences with two long ones: 8-15 % faster.)
+    // So a batch whose few longest sequences stand far out is cut in two jobs: the long tail starts first and runs
+    // beside the bulk (and beside the bulk of the next batch).  The workspaces of the bulk lane have a stream
+    // priority of their own, which gives them HW queues of their own - with all streams at one priority the waves
+    // share the process's four queues and the cut is a loss (17.3 ms against 15.2 for the benchmark batch; with it: 13.3 ms).
+    // RAFFT_SPLIT: unset / -1 automatic, 0 never, > 0 cut at that length.
     int split_len = 0;
     {
         const char *sp = getenv("RAFFT_SPLIT");
@@ -953,7 +1160,6 @@ int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs, 
             }
         }
     }
-    std::vector<std::deque<Job>> queues;
     {
         auto est_of = [&](const std::vector<SeqIn> &v) {
             // expected survivors per beam slot (~ folding steps in which a slot is renewed): grows with length
@@ -966,71 +1172,72 @@ int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs, 
         std::vector<SeqIn> shorts, longs;
         for (auto &sq : good) (split_len > 0 && sq.len >= split_len ? longs : shorts).push_back(sq);
         if (!longs.empty() && !shorts.empty()) {
-            queues.resize(2);
-            queues[0].push_back(Job{longs, est_of(longs), 0});      // the long tail starts first
-            queues[1].push_back(Job{shorts, est_of(shorts), 0});
-        } else {
-            queues.resize(1);
-            queues[0].push_back(Job{good, est_of(good), 0});
-        }
+            b.lane[0].push_back(Job{longs, est_of(longs), 0});      // the long tail starts first
+            b.lane[1].push_back(Job{shorts, est_of(shorts), 0});
+        } else if (!good.empty())
+            b.lane[good.size() >= 256 ? 1 : 0].push_back(Job{good, est_of(good), 0});
     }
-    int rc = good.empty() ? 0 : run_pipelines(*p, queues, *ho, spans);
-    if (rc) {
-        // early-harvest copies (copy_stream) or kernels of the other pipeline may still be in flight: the pinned
-        // result chunks return to the pool only once the whole device is idle
-        { hipError_t e_ = hipDeviceSynchronize(); (void)e_; }
-        free_out(ho);
-        return rc;
+    start_scheduler();
+    {
+        std::lock_guard<std::mutex> lk(g.qmu);
+        g.submitted.push_back(bp);
+        g.n_inflight++;
     }
-    if (getenv("RAFFT_TRACE")) {       // per-step timeline: spans are recorded in step order
-        float acc[16] = {0};
-        int stepno = 0;
-        for (auto &sp : spans) {
-            float ms = 0;
-            if (!span_on(sp.kind) || hipEventElapsedTime(&ms, sp.a, sp.b) != hipSuccess) continue;
-            if (sp.kind < 16) acc[sp.kind] += ms;
-            if (sp.kind == 1) {        // the beam step closes a folding step (materialize of it follows)
-                fprintf(stderr, "[rafft] t-step %2d: expand wall %.3f (c1 %.3f c2 %.3f c3 %.3f) beam %.3f  prev-materialize %.3f\n",
-                        ++stepno, acc[4], acc[11], acc[12], acc[13], acc[1], acc[2]);
-                for (float &x : acc) x = 0;
-            }
-        }
-    }
-    for (auto &sp : spans) {
-        float ms = 0;
-        if (span_on(sp.kind) && hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
-            if (sp.kind == 10) g.stats.ms_expand_c1 += ms;   /* class 0: unused */
-            else if (sp.kind == 11) g.stats.ms_expand += ms;   /* dominant kernel: regions with P <= 512 */
-            else if (sp.kind == 12) g.stats.ms_expand_c2 += ms;
-            else if (sp.kind == 13) g.stats.ms_expand_c3 += ms;
-            else if (sp.kind == 4) g.stats.ms_expand_wall += ms;
-            else if (sp.kind == 1) g.stats.ms_beam += ms;
-            else if (sp.kind == 2) g.stats.ms_materialize += ms;
-            else g.stats.ms_output += ms;
-        }
-    }
-    for (int i = 0; i < n_seq; i++) {
-        rafft_seq_result &sr = ho->seq[i];
-        sr.step_size = ho->step_size[i].data(); sr.step_off = ho->step_off[i].data();
-        sr.db = ho->db_ptr[i]; sr.dcal = ho->dcal_ptr[i];
-    }
-    ho->res.n_seq = n_seq; ho->res.seq = ho->seq.data(); ho->res._owner = ho;
-    *out_ = &ho->res;
-    g.stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    g.qcv_sched.notify_one();
+    *job_ = new rafft_job{bp};
     return 0;
+}
+
+static int wait_job(rafft_job *job, rafft_result **out_)
+{
+    if (out_) *out_ = nullptr;
+    if (!job) return fail(RAFFT_ERR_PARAM, "null job");
+    std::shared_ptr<Batch> bp = job->b;
+    delete job;
+    {
+        std::unique_lock<std::mutex> lk(g.qmu);
+        g.qcv_done.wait(lk, [&] { return bp->done; });
+    }
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        g.stats = bp->stats;
+    }
+    if (bp->rc) return fail(bp->rc, bp->err);
+    if (!out_) { free_out(bp->ho); bp->ho = nullptr; return fail(RAFFT_ERR_PARAM, "null result pointer"); }
+    *out_ = &bp->ho->res;
+    bp->ho = nullptr;          // the caller owns it now (rafft_free_result)
+    return 0;
+}
+
+int rafft_fold_submit(const rafft_params *p, int n_seq, const char *const *seqs, const int *lens, int device, rafft_job **job)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    return submit_locked(p, n_seq, seqs, lens, device, job);
+}
+
+int rafft_fold_wait(rafft_job *job, rafft_result **out) { return wait_job(job, out); }
+
+int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs, const int *lens, int device, rafft_result **out_)
+{
+    if (!out_) return fail(RAFFT_ERR_PARAM, "null argument");
+    *out_ = nullptr;
+    rafft_job *job = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        if (int rc = submit_locked(p, n_seq, seqs, lens, device, &job)) return rc;
+    }
+    return wait_job(job, out_);
 }
 
 void rafft_free_result(rafft_result *r)
 {
-    if (r && r->_owner) {
-        std::lock_guard<std::mutex> lk(g.mu);
-        free_out((HostOut *)r->_owner);
-    }
+    if (r && r->_owner) free_out((HostOut *)r->_owner);
 }
 
 int rafft_get_stats(rafft_stats *o)
 {
     if (!o) return RAFFT_ERR_PARAM;
+    std::lock_guard<std::mutex> lk(g.mu);
     *o = g.stats;
     return 0;
 }
@@ -1053,7 +1260,9 @@ static int parse_db(const char *seq, const char *db, int L, std::vector<int16_t>
 static int eval_structures_impl(int n, const char *const *seqs, const char *const *dbs, int *dcal_out, int *status_out, double temp = 37.0)
 {
     if (int rc = init_ctx(-1)) return rc;
+    drain();                                   // (g.mu is held: nothing new is submitted meanwhile)
     if (int rc = ensure_tables(temp)) return rc;
+    if (int rc = init_ws(g.ws[0])) return rc;
     std::vector<long long> off(n);
     std::vector<int> len(n), status(n, 0);
     long long tot = 0;
@@ -1258,11 +1467,13 @@ int rafft_expand_node(const rafft_params *p, const char *seq, const char *db, co
     std::vector<SeqIn> one{{seq, L, 0}};
     HostOut ho;
     ho.seq.resize(1); ho.step_size.resize(1); ho.step_off.resize(1); ho.dcal_ptr.assign(1, nullptr); ho.db_ptr.assign(1, nullptr);
-    std::vector<Span> spans;
-    g.ws[0].ev_used = 0;
-    rafft_params pp = *p;
-    pp.max_stack = std::max(1, pp.max_stack);
-    if (int rc = run_seam(pp, one, ho, spans, sm)) return rc;
+    Batch bt;                                  // a private batch: the scheduler is idle (drained above) and g.mu is held
+    bt.p = *p;
+    bt.p.max_stack = std::max(1, bt.p.max_stack);
+    bt.n_seq = 1; bt.ho = &ho;
+    const int src = run_seam(bt, one, sm);
+    for (hipEvent_t e : bt.events) g.ev_free.push_back(e);
+    if (src) return src;
     int hdr[4];
     HIPCHK(hipMemcpy(hdr, dbg.n_ranked, 16, hipMemcpyDeviceToHost));
     *n_ranked = hdr[0]; *n_kept = hdr[1];

@@ -100,6 +100,7 @@ struct Dev {
     const uint8_t *codes;
     const int *seq_off, *seq_len;
     int K, B, max_branch, min_hp, traj, memo, force_fft, rl_cap, mat_tile, merge_cls;
+    int cls1_P, cls1_br;         // limits of the one-wavefront expand class (FFT size, branches): they set its LDS per wavefront
     double min_nrj, gc, au, gu;
     int *beam, *beam_n, *done, *nsteps;
     // children of the current step
@@ -152,7 +153,7 @@ struct Dev {
 #define RL_CAP 1024        // beam_step_kernel: regions with >= 2 candidates of all beam members, kept in LDS
 
 __host__ __device__ inline int next_pow2_ge(int x) { int p = 2; while (p < x) p <<= 1; return p; }
-__host__ __device__ inline int node_class(int n, int L, int nbr, int merge_cls = 0)
+__host__ __device__ inline int node_class(int n, int L, int nbr, int merge_cls = 0, int cls1_P = CLS1_P, int cls1_br = CLS1_BR)
 {
     // few regions in this step (the tail of a batch): all of them go to one kernel, the widest one that is
     // configured - one launch and one region per workgroup instead of three nearly empty kernels in a row
@@ -161,7 +162,7 @@ __host__ __device__ inline int node_class(int n, int L, int nbr, int merge_cls =
     int P = next_pow2_ge(2 * n - 1);
     // class 0 is kept empty: measured on MI355X, running the tiny regions (P <= 128) in their own
     // persistent kernel beside class 1 oversubscribes the wave slots and is slower than one kernel
-    if (L <= CLS01_L && P <= CLS1_P && nbr <= CLS1_BR) return 1;
+    if (L <= CLS01_L && P <= cls1_P && nbr <= cls1_br) return 1;
     if (P <= CLS2_P) return 2;
     return 3;
 }
@@ -170,9 +171,11 @@ __host__ __device__ inline int node_class(int n, int L, int nbr, int merge_cls =
 // buffers and the sort keys; region B holds the loop itself.
 struct ExpandLds {
     int offA, szA, off_pos, off_code, off_S, off_br, off_rk, off_nb, off_mi, off_mj, off_dd, off_keep, off_w, off_misc,
-        off_tab, off_tw, total;
+        per_team,             // bytes of one team (wavefront or workgroup); a workgroup of `wpb` teams holds wpb of them ...
+        off_tab, off_tw,      // ... followed by ONE shared area: energy tables, twiddles (offsets inside that area)
+        total;
 };
-__host__ __device__ inline ExpandLds expand_lds(int Pmax, int Lmax, int nmax, int brmax, int Kmax, bool tab_lds)
+__host__ __device__ inline ExpandLds expand_lds(int Pmax, int Lmax, int nmax, int brmax, int Kmax, bool tab_lds, int wpb = 1)
 {
     ExpandLds l;
     auto al = [](int x) { return (x + 15) & ~15; };
@@ -191,8 +194,10 @@ __host__ __device__ inline ExpandLds expand_lds(int Pmax, int Lmax, int nmax, in
     l.off_keep = o; o += al(2 * Kmax);
     l.off_w = o; o += al(25 * 8);
     l.off_misc = o; o += 128;
-    l.off_tab = o; if (tab_lds) o += al((int)sizeof(SmallT));
-    l.off_tw = o; if (tab_lds) o += al(8 * (Pmax / 2));
-    l.total = o;
+    l.per_team = o;
+    int sh = 0;
+    l.off_tab = sh; if (tab_lds) sh += al((int)sizeof(SmallT));
+    l.off_tw = sh; if (tab_lds && Pmax <= CLS2_P) sh += al(8 * (Pmax / 2));    // (the twiddles of the largest class stay in L2)
+    l.total = wpb * l.per_team + sh;
     return l;
 }

@@ -114,25 +114,48 @@ struct PlainView {
 
 // ------------------------------------------------------------ expand kernel
 
-template <int NT, bool TAB_LDS>
-__global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, int Lmax, int nmax, int brmax, int Kmax)
+#ifndef RAFFT_EXPAND64_WAVES
+#define RAFFT_EXPAND64_WAVES 4        // <= 128 VGPRs: four wavefronts per SIMD
+#endif
+// Synchronisation inside one region's work.  The one-wavefront class needs no s_barrier: the LDS operations of a
+// wavefront execute in program order, so a compiler fence at wavefront scope is all it takes - and, unlike
+// __syncthreads(), it does not wait for the global loads in flight.  That also lets WPB wavefronts share a workgroup
+// (each with its own slice of LDS and its own regions, never waiting for each other) and with it ONE copy of the hot
+// energy tables in LDS.
+__device__ __forceinline__ void wave_sync()
 {
-    extern __shared__ __align__(16) unsigned char lds[];
-    const ExpandLds lay = expand_lds(Pmax, Lmax, nmax, brmax, Kmax, TAB_LDS);
-    const int tid = threadIdx.x;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+#define ESYNC() do { if (NT == 64) wave_sync(); else __syncthreads(); } while (0)
+
+template <int NT, bool TAB_LDS, int WPB>
+__global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 256 ? 3 : 2)) void expand_kernel(Dev d, int cls, int Pmax, int Lmax, int nmax, int brmax, int Kmax)
+{
+    static_assert(WPB == 1 || NT == 64, "only the one-wavefront class packs several wavefronts into a workgroup");
+    extern __shared__ __align__(16) unsigned char lds_all[];
+    const ExpandLds lay = expand_lds(Pmax, Lmax, nmax, brmax, Kmax, TAB_LDS, WPB);
+    const int tid = threadIdx.x % NT;                 // position inside this region's team (a wavefront / the workgroup)
+    const int team = threadIdx.x / NT;                // wavefront of the workgroup (0 when the workgroup is the team)
+    const unsigned gteam = blockIdx.x * WPB + team, n_teams = gridDim.x * WPB;
+    unsigned char *const lds = lds_all + team * lay.per_team;
     const SmallT *T = &d.T->s;
     const BigT *B = &d.T->b;
     const float2 *tw = d.tw;
     int twN = MAX_P;          // the twiddle table holds exp(-2 pi i m / twN), m < twN/2
-    if (TAB_LDS) {            // persistent workgroup: hot energy tables and twiddles live in LDS
-        int *dst = (int *)(lds + lay.off_tab);
+    if (TAB_LDS) {            // persistent workgroup: hot energy tables and twiddles live in LDS, one copy per workgroup
+        unsigned char *shared = lds_all + WPB * lay.per_team;
+        int *dst = (int *)(shared + lay.off_tab);
         const int *src = (const int *)&d.T->s;
-        for (int i = tid; i < (int)(sizeof(SmallT) / 4); i += NT) dst[i] = src[i];
-        float2 *twl = (float2 *)(lds + lay.off_tw);
-        for (int m = tid; m < Pmax / 2; m += NT) twl[m] = d.tw[m * (MAX_P / Pmax)];
+        for (int i = threadIdx.x; i < (int)(sizeof(SmallT) / 4); i += NT * WPB) dst[i] = src[i];
         T = (const SmallT *)dst;
-        tw = twl;
-        twN = Pmax;
+        if (Pmax <= CLS2_P) {
+            float2 *twl = (float2 *)(shared + lay.off_tw);
+            for (int m = threadIdx.x; m < Pmax / 2; m += NT * WPB) twl[m] = d.tw[m * (MAX_P / Pmax)];
+            tw = twl;
+            twN = Pmax;
+        }
+        __syncthreads();      // the only workgroup-wide barrier of the packed form
     }
     uint16_t *pos = (uint16_t *)(lds + lay.off_pos);
     uint8_t *code = lds + lay.off_code;
@@ -153,8 +176,8 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
         wtab[tid] = (tp == 5 || tp == 6) ? d.au : (tp == 1 || tp == 2) ? d.gc : (tp == 3 || tp == 4) ? d.gu : 0.0;
     }
     const unsigned n_items = d.c->n_work[cls];
-    if (blockIdx.x == 0 && tid == 0) d.c->n_mat = 0;           // the beam step that follows counts its new structures here
-    const int shard = blockIdx.x & (NSHARD - 1);
+    if (gteam == 0 && tid == 0) d.c->n_mat = 0;                // the beam step that follows counts its new structures here
+    const int shard = gteam & (NSHARD - 1);
     unsigned long long st_items = 0, st_n = 0, st_lags = 0, st_nbr = 0;   // per-block statistics
 
     // Work items are fetched FETCH at a time and candidate slots are reserved in slabs, so that the
@@ -163,15 +186,15 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
     const bool eprof = d.prof_e != nullptr && tid == 0;      // diagnostic phase stamps (RAFFT_TRACE=3)
     unsigned long long eacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, et = eprof ? clock64() : 0;
 #define ESTAMP(k) do { if (eprof) { const unsigned long long tn_ = clock64(); eacc[k] += tn_ - et; et = tn_; } } while (0)
-    const unsigned FETCH = (NT == 64 && n_items > 4u * gridDim.x) ? 4u : 1u;
+    const unsigned FETCH = (NT == 64 && n_items > 4u * n_teams) ? 4u : 1u;
     unsigned fetch_base = 0, fetch_left = 0;                 // uniform across the workgroup
     unsigned long long slab_base = 0; unsigned slab_left = 0;   // thread 0 only
 
     for (;;) {
-        __syncthreads();                       // previous region's LDS use is over
+        ESYNC();                       // previous region's LDS use is over
         if (fetch_left == 0) {
             if (tid == 0) misc[8] = (int)atomicAdd(&d.c->next_work[cls], FETCH);
-            __syncthreads();
+            ESYNC();
             fetch_base = (unsigned)misc[8];
             fetch_left = FETCH;
         }
@@ -203,7 +226,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
             for (int x = x0 + tid; x < x1; x += NT) Sl[x] = codes[x];
         }
         for (int t = tid; t < nbr; t += NT) brl[t] = brg[t];
-        __syncthreads();
+        ESYNC();
         }
 
         ESTAMP(1);   // LDS fill
@@ -222,7 +245,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                 z1[t] = make_float2(c == 1 ? 1.f : 0.f, c == 3 ? 1.f : 0.f); // A + iG
                 z2[t] = make_float2(c == 4 ? 1.f : 0.f, c == 2 ? 1.f : 0.f); // U + iC
             }
-            __syncthreads();
+            ESYNC();
             // DIF, natural in -> bit-reversed out.  Two radix-2 stages (spans s and s/2) are done per pass on four
             // elements held in registers: the same operations in the same order as stage by stage (bit-identical
             // results), half the LDS traffic and barriers.
@@ -248,7 +271,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                         z2[j + s] = add2(a2, a3); z2[j + s + h] = cmul(sub2(a2, a3), w2);
                     }
                 }
-                __syncthreads();
+                ESYNC();
             }
             if (s == 1) {                                           // odd number of stages: the last one alone
                 for (int b = tid; b < (P >> 1); b += NT) {
@@ -258,7 +281,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                     a = z2[j]; bb = z2[j + 1];
                     z2[j] = add2(a, bb); z2[j + 1] = cmul(sub2(a, bb), tw[0]);
                 }
-                __syncthreads();
+                ESYNC();
             }
             for (int k = tid; k <= (P >> 1); k += NT) {   // separate the packed real spectra, multiply
                 int km = (P - k) & (P - 1);
@@ -277,7 +300,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                     z2[jm] = make_float2(Z.x, -Z.y);
                 }
             }
-            __syncthreads();
+            ESYNC();
             // DIT inverse, bit-reversed in -> natural out; again two stages (spans s and 2s) per pass
             int si = 1;
             if (logP & 1) {                                         // odd number of stages: the first one alone
@@ -288,7 +311,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                     a = z2[j]; bb = cmulc(z2[j + 1], tw[0]);
                     z2[j] = add2(a, bb); z2[j + 1] = sub2(a, bb);
                 }
-                __syncthreads();
+                ESYNC();
                 si = 2;
             }
             for (; si < P; si <<= 2) {
@@ -312,7 +335,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                         z2[j] = add2(y0, u2); z2[j + s2] = sub2(y0, u2); z2[j + s1] = add2(y1, u3); z2[j + s2 + s1] = sub2(y1, u3);
                     }
                 }
-                __syncthreads();
+                ESYNC();
             }
         }
 
@@ -350,10 +373,10 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                 }
                 keyv[k] = v;
             }
-            __syncthreads();
+            ESYNC();
             if (inplace) {                                  // lag column of the in-place sort
                 for (int k = tid; k < P; k += NT) lagk[k] = (uint16_t)k;
-                __syncthreads();
+                ESYNC();
             }
         } else {
             // keyv[k] aliases z1[k] byte for byte and is written by the thread that read it;
@@ -371,10 +394,10 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                 }
                 keyv[k] = v;
             }
-            __syncthreads();
+            ESYNC();
             if (inplace) {                                  // lag column of the in-place sort
                 for (int k = tid; k < P; k += NT) lagk[k] = (uint16_t)k;
-                __syncthreads();
+                ESYNC();
             }
         }
         ESTAMP(3);   // lag values
@@ -391,13 +414,13 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
             bool take_ge = false;          // every key >= prefix is selected (the threshold fell between two values)
             for (int pass = 7; pass >= 0; pass--) {
                 for (int i = tid; i < 256; i += NT) hist[i] = 0;
-                __syncthreads();
+                ESYNC();
                 const int sh_hi = 8 * (pass + 1);
                 for (int i = tid; i < m; i += NT) {
                     const unsigned long long u = ukey(i);
                     if (pass == 7 || (u >> sh_hi) == (prefix >> sh_hi)) atomicAdd(&hist[(int)((u >> (8 * pass)) & 255ULL)], 1);
                 }
-                __syncthreads();
+                ESYNC();
                 // largest byte b with count(bytes > b) < kk <= count(bytes >= b): suffix scan over the bins
                 {
                     constexpr int BPT = NT >= 256 ? 1 : 256 / NT;      // bins per thread, from the top bin down
@@ -410,12 +433,12 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                         if (ex < kk && kk <= ex + hs[j] && hs[j] > 0) { shs[28] = 255 - (tid * BPT + j); shs[29] = kk - ex; shs[30] = hs[j]; }
                         ex += hs[j];
                     }
-                    __syncthreads();
+                    ESYNC();
                 }
                 prefix |= (unsigned long long)(unsigned)shs[28] << (8 * pass);
                 kk = shs[29];
                 const bool whole_bin = kk == shs[30];      // all keys of the threshold bin are wanted: no need to look
-                __syncthreads();                           // at the lower bytes (the usual case after two or three passes)
+                ESYNC();                           // at the lower bytes (the usual case after two or three passes)
                 if (whole_bin) { take_ge = true; break; }
             }
             // take every lag with key > prefix and the kk largest lags among key == prefix (sweep from the top)
@@ -430,13 +453,13 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                 int gtot, gex = block_exscan<NT>(g, shs, &gtot);
                 if (g) rk[outn + gex] = (uint16_t)i;
                 outn += gtot; tie_run += ttot;
-                __syncthreads();
+                ESYNC();
             }
             // the debug seam reports the ranking: sort the selected lags by (value desc, lag desc)
             if (dbgrank) {
             int M2 = 2; while (M2 < Kp) M2 <<= 1;
             for (int i = Kp + tid; i < M2; i += NT) rk[i] = 0xFFFF;
-            __syncthreads();
+            ESYNC();
             for (int k2 = 2; k2 <= M2; k2 <<= 1)
                 for (int j = k2 >> 1; j > 0; j >>= 1) {
                     for (int i = tid; i < M2; i += NT) {
@@ -451,14 +474,14 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                             if (up ? !a_first : a_first) { rk[i] = lb; rk[ixj] = la; }
                         }
                     }
-                    __syncthreads();
+                    ESYNC();
                 }
             }
             }
             for (int r = tid; r < Kp; r += NT)
                 if (d.dbg.lag) { d.dbg.lag[r] = rk[r]; d.dbg.corval[r] = keyv[rk[r]]; }
             if (tid == 0 && d.dbg.n_ranked) *d.dbg.n_ranked = Kp;
-            __syncthreads();
+            ESYNC();
         } else {
         if (inplace)
         for (int rep_ = 0; rep_ < 1 + ((d.rep >> 1) & 1); rep_++)
@@ -477,7 +500,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                             }
                         }
                     }
-                    __syncthreads();
+                    ESYNC();
                 }
             }
         for (int r = tid; r < Kp; r += NT) {
@@ -485,7 +508,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
             if (d.dbg.lag) { d.dbg.lag[r] = lagk[r]; d.dbg.corval[r] = keyv[r]; }   // (debug seam always sorts)
         }
         if (tid == 0 && d.dbg.n_ranked) *d.dbg.n_ranked = Kp;
-        __syncthreads();
+        ESYNC();
         }
 
         ESTAMP(4);   // ranking
@@ -520,7 +543,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                 const unsigned long long bg = __ballot(t >= 1 && t < n && (int)pos[t] - (int)pos[t > 0 ? t - 1 : 0] == 1);
                 if ((tid & 63) == 0) { F[0 * W + wq] = bA; F[1 * W + wq] = bC; F[2 * W + wq] = bG; F[3 * W + wq] = bU; F[4 * W + wq] = bg; }
             }
-            __syncthreads();
+            ESYNC();
             // reversed strings: bit j of R = bit (n-1-j) of F.  Reverse the whole 64 W-bit string (word order and
             // bit order), then shift the n live bits down: R bit j = T bit (j + 64 W - n) with T[w] = brev(F[W-1-w]);
             // bits of F past n are zero.
@@ -531,7 +554,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                 const unsigned long long hi = q + 1 < W ? __brevll(F[which * W + W - 2 - q]) : 0ULL;
                 R[which * W + w] = bsh ? (lo >> bsh) | (hi << (64 - bsh)) : lo;
             }
-            __syncthreads();
+            ESYNC();
             }
             // 64 bits of string X (W words) starting at bit `start` (may be negative / past the end -> zeros)
             auto window = [&](const unsigned long long *X, int start) -> unsigned long long {
@@ -622,7 +645,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                 }
             }
             if (C > 1) {
-                __syncthreads();
+                ESYNC();
                 for (int r = tid; r < Kp; r += NT) {
                     double mx_s = 0.0;
                     int mx_nb = 0, mx_i = 0, mx_j = 0;
@@ -668,7 +691,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                 }
             }
             if (C > 1) {
-                __syncthreads();
+                ESYNC();
                 for (int r = tid; r < Kp; r += NT) {
                     double mx_s = 0.0;
                     int mx_nb = 0, mx_i = 0, mx_j = 0;
@@ -681,7 +704,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                 }
             }
         }
-        __syncthreads();
+        ESYNC();
 
         ESTAMP(5);   // window_slide
         // ---- dE of every candidate stem: only the loops it changes, from the branch list
@@ -714,7 +737,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
             }
             if (tid == 0) { pe_ext[nbr] = c_e; pe_ml[nbr] = c_m; psp[nbr] = (uint16_t)c_s; }
         }
-        __syncthreads();
+        ESYNC();
         const BrPrefix pf{pe_ext, pe_ml, psp};
         const BrList all_br{brl, 0, nbr, 0, 0, 0, 0, 0};
         const int e_old = loop_energy_pre(T, B, Sl, L, ci, cj, all_br, pf);      // the loop as it is (same for every stem)
@@ -754,7 +777,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                 } else if (d.dbg.ddcal)
                     d.dbg.ddcal[r] = INT_MIN;
             }
-        __syncthreads();
+        ESYNC();
 
         ESTAMP(6);   // dE
         // ---- stable sort of the kept candidates by dE (ties keep lag-rank order), emit
@@ -766,23 +789,23 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
             for (int base = 0; base < Kp; base += NT) {
                 const int r = base + tid;
                 const int f = (r < Kp) ? keep[r] : 0;
-                __syncthreads();                      // everyone has read keep[] of this slab
+                ESYNC();                      // everyone has read keep[] of this slab
                 const unsigned long long bal = __ballot(f != 0);
                 int pre = __popcll(bal & ((1ULL << lane) - 1));
                 if (NT > 64) {
                     if (lane == 0) wave_tot[wv] = __popcll(bal);
-                    __syncthreads();
+                    ESYNC();
                     int tot = 0;
                     for (int w = 0; w < NT / 64; w++) { if (w < wv) pre += wave_tot[w]; tot += wave_tot[w]; }
                     if (f) keep[nkept + pre] = (uint16_t)r;   // nkept + pre <= r: never clobbers an unread flag
                     nkept += tot;
-                    __syncthreads();
+                    ESYNC();
                 } else {
                     if (f) keep[nkept + pre] = (uint16_t)r;
                     nkept += __popcll(bal);
                 }
             }
-            __syncthreads();
+            ESYNC();
         }
         if (tid == 0) {
             unsigned long long base = 0;
@@ -800,7 +823,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
             *(unsigned long long *)&misc[4] = base;
             st_items++; st_n += n; st_lags += Kp; st_nbr += nbr;
         }
-        __syncthreads();
+        ESYNC();
         const unsigned long long cbase = *(unsigned long long *)&misc[4];
         const bool ovf = misc[2] != 0;
         if (!ovf)
@@ -812,7 +835,7 @@ __global__ __launch_bounds__(NT) void expand_kernel(Dev d, int cls, int Pmax, in
                 const int r = keep[x];
                 ck[x] = ((unsigned long long)((unsigned)dd[r] ^ 0x80000000u) << 32) | (unsigned)r;
             }
-            __syncthreads();
+            ESYNC();
             for (int x = tid; x < nkept; x += NT) {
                 const unsigned long long kx = ck[x];
                 const int r = (int)(kx & 0xFFFFFFFFu);
@@ -1715,7 +1738,7 @@ __global__ __launch_bounds__(256) void dedupe_kernel(Dev d)
             if (canon == nid) {
                 // a stem needs two unpaired positions: a lone position (bulge remnant) has no candidates
                 if (d.nd[nid].n < 2) d.nd[nid].ncand = 0;
-                else cls = node_class(d.nd[nid].n, d.seq_len[d.nd[nid].seq], d.nd[nid].nbr, d.merge_cls);
+                else cls = node_class(d.nd[nid].n, d.seq_len[d.nd[nid].seq], d.nd[nid].nbr, d.merge_cls, d.cls1_P, d.cls1_br);
             }
             else { d.nd_canon[nid] = canon; aliases++; }
         }
@@ -1756,7 +1779,7 @@ __global__ void init_roots_kernel(Dev d)
         d.done[sq] = L > 0 ? 0 : 1;
         d.seen_off[sq] = (uint64_t)sq * SEEN0; d.seen_cap[sq] = SEEN0; d.seen_cnt[sq] = 0;   // zeroed by the host memset
         if (L > 0) {
-            int cls = node_class(L, L, 0);
+            int cls = node_class(L, L, 0, 0, d.cls1_P, d.cls1_br);
             unsigned int w = atomicAdd(&d.c->n_work[cls], 1u);
             d.work[cls][w] = sq;
         }

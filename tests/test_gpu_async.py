@@ -1,0 +1,94 @@
+"""Continuous batching (rafft_fold_submit / rafft_fold_wait): several batches in flight, driven by the library's one
+scheduler thread, give exactly the results of synchronous calls - whatever is in flight beside them."""
+import threading
+
+import numpy as np
+import pytest
+
+import oracle
+import rafft_amd
+from rafft_amd import _native, rafft as R
+
+pytestmark = pytest.mark.gpu
+
+
+def key(res, traj):
+    if traj:
+        return [[[(s.str_struct, s.dcal) for s in st] for st in t] for _, t in res]
+    return [[(s.str_struct, s.dcal) for s in beam] for beam in res]
+
+
+def make_batches(bench_rows):
+    rng = np.random.default_rng(17)
+    rnd = lambda lens: ["".join(rng.choice(list("ACGU"), int(n))) for n in lens]
+    long_tail = rnd(rng.integers(30, 150, size=300)) + rnd([1500, 2100])
+    return [
+        (dict(nb_mode=100, max_stack=50, max_branch=1000, traj=False), [r["seq"] for r in bench_rows[::3]]),
+        (dict(nb_mode=100, max_stack=10, max_branch=200, traj=True), long_tail),
+        (dict(nb_mode=100, max_stack=20, max_branch=1000, traj=False), rnd(rng.integers(60, 400, size=500))),
+        (dict(nb_mode=30, max_stack=5, max_branch=50, traj=True), rnd(rng.integers(10, 90, size=40))),
+        (dict(nb_mode=100, max_stack=50, max_branch=1000, traj=False), [r["seq"] for r in bench_rows[1::3]]),
+        (dict(nb_mode=100, max_stack=200, max_branch=1000, traj=False), rnd([700, 900, 1200])),
+    ]
+
+
+def test_gpu_batches_in_flight_equal_synchronous_calls(bench_rows):
+    batches = make_batches(bench_rows)
+    want = [key(rafft_amd.fold_batch(seqs, **kw), kw["traj"]) for kw, seqs in batches]
+    # all in flight at once, waited for in reverse order
+    pend = [rafft_amd.submit_batch(seqs, **kw) for kw, seqs in batches]
+    got = [None] * len(batches)
+    for i in reversed(range(len(batches))):
+        got[i] = key(pend[i].result(), batches[i][0]["traj"])
+    assert got == want
+    # a rolling window of two (the bench loop), several rounds
+    q, got2 = [], []
+    for rnd_ in range(3):
+        for kw, seqs in batches:
+            q.append((rafft_amd.submit_batch(seqs, **kw), kw["traj"]))
+            if len(q) >= 2:
+                pb, tr = q.pop(0)
+                got2.append(key(pb.result(), tr))
+    while q:
+        pb, tr = q.pop(0)
+        got2.append(key(pb.result(), tr))
+    assert got2 == want * 3
+    # and a sample against the oracle
+    kw, seqs = batches[3]
+    for s, (fin, traj) in zip(seqs[:10], rafft_amd.fold_batch(seqs, **kw)):
+        _, o = oracle.fold(s, kw["nb_mode"], kw["max_stack"], kw["max_branch"], traj=True)
+        assert [[(x.str_struct, x.dcal) for x in st] for st in traj] == [[(x.str_struct, x.dcal) for x in st] for st in o]
+
+
+def test_gpu_calls_from_several_threads_and_seam_calls_between(bench_rows):
+    """fold_batch from three host threads at once (ctypes releases the GIL), whole-structure evaluations (which borrow
+    a workspace: they wait for the batches in flight) and a failing submission in between"""
+    batches = make_batches(bench_rows)[:3]
+    want = [key(rafft_amd.fold_batch(seqs, **kw), kw["traj"]) for kw, seqs in batches]
+    got = [None] * 3
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                got[i] = key(rafft_amd.fold_batch(batches[i][1], **batches[i][0]), batches[i][0]["traj"])
+        except Exception as e:        # pragma: no cover
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in th:
+        t.start()
+    flat = [(s, beam[0][0]) for s, beam in zip(batches[0][1][:50], want[0][:50])]
+    for _ in range(3):
+        e, st = R.eval_structures([f[0] for f in flat], [f[1] for f in flat])
+        assert not any(st) and e == [w[0][1] for w in want[0][:50]]
+        with pytest.raises(_native.RafftError):
+            rafft_amd.submit_batch(["GGGAAACCC"], max_stack=0)
+    for t in th:
+        t.join()
+    assert not errs and got == want
+
+
+def test_gpu_unwaited_job_is_released():
+    pb = rafft_amd.submit_batch(["GGGGAAAACCCC"] * 4, max_stack=3)
+    del pb                                   # PendingBatch.__del__ waits and frees
+    assert rafft_amd.fold("GGGGAAAACCCC")[0].str_struct == "((((....))))"

@@ -1,0 +1,66 @@
+"""The N > 1 path on the one GPU of the test box: two ranks (child processes, gloo) sharing the card.
+The 8-GPU run is the driver's; this covers its code path - LPT shards, every rank folding its shard through the real
+libraffthip.so, host-side gather on rank 0 - and bench.py's multi-rank mode."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import rafft_amd
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+WORKER = r'''
+import os, sys, json
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+import rafft_amd
+from rafft_amd import sharding
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+seqs = json.load(open({seqfile!r}))
+res = sharding.fold_sharded(seqs, device=0, nb_mode=100, max_stack=20, max_branch=1000, traj=True)
+if dist.get_rank() == 0:
+    json.dump([[[(x.str_struct, x.dcal) for x in st] for st in traj] for fin, traj in res], open({outfile!r}, "w"))
+    json.dump(rafft_amd.last_stats(), open({outfile!r} + ".stats", "w"))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_gpu_two_ranks_one_gpu_sharded_fold(tmp_path):
+    rng = np.random.default_rng(4)
+    lens = [int(x) for x in rng.integers(20, 300, size=120)] + [900, 1400]
+    seqs = ["".join(rng.choice(list("ACGU"), n)) for n in lens]
+    seqfile, outfile = tmp_path / "seqs.json", tmp_path / "out.json"
+    seqfile.write_text(json.dumps(seqs))
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, seqfile=str(seqfile), outfile=str(outfile)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29653", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    got = json.loads(outfile.read_text())
+    want = rafft_amd.fold_batch(seqs, 100, 20, 1000, traj=True)
+    assert [[[tuple(x) for x in st] for st in t] for t in got] == [[[(x.str_struct, x.dcal) for x in st] for st in traj] for fin, traj in want]
+    st = json.loads((tmp_path / "out.json.stats").read_text())
+    assert 0 < st["n_structs"] and st["n_regrows"] == 0           # rank 0 really folded (its shard) on the GPU
+
+
+def test_gpu_bench_two_ranks_sharded_mode():
+    """bench.py as the driver starts it for N > 1 (here: 2 ranks on the one GPU, gloo instead of RCCL): strong scaling
+    over LPT shards, the gathered result equal to a single-GPU fold of the whole set"""
+    env = dict(os.environ, BENCH_SAME_GPU="1", BENCH_BACKEND="gloo", BENCH_SKIP_CFG4="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29657", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0 and out["steps"] == 4
+    assert out["config"]["sequences_per_step"] == 2296 and 0 < out["config"]["sequences_on_rank0"] < 2296
+    assert out["sharded_parity"] == {"sequences": 2296, "final_beam_identical_to_single_gpu_fold": 2296}
+    assert out["weak_replica_value"] > 0 and out["roofline"]["frac"] > 0

@@ -1,22 +1,43 @@
-"""Median/min wall time of rafft_fold_batch on the benchmark set over N calls (A/B comparisons of builds)."""
-import ctypes as C, gzip, statistics, sys, time
+"""A/B comparisons of builds on the benchmark set: latency of one synchronous call, throughput with two batches in
+flight (the bench loop), and the summed duration of the dominant kernel per batch.  AB_LIB=<path> picks the build."""
+import ctypes as C, gzip, os, statistics, sys, time
 sys.path.insert(0, ".")
 from rafft_amd import _native as N
 from rafft_amd.rafft import _params
 seqs = [l.split("\t")[1] for l in gzip.open("tests/golden/bench_inputs.tsv.gz", "rt")]
-import os
 if os.environ.get('AB_LIB'):
     N.LIB_PATH = os.path.abspath(os.environ['AB_LIB'])
 lib = N.lib(); N.check(lib.rafft_init(0))
 p = _params(100, 50, 1000, 3, 0.0, False, 37.0, 3.0, 2.0, 1.0)
 enc = [s.encode() for s in seqs]; n = len(enc)
 arr = (C.c_char_p * n)(*enc); lens = (C.c_int * n)(*[len(e) for e in enc])
-ts = []
-for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 14):
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 14
+
+def submit():
+    job = C.c_void_p()
+    N.check(lib.rafft_fold_submit(C.byref(p), n, arr, lens, 0, C.byref(job)))
+    return job
+
+def wait(job):
     res = C.POINTER(N.Result)()
-    t = time.perf_counter()
-    N.check(lib.rafft_fold_batch(C.byref(p), n, arr, lens, 0, C.byref(res)))
-    el = time.perf_counter() - t
+    N.check(lib.rafft_fold_wait(job, C.byref(res)))
     lib.rafft_free_result(res)
-    if it >= 2: ts.append(el * 1e3)
-print(f"median {statistics.median(ts):.3f} ms  min {min(ts):.3f}  max {max(ts):.3f}  ({n / statistics.median(ts) * 1e3:.0f} seq/s)", flush=True)
+    st = N.Stats(); lib.rafft_get_stats(C.byref(st))
+    return st.ms_expand
+
+ts, ex = [], []
+for it in range(iters):
+    t = time.perf_counter()
+    e = wait(submit())
+    if it >= 2: ts.append((time.perf_counter() - t) * 1e3); ex.append(e)
+depth = int(os.environ.get("AB_DEPTH", "2"))
+for rnd in range(2):
+    q = []
+    t = time.perf_counter()
+    for it in range(iters):
+        q.append(submit())
+        if len(q) >= depth: wait(q.pop(0))
+    while q: wait(q.pop(0))
+    tp = (time.perf_counter() - t) / iters * 1e3
+print(f"sequential median {statistics.median(ts):.3f} ms (min {min(ts):.3f}); pipelined x{depth} {tp:.3f} ms/batch = {n / tp * 1e3:.0f} seq/s; "
+      f"expand<64> {statistics.median(ex):.3f} ms/batch", flush=True)
