@@ -169,6 +169,17 @@ int rafft_expand_node(const rafft_params *p, const char *seq, const char *db, co
 
 int rafft_get_stats(rafft_stats *out);
 
+/* Kinetics on the fast-folding graph (the "next" row 8f-2).  Replaces: get_connected_prev + get_transition_mat,
+ * rafft/rafft_kin.py:48-56,68-91 - the O(steps * ms^2 * L) pair-set inclusion search and the Metropolis rate matrix.
+ * Input: the graph as the fold returns it (n_steps beams, `rows` = all their dot-brackets back to back, L bytes each,
+ * no terminator), `uid[r]` = index of row r in the list of unique structures in order of first appearance
+ * (rafft_kin.py:106-112), `energy[u]` = energy of unique structure u, kt = 0.61 in the reference.
+ * Output: the dense n_unique x n_unique rate matrix (row-major doubles, diagonal = -row sum) in DEVICE memory
+ * `rate_device` (HIP pointer of the caller, e.g. a torch tensor's data_ptr) - at ms=1000 it has 10^8 entries and goes
+ * straight into the dense solver. */
+int rafft_kin_rate_matrix(int n_steps, const int *step_size, int L, const char *rows, const int *uid, int n_unique,
+                          const double *energy, double kt, double *rate_device);
+
 /* library / build information: "gfx950 ..." */
 const char *rafft_version(void);
 

@@ -42,7 +42,7 @@ class Stats(C.Structure):
 EXPORTS = ["rafft_init", "rafft_fold_batch", "rafft_fold_submit", "rafft_fold_wait", "rafft_free_result", "rafft_last_error", "rafft_eval_structure",
            "rafft_eval_structures", "rafft_eval_structures_at", "rafft_expand_node", "rafft_get_stats", "rafft_version",
            "rafft_load_params", "rafft_load_params_text", "rafft_reset_params", "rafft_save_params", "rafft_params_info",
-           "rafft_param_value"]
+           "rafft_param_value", "rafft_kin_rate_matrix"]
 
 _lib = None
 
@@ -53,6 +53,29 @@ class RafftError(RuntimeError):
         self.code = code
 
 
+def _one_hip_runtime():
+    """A process must hold ONE HIP runtime.  PyTorch-ROCm ships its own libamdhip64 (same SONAME as /opt/rocm's); if
+    libraffthip.so pulled in the system one first, a later `import torch` would load a second runtime that finds no
+    GPU ("No HIP GPUs are available" - measured).  So when torch is installed its runtime is loaded first and
+    libraffthip.so binds to it; without torch the system runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    hip = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(hip):
+        try:
+            C.CDLL(hip, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load the HIP library (building it is __graft_entry__.build()'s / rafft_amd.build's job)."""
     global _lib
@@ -61,6 +84,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing - run `python -m rafft_amd.build` (hipcc, gfx950). "
                           "rafft_amd has no CPU fallback.")
+    _one_hip_runtime()
     L = C.CDLL(LIB_PATH)
     L.rafft_init.argtypes = [C.c_int]
     L.rafft_fold_batch.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int,
@@ -86,6 +110,8 @@ def lib():
     L.rafft_params_info.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int)]
     L.rafft_param_value.argtypes = [C.c_char_p, C.c_int, C.c_long, C.POINTER(C.c_int)]
     L.rafft_get_stats.argtypes = [C.POINTER(Stats)]
+    L.rafft_kin_rate_matrix.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int, C.c_char_p, C.POINTER(C.c_int), C.c_int,
+                                        C.POINTER(C.c_double), C.c_double, C.c_void_p]
     _lib = L
     return L
 

@@ -26,6 +26,7 @@
 // kernels (rafft_kernels.hip is compiled into the same translation unit so the
 // templates and the Dev struct are shared without a device-link step)
 #include "rafft_kernels.hip"
+#include "rafft_kin.hip"
 
 namespace {
 
@@ -1486,6 +1487,53 @@ int rafft_expand_node(const rafft_params *p, const char *seq, const char *db, co
     HIPCHK(hipMemcpy(kept, dbg.kept, 4 * hdr[1], hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(corval, dbg.corval, 8 * r, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(score, dbg.score, 8 * r, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- kinetics on the fast-folding graph
+
+int rafft_kin_rate_matrix(int n_steps, const int *step_size, int L, const char *rows, const int *uid, int n_unique,
+                          const double *energy, double kt, double *rate_device)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!step_size || !rows || !uid || !energy || !rate_device || n_steps < 1 || L < 1 || L > 32767 || n_unique < 1 || !(kt > 0))
+        return fail(RAFFT_ERR_PARAM, "bad argument");
+    if (int rc = init_ctx(-1)) return rc;
+    if (int rc = init_ws(g.ws[0])) return rc;
+    long long n = 0;
+    std::vector<int> row0(n_steps);
+    for (int i = 0; i < n_steps; i++) { row0[i] = (int)n; n += step_size[i]; if (step_size[i] < 0) return fail(RAFFT_ERR_PARAM, "negative step size"); }
+    if (n < 1 || n > 0x7fffffff) return fail(RAFFT_ERR_PARAM, "bad number of structures");
+    for (long long r = 0; r < n; r++) if (uid[r] < 0 || uid[r] >= n_unique) return fail(RAFFT_ERR_PARAM, "uid out of range");
+    hipStream_t st = g.ws[0].stream;
+    void *d_rows = nullptr, *d_pt = nullptr, *d_stack = nullptr, *d_uid = nullptr, *d_en = nullptr, *d_bad = nullptr;
+    auto cleanup = [&]() { for (void *q : {d_rows, d_pt, d_stack, d_uid, d_en, d_bad}) if (q) { hipError_t fe = hipFree(q); (void)fe; } };
+#define KCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(RAFFT_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
+    KCHK(hipMalloc(&d_rows, (size_t)n * L)); KCHK(hipMalloc(&d_pt, (size_t)n * L * 2)); KCHK(hipMalloc(&d_stack, (size_t)n * L * 2));
+    KCHK(hipMalloc(&d_uid, (size_t)n * 4)); KCHK(hipMalloc(&d_en, (size_t)n_unique * 8)); KCHK(hipMalloc(&d_bad, 4));
+    KCHK(hipMemcpyAsync(d_rows, rows, (size_t)n * L, hipMemcpyHostToDevice, st));
+    KCHK(hipMemcpyAsync(d_uid, uid, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    KCHK(hipMemcpyAsync(d_en, energy, (size_t)n_unique * 8, hipMemcpyHostToDevice, st));
+    KCHK(hipMemsetAsync(d_bad, 0, 4, st));
+    KCHK(hipMemsetAsync(rate_device, 0, (size_t)n_unique * n_unique * 8, st));
+    hipLaunchKernelGGL(kin_pair_table_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (int)n, L, (const char *)d_rows,
+                       (int16_t *)d_pt, (int16_t *)d_stack, (int *)d_bad);
+    KCHK(hipGetLastError());
+    for (int i = 0; i < n_steps; i++) {
+        const int pi = i == 0 ? n_steps - 1 : i - 1;      // the reference compares step 0 with the LAST step (fast_paths[-1], rafft_kin.py:75)
+        if (!step_size[i] || !step_size[pi]) continue;
+        hipLaunchKernelGGL(kin_rates_kernel, dim3((unsigned)step_size[i]), dim3(KIN_NT), (size_t)L * 2, st, L, (const int16_t *)d_pt,
+                           row0[i], step_size[pi], row0[pi], (const int *)d_uid, (const double *)d_en, kt, n_unique, rate_device);
+        KCHK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(kin_diag_kernel, dim3((unsigned)n_unique), dim3(256), 0, st, n_unique, rate_device);
+    KCHK(hipGetLastError());
+    int bad = 0;
+    KCHK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st));
+    KCHK(hipStreamSynchronize(st));
+#undef KCHK
+    cleanup();
+    if (bad) return fail(RAFFT_ERR_STRUCT, "malformed dot-bracket row");
     return 0;
 }
 

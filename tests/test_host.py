@@ -202,3 +202,36 @@ def test_scoring_reproduces_reference_columns(bench_rows):
             if abs(p - a) > 0.006 or abs(s - b) > 0.006:
                 bad += 1
     assert bad <= 3, bad        # one benchmark entry's CT file differs from the CSV's known structure
+
+
+def test_kinetics_solvers_against_high_precision_truth():
+    """the two solvers behind kinetics_gpu (run here on the CPU through torch) against 60-digit arithmetic on the
+    reference's example graphs (tests/golden/kinetics_truth.json.gz, tools/make_kinetics_truth.py) - and the reference's
+    own float64 eig/inv output against the same truth: it is exact early and off by ~0.5 at the end, which is why
+    the late-time check of the GPU path cannot be the reference's numbers"""
+    import torch
+    from conftest import load_json_gz
+    from rafft_amd import rafft_kin
+    truth, gold = load_json_gz("kinetics_truth.json.gz"), load_json_gz("kinetics.json.gz")
+    for name, tr in truth.items():
+        fp, seq = utils.parse_rafft_output(os.path.join(GOLD, name))
+        sl, index = rafft_kin.unique_structures(fp)
+        sm = {st.str_struct: (index[st.str_struct], st.energy) for st in sl}
+        rate = torch.as_tensor(np.asarray(rafft_kin.get_transition_mat(fp, len(sl), sm), dtype=np.float64))
+        en = np.array([st.energy for st in sl])
+        p0 = torch.zeros(len(sl), dtype=torch.float64)
+        p0[0] = 1.0
+        times = np.exp(np.arange(tr["n_steps"]) * (tr["max_time"] / tr["n_steps"]) - 4)
+        ks = tr["sample_index"]
+        want = np.array(tr["populations"])
+        early = [i for i, k in enumerate(ks) if k <= 0.6 * tr["n_steps"]]
+        imp = rafft_kin.solve_master_equation(rate, en, p0, times, "implicit", 32)[ks]
+        spe = rafft_kin.solve_master_equation(rate, en, p0, times, "spectral")[ks]
+        assert np.abs(imp - want)[early].max() < 5e-6 and np.abs(imp - want).max() < 2e-2
+        assert np.abs(spe - want)[early].max() < 1e-6
+        assert imp.min() > -1e-12 and np.allclose(imp.sum(axis=1), 1.0)
+        ref = np.array(gold[name]["trajectory"])[1:][ks]
+        assert np.abs(ref - want)[early].max() < 1e-6
+        if name == "example_rafft_20.out":
+            assert np.abs(ref - want).max() > 0.3                       # the reference's own late-time numbers are noise
+            assert abs(want[-1].max() - 0.5316) < 1e-4                  # = README.org:146 (0.531)
