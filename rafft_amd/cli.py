@@ -27,7 +27,12 @@ _OPTIONS = [
     (("-gc", "--gc_wei"), dict(type=float, default=3.0, help="GC weight")),
     (("-au", "--au_wei"), dict(type=float, default=2.0, help="AU weight")),
     (("-gu", "--gu_wei"), dict(type=float, default=1.0, help="GU weight")),
-    (("--batch",), dict(action="store_true", help="every FASTA record / line of -sf is its own sequence (one GPU batch)")),
+    (("--batch",), dict(action="store_true", help="every record of -sf is its own sequence, all folded as one GPU batch: FASTA records,\n"
+                                                  "one sequence per line, or a CSV with a header (column --csv_column; the reference's\n"
+                                                  "benchmark_cleaned_all_length.csv has `seq`).  With --bench this replaces the process pool of\n"
+                                                  "benchmark_results/bench_fft.py")),
+    (("--csv_column",), dict(default="seq", help="sequence column of a CSV given to -sf --batch (default: seq)")),
+    (("--output", "-o"), dict(help="write the result there instead of stdout")),
     (("--sidecar",), dict(help="with --traj: also write the fast-folding graph as a binary side-car (exact dcal energies,\n"
                                "no strings to re-parse) that `rafft_kin --sidecar` reads; with several sequences the\n"
                                "files are <SIDECAR>.0, <SIDECAR>.1, ...")),
@@ -49,6 +54,13 @@ def read_sequences(args):
     if not args.batch:   # reference behaviour: all non-header lines joined (bin/rafft:42)
         return ["".join(l for l in lines if not l.startswith(">")).replace("T", "U")]
     seqs, cur = [], []
+    if lines and "," in lines[0] and not lines[0].startswith(">"):     # CSV with a header line
+        import csv
+        with open(args.seq_file, newline="") as fh:
+            rd = csv.DictReader(fh)
+            if args.csv_column not in (rd.fieldnames or []):
+                raise SystemExit(f"{args.seq_file}: no column {args.csv_column!r} (columns: {rd.fieldnames})")
+            return [r[args.csv_column].strip().replace("T", "U") for r in rd if r[args.csv_column].strip()]
     fasta = any(l.startswith(">") for l in lines)
     for l in lines:
         if fasta:
@@ -92,11 +104,30 @@ def main(argv=None, fold_batch=None):
         from .rafft import fold_batch
     results = fold_batch(seqs, args.n_mode, args.max_stack, args.max_branch, args.min_hp, args.min_nrj, args.traj,
                          args.temp, args.gc_wei, args.au_wei, args.gu_wei)
-    for k, (s, r) in enumerate(zip(seqs, results)):
-        print(format_result(s, r, args))
-        if args.sidecar and args.traj:
-            from .utils import write_sidecar
-            write_sidecar(args.sidecar if len(seqs) == 1 else f"{args.sidecar}.{k}", s, r[1])
+    out = open(args.output, "wb") if args.output else sys.stdout.buffer if hasattr(sys.stdout, "buffer") else None
+    try:
+        for k, s in enumerate(seqs):
+            side = (args.sidecar if len(seqs) == 1 else f"{args.sidecar}.{k}") if (args.sidecar and args.traj) else None
+            raw = results.raw(k) if hasattr(results, "raw") and out is not None else None
+            if raw is not None:       # streaming: flat result buffers -> text, no Structure objects
+                from .utils import write_result_text, write_sidecar_raw
+                write_result_text(out, s, raw, traj=args.traj, bench=args.bench)
+                if side:
+                    write_sidecar_raw(side, s, raw)
+            else:                     # an injected fold function (tests) or a captured text stdout
+                txt = format_result(s, results[k], args) + "\n"
+                if out is not None:
+                    out.write(txt.encode("ascii"))
+                else:
+                    sys.stdout.write(txt)
+                if side:
+                    from .utils import write_sidecar
+                    write_sidecar(side, s, results[k][1])
+        if out is not None:
+            out.flush()
+    finally:
+        if args.output:
+            out.close()
 
 
 if __name__ == '__main__':

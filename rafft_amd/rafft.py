@@ -138,6 +138,21 @@ class BatchResult(Sequence):
     def status(self, i):
         return self._res.seq[i].status
 
+    def raw(self, i):
+        """Sequence i as flat buffers, without building any Structure: (L, step sizes, dot-bracket rows as an
+        (n_structs, L) uint8 array, int32 dcal array) - views into the library's pinned result chunk, valid while this
+        BatchResult lives.  Steps are laid out one after the other (one step without traj)."""
+        sr = self._res.seq[i]
+        if sr.status != N.OK:
+            return None
+        n, L = sr.n_structs, sr.length
+        sizes = [sr.step_size[s] for s in range(sr.n_steps)]
+        if n == 0:
+            return L, sizes, np.zeros((0, L), np.uint8), np.zeros(0, np.int32)
+        buf = (C.c_char * (n * (L + 1))).from_address(C.addressof(sr.db.contents))
+        rows = np.frombuffer(buf, dtype=np.uint8).reshape(n, L + 1)[:, :L]
+        return L, sizes, rows, np.ctypeslib.as_array(sr.dcal, shape=(n,))
+
 
 class PendingBatch:
     """A batch in flight (submit_batch): `.result()` waits for it and returns what fold_batch returns."""

@@ -93,6 +93,67 @@ def format_trajectory(sequence, trajectory):
     return "\n".join(out) + "\n"
 
 
+# ---- streaming writers: from the fold's flat result buffers to the reference's text formats, no
+# Structure objects, no per-row Python - what `rafft --traj` needs at max_stack = 1000 and what the batch front-end
+# needs for thousands of sequences.  `raw` is BatchResult.raw(i): (L, step sizes, rows uint8 (n, L), dcal int32 (n,)).
+
+def _rows_with_energy(rows, dcal, prefix=b"", with_pairs=False):
+    """bytes of the lines `<prefix><dot-bracket> <E:6.1f>[ <#pairs>]\n` for all rows at once (bin/rafft:64-68,77-78)"""
+    n, L = rows.shape
+    if n == 0:
+        return b""
+    en = np.char.mod("%6.1f", energies_from_dcal(dcal)).astype("S")
+    cols = [en]
+    if with_pairs:
+        cols.append(np.char.add(b" ", np.char.mod("%d", (rows == ord("(")).sum(axis=1)).astype("S")))
+    if any((np.char.str_len(c) != c.dtype.itemsize).any() for c in cols):
+        # columns of ragged width (an energy below -999.9, pair counts of different digit counts): join row by row
+        tail = cols[0] if len(cols) == 1 else np.char.add(cols[0], cols[1])
+        return b"".join(prefix + rows[k].tobytes() + b" " + tail[k] + b"\n" for k in range(n))
+    parts = []
+    if prefix:
+        parts.append(np.broadcast_to(np.frombuffer(prefix, dtype=np.uint8), (n, len(prefix))))
+    parts += [rows, np.full((n, 1), 32, np.uint8)]
+    parts += [np.frombuffer(c.tobytes(), dtype=np.uint8).reshape(n, c.dtype.itemsize) for c in cols]
+    parts.append(np.full((n, 1), 10, np.uint8))
+    return np.concatenate(parts, axis=1).tobytes()
+
+
+def write_result_text(fh, sequence, raw, traj=False, bench=False):
+    """One sequence in the reference's output formats (bin/rafft:59-79) straight from the flat result buffers:
+    final (sequence line + rows), --bench (seq len db E #pairs per row, no header), --traj (sequence line, then per
+    step `# ---------k----------` + rows).  `fh` is a binary file object."""
+    L, sizes, rows, dcal = raw
+    seqb = sequence.encode("ascii")
+    if traj:
+        fh.write(seqb + b"\n")
+        o = 0
+        for si, cnt in enumerate(sizes):
+            fh.write("# {:-^20}\n".format(si).encode("ascii"))
+            fh.write(_rows_with_energy(rows[o:o + cnt], dcal[o:o + cnt]))
+            o += cnt
+        return
+    last = sizes[-1] if sizes else 0
+    r, d = rows[len(rows) - last:], dcal[len(dcal) - last:]
+    if bench:
+        fh.write(_rows_with_energy(r, d, prefix=seqb + b" " + str(len(sequence)).encode() + b" ", with_pairs=True))
+    else:
+        fh.write(seqb + b"\n")
+        fh.write(_rows_with_energy(r, d))
+
+
+def write_sidecar_raw(path, sequence, raw):
+    """write_sidecar from the flat result buffers of a --traj fold"""
+    L, sizes, rows, dcal = raw
+    with open(path, "wb") as fh:
+        fh.write(_SIDECAR_MAGIC)
+        fh.write(np.array([1, L, len(sizes), len(dcal)], dtype="<u4").tobytes())
+        fh.write(sequence.encode("ascii"))
+        fh.write(np.asarray(sizes, dtype="<i4").tobytes())
+        fh.write(np.asarray(dcal, dtype="<i4").tobytes())
+        fh.write(np.ascontiguousarray(rows).tobytes())
+
+
 # ---- binary side-car of the fast-folding graph ---------------------
 # The `--traj` text (bin/rafft:73-79) prints energies with one decimal, so a reader of the text loses the
 # exact dcal values and has to re-parse every dot-bracket string.  The side-car keeps what the fold engine

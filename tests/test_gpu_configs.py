@@ -144,3 +144,34 @@ def test_gpu_cfg4_real_lpt_shard_ms200():
         assert not any(st) and got == [f[2] for f in part]
     bad = [k for k, w in zip(small, want) if beam_key(res[k]) != w]
     assert not bad, (len(bad), [len(seqs[k]) for k in bad[:10]])
+
+
+def test_gpu_cfg5_streamed_graph_text_and_sidecar(tmp_path):
+    """BASELINE configs[4] through the CLI: one 400-nt sequence, beam 1000, `--traj` text and binary side-car streamed
+    from the flat result buffers - equal to the oracle's trajectory formatted the reference's way, and
+    readable by rafft_kin's readers"""
+    rng = np.random.default_rng(400)
+    s = "".join(rng.choice(list("ACGU"), 400))
+    out, side = tmp_path / "ffg.out", tmp_path / "ffg.bin"
+    run_cli("-s", s, "-ms", "1000", "--traj", "-o", str(out), "--sidecar", str(side))
+    _, o = oracle.fold(s, 100, 1000, 1000, traj=True)
+    want = utils.format_trajectory(s, [[utils.Structure(x.str_struct, x.dcal) for x in st] for st in o])
+    assert out.read_text() == want
+    fp, sq = utils.read_sidecar(str(side))
+    assert sq == s and [[(x.str_struct, x.dcal) for x in st] for st in fp] == [[(x.str_struct, x.dcal) for x in st] for st in o]
+    steps, seq = utils.parse_rafft_output(str(out))
+    assert seq == s and [len(x) for x in steps] == [len(x) for x in o]
+
+
+def test_gpu_batch_front_end_csv_in_bench_rows_out(tmp_path, bench_rows):
+    """what benchmark_results/bench_fft.py does with a process pool - the benchmark CSV in, `--bench` rows
+    of n=100 ms=50 out - as ONE process and one GPU batch (every 12th row here; the full set is the cfg3 test)"""
+    rows = bench_rows[::12]
+    csvf = tmp_path / "bench.csv"
+    csvf.write_text("seq,struct,name\n" + "".join(f"{r['seq']},{r['known']},{r['name']}\n" for r in rows))
+    outf = tmp_path / "rows.txt"
+    run_cli("-sf", str(csvf), "--batch", "--bench", "-n", "100", "-ms", "50", "-o", str(outf))
+    want = fold_many([(r["seq"], 100, 50, 1000, False) for r in rows])
+    exp = "".join(f"{r['seq']} {len(r['seq'])} {db} {utils.Structure(db, d).energy:6.1f} {db.count('(')}\n"
+                  for r, beam in zip(rows, want) for db, d in beam)
+    assert outf.read_text() == exp

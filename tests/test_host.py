@@ -235,3 +235,70 @@ def test_kinetics_solvers_against_high_precision_truth():
         if name == "example_rafft_20.out":
             assert np.abs(ref - want).max() > 0.3                       # the reference's own late-time numbers are noise
             assert abs(want[-1].max() - 0.5316) < 1e-4                  # = README.org:146 (0.531)
+
+
+def _raw_of(traj_or_beam, traj):
+    steps = traj_or_beam if traj else [traj_or_beam]
+    rows = np.array([list(s.str_struct.encode()) for st in steps for s in st], dtype=np.uint8)
+    L = len(steps[0][0].str_struct)
+    return L, [len(st) for st in steps], rows.reshape(-1, L), np.array([s.dcal for st in steps for s in st], dtype=np.int32)
+
+
+def test_streaming_writers_equal_the_reference_formats(tmp_path):
+    """the text formats of bin/rafft:59-79 and the side-car written straight from flat result buffers
+    (no Structure objects) are byte-identical to the per-structure formatting"""
+    import argparse
+    rng = np.random.default_rng(9)
+    seqs = [EX, "".join(rng.choice(list("ACGU"), 150)), "GGGAAACCC"]
+    for s in seqs:
+        fin, traj = oracle.fold(s, 100, 12, 1000, traj=True)
+        for mode in ("final", "bench", "traj"):
+            args = argparse.Namespace(traj=mode == "traj", bench=mode == "bench")
+            res = (fin, traj) if mode == "traj" else fin
+            mine = [[utils.Structure(x.str_struct, x.dcal) for x in st] for st in traj]
+            want = cli.format_result(s, (mine[-1], mine) if mode == "traj" else mine[-1], args) + "\n"
+            buf = io.BytesIO()
+            utils.write_result_text(buf, s, _raw_of(traj if mode == "traj" else fin, mode == "traj"), traj=args.traj, bench=args.bench)
+            assert buf.getvalue().decode() == want, (mode, len(s))
+        side = tmp_path / "s.bin"
+        utils.write_sidecar_raw(str(side), s, _raw_of(traj, True))
+        fp, sq = utils.read_sidecar(str(side))
+        assert sq == s and [[(x.str_struct, x.dcal) for x in st] for st in fp] == [[(x.str_struct, x.dcal) for x in st] for st in traj]
+    # ragged columns: pair counts of one and two digits, an energy that needs seven characters
+    rows = np.array([list(b"((((((((((....))))))))))"), list(b"((((((((........))))))))"), list(b"........................")], dtype=np.uint8)
+    raw = (24, [3], rows, np.array([-100010, -1230, 0], dtype=np.int32))
+    buf = io.BytesIO()
+    utils.write_result_text(buf, "A" * 24, raw, bench=True)
+    st = [utils.Structure(bytes(r).decode(), d) for r, d in zip(rows, raw[3])]
+    assert buf.getvalue().decode() == cli.format_result("A" * 24, st, argparse.Namespace(traj=False, bench=True)) + "\n"
+    buf = io.BytesIO()
+    utils.write_result_text(buf, "A" * 24, raw)
+    assert buf.getvalue().decode() == cli.format_result("A" * 24, st, argparse.Namespace(traj=False, bench=False)) + "\n"
+
+
+def test_batch_front_end_reads_csv_fasta_and_lines(tmp_path):
+    """`rafft -sf FILE --batch --bench [-o OUT]` replaces benchmark_results/bench_fft.py:8-22 - CSV with the
+    reference's `seq` column (benchmark_cleaned_all_length.csv), FASTA records or one sequence per line in; one
+    `seq len structure energy #pairs` row per structure out"""
+    seqs = [EX, "GGGGAAAACCCC", "ACGUACGUACGUUUUACGUACGUACGU"]
+    csvf = tmp_path / "b.csv"
+    csvf.write_text("seq,struct,name\n" + "".join(f"{s.replace('U', 'T') if k == 1 else s},{'.' * len(s)},n{k}\n" for k, s in enumerate(seqs)))
+    outf = tmp_path / "rows.txt"
+    cli.main(["-sf", str(csvf), "--batch", "--bench", "-ms", "4", "-o", str(outf)], fold_batch=_oracle_fold_batch)
+    want = ""
+    for s in seqs:
+        for x in oracle.fold(s, 100, 4, 1000):
+            want += f"{s} {len(s)} {x.str_struct} {x.energy:6.1f} {x.str_struct.count('(')}\n"
+    assert outf.read_text() == want
+    fa = tmp_path / "b.fa"
+    fa.write_text("".join(f">r{k}\n{s[:20]}\n{s[20:]}\n" for k, s in enumerate(seqs)))
+    out2 = tmp_path / "rows2.txt"
+    cli.main(["-sf", str(fa), "--batch", "--bench", "-ms", "4", "-o", str(out2)], fold_batch=_oracle_fold_batch)
+    assert out2.read_text() == want
+    ln = tmp_path / "b.txt"
+    ln.write_text("\n".join(seqs) + "\n")
+    out3 = tmp_path / "rows3.txt"
+    cli.main(["-sf", str(ln), "--batch", "--bench", "-ms", "4", "-o", str(out3)], fold_batch=_oracle_fold_batch)
+    assert out3.read_text() == want
+    with pytest.raises(SystemExit):
+        cli.main(["-sf", str(csvf), "--batch", "--csv_column", "nope"], fold_batch=_oracle_fold_batch)
