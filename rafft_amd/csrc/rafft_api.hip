@@ -107,9 +107,12 @@ Ctx &g = *new Ctx();
 int ensure(Buf &b, size_t bytes)
 {
     if (bytes <= b.cap) return 0;
+    const auto t0_ = std::chrono::steady_clock::now();
+    const size_t old_cap = b.cap;
     if (b.p) { hipError_t e = hipFree(b.p); (void)e; b.p = nullptr; b.cap = 0; }
-    size_t want = bytes + bytes / 8 + 256;
+    size_t want = bytes + bytes / (old_cap ? 2 : 8) + 256;      // a buffer that had to grow once will grow again: leave room
     hipError_t e = hipMalloc(&b.p, want);
+    if (getenv("RAFFT_TRACE_ALLOC")) fprintf(stderr, "[rafft] device buffer -> %.1f MB in %.3f ms\n", (double)want / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count());
     if (e != hipSuccess) {
         b.p = nullptr;
         return fail(RAFFT_ERR_HIP, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
@@ -313,7 +316,10 @@ Caps plan_caps(size_t S, size_t sumL, const rafft_params &p, double est)
     c.db = (size_t)((double)sumL + (double)(c.st - S) * avgL * 1.5) + 4096;
     c.cand = std::max<size_t>(c.nd * (size_t)std::min(std::max(p.nb_mode, 1), 8) + 4096, (size_t)NSHARD * 16384);
     // accepted children per sequence ~ steps * min(max_branch, ...); regions double and old ones are dropped
-    double per_seq_seen = std::min(std::max(24.0 * est * ((double)B + (double)p.max_branch / 4.0), 16384.0), 16777216.0);
+    // (measured, ms 50, max_branch 1000, regions abandoned by rehashing included: the benchmark set's bulk uses 4.6 x est x
+    //  (B + max_branch / 4) slots per sequence, its two 2.9-knt sequences 11.6 x.  A factor of 24 used to reserve 1 MB per
+    //  sequence - 12 GB for a merged wave of five batches, and a hipMalloc of that size now and then took seconds.)
+    double per_seq_seen = std::min(std::max(14.0 * est * ((double)B + (double)p.max_branch / 4.0), 16384.0), 16777216.0);
     c.seen = S * (size_t)SEEN0 + (size_t)((double)S * per_seq_seen);
     c.trec = p.traj ? S * (size_t)(est * 3 + 16) : S + 16;
     c.tsid = c.trec * B + 16;
@@ -336,28 +342,34 @@ Caps plan_caps(size_t S, size_t sumL, const rafft_params &p, double est)
     return c;
 }
 
-struct SeqIn { const char *s; int len; int idx; };
+struct SeqIn { const char *s; int len; int idx; int bi; };   // bi: which member batch of the job the sequence belongs to
 
 struct HostOut {   // owner of a rafft_result
     std::vector<rafft_seq_result> seq;
     std::vector<std::vector<int>> step_size, step_off;
     std::vector<const char *> db_ptr;       // rows live in pinned chunks (one per wave): the D2H copy lands
     std::vector<const int *> dcal_ptr;      // directly in the memory the caller reads
-    std::vector<PinBuf> chunks;
+    std::vector<std::shared_ptr<struct PinChunk>> chunks;   // a chunk may hold rows of several batches folded as one wave
     rafft_result res;
 };
 
-// small pool of pinned host buffers, recycled across calls (hipHostMalloc is slow)
+// Pool of pinned host buffers, recycled across calls: hipHostMalloc / hipHostFree cost milliseconds for a result chunk
+// of tens of MB and stall the queues while they run (measured: a steady stream of them turned 10 ms batches into
+// 45-70 ms ones).  Sizes are rounded up to powers of two so that chunks of merged waves of different sizes reuse each
+// other's buffers; the pool gives memory back only above 4 GB.
 PinBuf pin_acquire(size_t bytes)
 {
     std::lock_guard<std::mutex> lk(g.pin_mu);
+    size_t want = 256 * 1024;
+    while (want < bytes) want <<= 1;
     int best = -1;
     for (size_t i = 0; i < g.pin_free.size(); i++)
-        if (g.pin_free[i].cap >= bytes && (best < 0 || g.pin_free[i].cap < g.pin_free[best].cap)) best = (int)i;
+        if (g.pin_free[i].cap >= bytes && g.pin_free[i].cap <= 4 * want && (best < 0 || g.pin_free[i].cap < g.pin_free[best].cap)) best = (int)i;
     if (best >= 0) { PinBuf b = g.pin_free[best]; g.pin_free.erase(g.pin_free.begin() + best); return b; }
     PinBuf b;
-    size_t want = bytes + bytes / 4 + 4096;
+    const auto t0_ = std::chrono::steady_clock::now();
     if (hipHostMalloc(&b.p, want, hipHostMallocDefault) != hipSuccess) { b.p = nullptr; return b; }
+    if (getenv("RAFFT_TRACE_ALLOC")) fprintf(stderr, "[rafft] pinned chunk %.1f MB in %.3f ms (pool %zu)\n", (double)want / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count(), g.pin_free.size());
     b.cap = want;
     return b;
 }
@@ -365,11 +377,29 @@ void pin_release(PinBuf b)
 {
     if (!b.p) return;
     std::lock_guard<std::mutex> lk(g.pin_mu);
-    if (g.pin_free.size() < 8) g.pin_free.push_back(b);
-    else { hipError_t e = hipHostFree(b.p); (void)e; }
+    size_t held = 0;
+    for (auto &x : g.pin_free) held += x.cap;
+    if (g.pin_free.size() < 64 && held + b.cap <= ((size_t)4 << 30)) g.pin_free.push_back(b);
+    else {
+        const auto t0_ = std::chrono::steady_clock::now();
+        hipError_t e = hipHostFree(b.p); (void)e;
+        if (getenv("RAFFT_TRACE_ALLOC")) fprintf(stderr, "[rafft] pinned chunk freed in %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count());
+    }
 }
 
-struct Job { std::vector<SeqIn> seqs; double est; int depth; };
+// a pinned result chunk, returned to the pool when the last result that points into it is freed
+struct PinChunk {
+    PinBuf b;
+    explicit PinChunk(PinBuf x) : b(x) {}
+    ~PinChunk() { pin_release(b); }
+    PinChunk(const PinChunk &) = delete;
+    PinChunk &operator=(const PinChunk &) = delete;
+};
+
+struct Batch;
+// One wave's worth of work.  `members`: the batches its sequences come from - queued jobs with identical parameters
+// are merged (continuous batching), so one wave may serve several batches; seqs[i].bi indexes this list.
+struct Job { std::vector<SeqIn> seqs; double est; int depth; std::vector<std::shared_ptr<Batch>> members; bool no_merge = false; };
 
 // One rafft_fold_submit(): its sequences (copied), its result under construction, its jobs (lane 0: the long tail of
 // the batch, lane 1: the bulk - see rafft_fold_submit) and what the scheduler needs to finish it.
@@ -378,8 +408,8 @@ struct Batch {
     int n_seq = 0;
     std::vector<char> seqbuf;                 // the caller's sequences, copied at submit
     HostOut *ho = nullptr;
-    std::deque<Job> lane[2];
-    int running = 0;                          // waves of this batch on a workspace right now
+    std::deque<Job> lane[2];                  // as submitted; the scheduler moves them to its own queues
+    int pending = 0;                          // jobs (queued or running) that still hold sequences of this batch
     int rc = 0;
     std::string err;
     std::vector<Span> spans;
@@ -404,8 +434,8 @@ struct Wave {
     rafft_params p;
     std::vector<SeqIn> seqs;
     double est;
-    Batch &bt;
-    HostOut &out;
+    std::vector<std::shared_ptr<Batch>> members;   // whose sequences this wave folds (seqs[i].bi)
+    Batch &bt;                                      // the first of them: carries the wave's timing spans and statistics
     std::vector<Span> &spans;
     const SeamIn *seam;
     size_t S = 0, sumL = 0, B = 0, bs_lds[2] = {0, 0};
@@ -427,8 +457,9 @@ struct Wave {
     std::chrono::steady_clock::time_point tw0, tw1;
     double ms_setup = 0, ms_issue = 0, ms_after = 0;   // host time inside issue_step / after_beam (trace)
 
-    Wave(Workspace &w, Batch &b, std::vector<SeqIn> s, double e, const SeamIn *sm = nullptr)
-        : g(w), p(b.p), seqs(std::move(s)), est(e), bt(b), out(*b.ho), spans(b.spans), seam(sm) {}
+    Wave(Workspace &w, std::vector<std::shared_ptr<Batch>> m, std::vector<SeqIn> s, double e, const SeamIn *sm = nullptr)
+        : g(w), p(m[0]->p), seqs(std::move(s)), est(e), members(std::move(m)), bt(*members[0]), spans(members[0]->spans), seam(sm) {}
+    HostOut &out_of(int local_seq) { return *members[seqs[local_seq].bi]->ho; }
 
     double since(std::chrono::steady_clock::time_point t) const
     {
@@ -696,7 +727,10 @@ int Wave::emit_rows(size_t first, size_t count, bool early, double *t_gather)
     PinBuf chunk;
     chunk = pin_acquire(dcal_off + nrows * 4 + 64);
     if (!chunk.p) return fail(RAFFT_ERR_HIP, "hipHostMalloc failed for the result buffer");
-    out.chunks.push_back(chunk);
+    {
+        auto shared = std::make_shared<PinChunk>(chunk);
+        for (auto &m : members) m->ho->chunks.push_back(shared);
+    }
     char *all_db = (char *)chunk.p;
     int *all_dcal = (int *)((char *)chunk.p + dcal_off);
     if (int rc = ensure(b_rec, recs.size() * sizeof(OutRec))) return rc;
@@ -721,6 +755,7 @@ int Wave::emit_rows(size_t first, size_t count, bool early, double *t_gather)
         size_t r1 = r0;
         while (r1 < recs.size() && trec[r1].x == i) r1++;
         const int gi = seqs[i].idx;
+        HostOut &out = out_of(i);
         auto &ss = out.step_size[gi];
         auto &so = out.step_off[gi];
         ss.resize(r1 - r0); so.resize(r1 - r0);
@@ -845,7 +880,7 @@ int Wave::finish()
 // rafft_expand_node: one region of one given structure through the expand kernel
 int run_seam(Batch &bt, const std::vector<SeqIn> &one, const SeamIn &sm)
 {
-    Wave w(g.ws[0], bt, one, 4.0, &sm);
+    Wave w(g.ws[0], {std::shared_ptr<Batch>(&bt, [](Batch *) {})}, one, 4.0, &sm);
     if (int rc = w.setup()) return rc;
     Workspace &W = g.ws[0];
     // overwrite the root region of sequence 0 with the given loop of the given structure
@@ -882,12 +917,25 @@ void free_out(HostOut *o);
 //     calls; holding the next bulk wave back until the running one has turned light - RAFFT_ADMIT_BELOW=<structures
 //     per step> - was 2-4 % slower);
 //   * a job that does not fit the HBM still free is split (or waits for running waves to release theirs).
-struct Slot { std::unique_ptr<Wave> wave; std::shared_ptr<Batch> owner; Job job; int lane = 0; };
+struct Slot { std::unique_ptr<Wave> wave; Job job; int lane = 0; };
 
 static unsigned admit_below()
 {
     static const unsigned v = getenv("RAFFT_ADMIT_BELOW") ? (unsigned)atoi(getenv("RAFFT_ADMIT_BELOW")) : 0u;
-    return v ? v : 0x7fffffffu;                 // default: no wave is ever held back
+    return v ? v : 128u * (unsigned)g.n_cu;     // = the step size below which the one-wavefront expand class is merged away
+}
+// sequences one merged wave may hold (a wave of the whole benchmark set four times over folds 25 % faster per sequence
+// than the set alone: fewer, fuller launches; beyond that nothing is gained and the arenas only grow)
+static size_t merge_cap()
+{
+    static const size_t v = getenv("RAFFT_MERGE_SEQS") ? (size_t)atol(getenv("RAFFT_MERGE_SEQS")) : 9600;
+    return v;
+}
+
+static bool same_params(const rafft_params &a, const rafft_params &b)
+{
+    return a.nb_mode == b.nb_mode && a.max_stack == b.max_stack && a.max_branch == b.max_branch && a.min_hp == b.min_hp &&
+           a.min_nrj == b.min_nrj && a.traj == b.traj && a.temp == b.temp && a.gc_wei == b.gc_wei && a.au_wei == b.au_wei && a.gu_wei == b.gu_wei;
 }
 
 static void finalize_batch(const std::shared_ptr<Batch> &bp)
@@ -952,13 +1000,39 @@ static void scheduler_main()
 {
     { hipError_t e_ = hipSetDevice(g.device); (void)e_; }
     Slot slot[MAX_PIPES];
-    std::deque<std::shared_ptr<Batch>> active;
-    const int max_waves = std::max(1, std::min(getenv("RAFFT_MAX_WAVES") ? atoi(getenv("RAFFT_MAX_WAVES")) : MAX_PIPES, MAX_PIPES));
+    std::deque<Job> queue[2];                 // lane 0: long-tail jobs, lane 1: bulk jobs; submission order
+    int n_active_batches = 0;
+    // waves in flight: two (typically the long-tail wave of one batch beside a bulk wave) - more only split the work
+    // into smaller, less efficient waves (measured with 6-12 batches in flight: 2 waves 9.5-9.9 ms per benchmark batch, 3-4
+    // waves 10.1-10.3 ms) and multiply the HBM held by workspaces
+    const int max_waves = std::max(1, std::min(getenv("RAFFT_MAX_WAVES") ? atoi(getenv("RAFFT_MAX_WAVES")) : 2, MAX_PIPES));
+    // a member batch is finished when its last job is: finalise it
+    auto release = [&](Job &job, int rc, const std::string &err) {
+        for (auto &m : job.members) {
+            if (rc && !m->rc) { m->rc = rc; m->err = err; }
+            if (--m->pending == 0) { finalize_batch(m); n_active_batches--; }
+        }
+        job.members.clear();
+    };
     for (;;) {
         {
             std::unique_lock<std::mutex> lk(g.qmu);
-            if (active.empty() && g.submitted.empty()) g.qcv_sched.wait(lk, [] { return !g.submitted.empty(); });
-            while (!g.submitted.empty()) { active.push_back(g.submitted.front()); g.submitted.pop_front(); }
+            if (n_active_batches == 0 && g.submitted.empty()) g.qcv_sched.wait(lk, [] { return !g.submitted.empty(); });
+            while (!g.submitted.empty()) {
+                std::shared_ptr<Batch> bp = g.submitted.front();
+                g.submitted.pop_front();
+                n_active_batches++;
+                bp->pending = 1;                                  // (held while its jobs are being queued)
+                for (int ln = 0; ln < 2; ln++)
+                    for (Job &j : bp->lane[ln]) {
+                        if (j.seqs.empty()) continue;
+                        j.members.assign(1, bp);
+                        bp->pending++;
+                        queue[ln].push_back(std::move(j));
+                    }
+                bp->lane[0].clear(); bp->lane[1].clear();
+                if (--bp->pending == 0) { lk.unlock(); finalize_batch(bp); n_active_batches--; lk.lock(); }   // nothing foldable in it
+            }
         }
         bool progressed = false;
         // ---- advance the running waves
@@ -966,92 +1040,97 @@ static void scheduler_main()
             Slot &sl = slot[i];
             if (!sl.wave || !sl.wave->ready()) continue;
             progressed = true;
-            Batch &b = *sl.owner;
             int rc = sl.wave->after_beam();
             if (sl.wave->finished) {
                 rc = sl.wave->result;
-                if (rc == RAFFT_ERR_CAPACITY && !b.rc) {
-                    if (sl.job.depth >= 12) { b.rc = RAFFT_ERR_CAPACITY; b.err = "HBM arena overflow after 12 regrowths (bits " + std::to_string(sl.wave->ovf) + ")"; }
-                    else {
-                        b.stats.n_regrows++;
-                        b.lane[sl.lane].push_front(Job{std::move(sl.job.seqs), sl.job.est * (sl.job.depth >= 2 ? 4.0 : 2.0), sl.job.depth + 1});
+                if (rc == RAFFT_ERR_CAPACITY) {
+                    if (sl.job.depth >= 12)
+                        release(sl.job, RAFFT_ERR_CAPACITY, "HBM arena overflow after 12 regrowths (bits " + std::to_string(sl.wave->ovf) + ")");
+                    else {                                   // re-run with larger arenas, ahead of everything queued
+                        sl.job.members[0]->stats.n_regrows++;
+                        sl.job.est *= (sl.job.depth >= 2 ? 4.0 : 2.0);
+                        sl.job.depth++;
+                        queue[sl.lane].push_front(std::move(sl.job));
                     }
-                } else if (rc && !b.rc) { b.rc = rc; b.err = g_err; }
-                sl.wave.reset(); sl.owner.reset();
-                b.running--;
+                } else
+                    release(sl.job, rc, g_err);
+                sl.wave.reset();
             } else if (rc) {
-                if (!b.rc) { b.rc = rc; b.err = g_err; }
                 { hipError_t e_ = hipDeviceSynchronize(); (void)e_; }
-                sl.wave.reset(); sl.owner.reset();
-                b.running--;
+                release(sl.job, rc, g_err);
+                sl.wave.reset();
             }
         }
-        // ---- admit queued jobs, batches in submission order, the long-tail lane of a batch before its bulk
+        // ---- admit queued jobs: the long-tail lane first (light from the start), then the bulk lane
         int n_running = 0;
         bool heavy_running = false;
         for (int i = 0; i < MAX_PIPES; i++) if (slot[i].wave) { n_running++; heavy_running = heavy_running || slot[i].wave->heavy(admit_below()); }
-        for (auto &bp : active) {
-            Batch &b = *bp;
-            if (b.rc) { b.lane[0].clear(); b.lane[1].clear(); continue; }
-            for (int ln = 0; ln < 2; ln++) {
-                while (!b.lane[ln].empty() && n_running < max_waves) {
-                    Job &job = b.lane[ln].front();
-                    if (job.seqs.empty()) { b.lane[ln].pop_front(); continue; }
-                    const bool job_heavy = job.seqs.size() >= 256;
-                    if (job_heavy && heavy_running) break;
-                    int w = -1;                                       // a free workspace, this lane's parity first
-                    for (int k = 0; k < MAX_PIPES && w < 0; k++) if (!slot[k].wave && (k & 1) == ln) w = k;
-                    for (int k = 0; k < MAX_PIPES && w < 0; k++) if (!slot[k].wave) w = k;
-                    if (w < 0) break;
-                    size_t sl_ = 0;
-                    for (auto &sq : job.seqs) sl_ += sq.len;
-                    const Caps cc = plan_caps(job.seqs.size(), sl_, b.p, job.est);
-                    size_t others = 0;
-                    for (int k = 0; k < MAX_PIPES; k++) if (k != w) others += g.ws[k].bytes();
-                    const size_t budget = (size_t)((double)g.hbm_total * 0.55 / 2.0);
-                    const bool fits_now = std::max(cc.bytes, g.ws[w].bytes()) + others <= (size_t)((double)g.hbm_total * 0.85);
-                    if ((cc.bytes > budget || (!fits_now && n_running == 0)) && job.seqs.size() > 1) {
-                        const size_t h = job.seqs.size() / 2;          // too big for one wave: two jobs, one after the other
-                        Job a{std::vector<SeqIn>(job.seqs.begin(), job.seqs.begin() + h), job.est, job.depth};
-                        Job c{std::vector<SeqIn>(job.seqs.begin() + h, job.seqs.end()), job.est, job.depth};
-                        b.lane[ln].pop_front();
-                        b.lane[ln].push_front(std::move(c));
-                        b.lane[ln].push_front(std::move(a));
-                        progressed = true;
-                        continue;
-                    }
-                    if (!fits_now && n_running > 0) break;            // wait for running waves to finish (their workspaces stay, but...)
-                    Slot &sl = slot[w];
-                    sl.job = std::move(job);
-                    b.lane[ln].pop_front();
-                    sl.lane = ln; sl.owner = bp;
-                    int rc = init_ws(g.ws[w]);
-                    if (!rc) {
-                        sl.wave.reset(new Wave(g.ws[w], b, sl.job.seqs, sl.job.est));
-                        sl.wave->depth = sl.job.depth;
-                        rc = sl.wave->setup();
-                        if (!rc) rc = sl.wave->issue_step();
-                    }
-                    progressed = true;
-                    if (rc) {
-                        if (!b.rc) { b.rc = rc; b.err = g_err; }
-                        { hipError_t e_ = hipDeviceSynchronize(); (void)e_; }
-                        sl.wave.reset(); sl.owner.reset();
+        for (int ln = 0; ln < 2; ln++) {
+            while (!queue[ln].empty() && n_running < max_waves) {
+                Job &front = queue[ln].front();
+                bool failed = false;                              // a member already failed elsewhere: do not fold for it
+                for (auto &m : front.members) failed = failed || m->rc != 0;
+                if (failed) { Job j = std::move(front); queue[ln].pop_front(); release(j, 0, ""); progressed = true; continue; }
+                const bool job_heavy = front.seqs.size() >= 256;
+                if (job_heavy && heavy_running) break;
+                int w = -1;                                       // a free workspace, this lane's parity first
+                for (int k = 0; k < MAX_PIPES && w < 0; k++) if (!slot[k].wave && (k & 1) == ln) w = k;
+                for (int k = 0; k < MAX_PIPES && w < 0; k++) if (!slot[k].wave) w = k;
+                if (w < 0) break;
+                // continuous batching: queued jobs with the same parameters join this one (first regrowths stay alone)
+                Job job = std::move(front);
+                queue[ln].pop_front();
+                while (job.depth == 0 && !job.no_merge && !queue[ln].empty()) {
+                    Job &nx = queue[ln].front();
+                    bool nx_failed = false;
+                    for (auto &m : nx.members) nx_failed = nx_failed || m->rc != 0;
+                    if (nx.depth != 0 || nx.no_merge || nx_failed || !same_params(nx.members[0]->p, job.members[0]->p) ||
+                        job.seqs.size() + nx.seqs.size() > merge_cap())
                         break;
-                    }
-                    b.running++; n_running++;
-                    heavy_running = heavy_running || job_heavy;
+                    const int off = (int)job.members.size();
+                    for (SeqIn sq : nx.seqs) { sq.bi += off; job.seqs.push_back(sq); }
+                    for (auto &m : nx.members) job.members.push_back(m);
+                    job.est = std::max(job.est, nx.est);
+                    queue[ln].pop_front();
                 }
-            }
-        }
-        // ---- batches with nothing queued and nothing running are complete
-        for (auto it = active.begin(); it != active.end();) {
-            Batch &b = **it;
-            if (b.running == 0 && ((b.lane[0].empty() && b.lane[1].empty()) || b.rc)) {
-                finalize_batch(*it);
-                it = active.erase(it);
+                size_t sl_ = 0;
+                for (auto &sq : job.seqs) sl_ += sq.len;
+                const Caps cc = plan_caps(job.seqs.size(), sl_, job.members[0]->p, job.est);
+                size_t others = 0;
+                for (int k = 0; k < MAX_PIPES; k++) if (k != w) others += g.ws[k].bytes();
+                const size_t budget = (size_t)((double)g.hbm_total * 0.55 / 2.0);
+                const bool fits_now = std::max(cc.bytes, g.ws[w].bytes()) + others <= (size_t)((double)g.hbm_total * 0.85);
+                if ((cc.bytes > budget || (!fits_now && n_running == 0)) && job.seqs.size() > 1) {
+                    const size_t h = job.seqs.size() / 2;          // too big for one wave: two jobs, one after the other
+                    Job a{std::vector<SeqIn>(job.seqs.begin(), job.seqs.begin() + h), job.est, job.depth, job.members, true};
+                    Job c{std::vector<SeqIn>(job.seqs.begin() + h, job.seqs.end()), job.est, job.depth, job.members, true};
+                    for (auto &m : job.members) m->pending++;      // one job became two (halves of a split are not merged again)
+                    queue[ln].push_front(std::move(c));
+                    queue[ln].push_front(std::move(a));
+                    progressed = true;
+                    continue;
+                }
+                if (!fits_now && n_running > 0) { queue[ln].push_front(std::move(job)); break; }   // wait for running waves to finish
+                Slot &sl = slot[w];
+                sl.job = std::move(job);
+                sl.lane = ln;
+                int rc = init_ws(g.ws[w]);
+                if (!rc) {
+                    sl.wave.reset(new Wave(g.ws[w], sl.job.members, sl.job.seqs, sl.job.est));
+                    sl.wave->depth = sl.job.depth;
+                    rc = sl.wave->setup();
+                    if (!rc) rc = sl.wave->issue_step();
+                }
                 progressed = true;
-            } else ++it;
+                if (rc) {
+                    { hipError_t e_ = hipDeviceSynchronize(); (void)e_; }
+                    release(sl.job, rc, g_err);
+                    sl.wave.reset();
+                    continue;
+                }
+                n_running++;
+                heavy_running = heavy_running || (job_heavy && sl.wave->heavy(admit_below()));
+            }
         }
         if (!progressed) std::this_thread::yield();
     }
@@ -1071,11 +1150,7 @@ static void drain()
     g.qcv_done.wait(lk, [] { return g.n_inflight == 0; });
 }
 
-void free_out(HostOut *o)
-{
-    for (auto &c : o->chunks) pin_release(c);
-    delete o;
-}
+void free_out(HostOut *o) { delete o; }      // (its pinned chunks go back to the pool with their last reference)
 
 } // namespace
 
@@ -1135,7 +1210,7 @@ static int submit_locked(const rafft_params *p, int n_seq, const char *const *se
         for (int x = 0; x < L[i]; x++) bad |= kBaseCode[(unsigned char)dst[x]];
         if (bad & 8) { sr.status = RAFFT_ERR_BAD_CHAR; continue; }
         if (L[i] > RAFFT_MAX_LEN) { sr.status = RAFFT_ERR_TOO_LONG; continue; }
-        good.push_back({dst, L[i], i});
+        good.push_back({dst, L[i], i, 0});
     }
     // ---- lanes.  Folds are independent, so how the batch is cut cannot change any result.  The number of
     // folding steps of a wave is set by its longest sequence, and the steps that only the long ones still need
@@ -1465,7 +1540,7 @@ int rafft_expand_node(const rafft_params *p, const char *seq, const char *db, co
     dbg.ddcal = (int *)b; b += 4 * K; dbg.kept = (int *)b; b += 4 * K;
     b = (char *)(((uintptr_t)b + 15) & ~(uintptr_t)15);
     dbg.corval = (double *)b; b += 8 * K; dbg.score = (double *)b;
-    std::vector<SeqIn> one{{seq, L, 0}};
+    std::vector<SeqIn> one{{seq, L, 0, 0}};
     HostOut ho;
     ho.seq.resize(1); ho.step_size.resize(1); ho.step_off.resize(1); ho.dcal_ptr.assign(1, nullptr); ho.db_ptr.assign(1, nullptr);
     Batch bt;                                  // a private batch: the scheduler is idle (drained above) and g.mu is held

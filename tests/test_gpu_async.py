@@ -92,3 +92,32 @@ def test_gpu_unwaited_job_is_released():
     pb = rafft_amd.submit_batch(["GGGGAAAACCCC"] * 4, max_stack=3)
     del pb                                   # PendingBatch.__del__ waits and frees
     assert rafft_amd.fold("GGGGAAAACCCC")[0].str_struct == "((((....))))"
+
+
+def test_gpu_queued_batches_with_equal_parameters_are_merged_and_split_back(bench_rows):
+    """continuous batching: batches queued behind a running wave are folded as ONE wave when their parameters are identical;
+    every batch still gets exactly its own result (rows live in pinned chunks shared between the merged batches), bad
+    sequences stay per batch, and the statistics of the merged wave are counted once"""
+    rng = np.random.default_rng(23)
+    base = [r["seq"] for r in bench_rows[::4]]
+    variants = [base, base[::-1], base[:200] + ["ACGT", ""] + base[200:], ["".join(rng.choice(list("ACGU"), int(n))) for n in rng.integers(40, 300, size=300)],
+                base[100:400], base]
+    kw = dict(nb_mode=100, max_stack=30, max_branch=1000, traj=False)
+    want = [key(rafft_amd.fold_batch(v, raise_errors=False, **kw), False) if "ACGT" not in v else None for v in variants]
+    single_structs = []
+    for v in variants:
+        rafft_amd.fold_batch(v, raise_errors=False, **kw)
+        single_structs.append(rafft_amd.last_stats()["n_structs"])
+    for rnd_ in range(3):
+        pend = [rafft_amd.submit_batch(v, raise_errors=False, **kw) for v in variants]
+        total = 0
+        for i, pb in enumerate(pend):
+            res = pb.result()
+            total += rafft_amd.last_stats()["n_structs"]
+            if want[i] is None:
+                assert res[200] is None and res[201] is None and res.status(200) == _native.ERR_BAD_CHAR and res.status(201) == _native.ERR_EMPTY
+                ok = [k for k in range(len(variants[i])) if k not in (200, 201)]
+                assert [[(s.str_struct, s.dcal) for s in res[k]] for k in ok] == key(rafft_amd.fold_batch([variants[i][k] for k in ok], **kw), False)
+            else:
+                assert key(res, False) == want[i], (rnd_, i)
+        assert total == sum(single_structs)          # every wave's work is attributed to exactly one of its batches

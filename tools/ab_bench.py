@@ -23,9 +23,12 @@ def wait(job):
     N.check(lib.rafft_fold_wait(job, C.byref(res)))
     lib.rafft_free_result(res)
     st = N.Stats(); lib.rafft_get_stats(C.byref(st))
+    global regrows, worst
+    regrows += st.n_regrows; worst = max(worst, st.ms_total)
     return st.ms_expand
 
 ts, ex = [], []
+regrows, worst = 0, 0.0
 for it in range(iters):
     t = time.perf_counter()
     e = wait(submit())
@@ -40,4 +43,4 @@ for rnd in range(2):
     while q: wait(q.pop(0))
     tp = (time.perf_counter() - t) / iters * 1e3
 print(f"sequential median {statistics.median(ts):.3f} ms (min {min(ts):.3f}); pipelined x{depth} {tp:.3f} ms/batch = {n / tp * 1e3:.0f} seq/s; "
-      f"expand<64> {statistics.median(ex):.3f} ms/batch", flush=True)
+      f"expand<64> {statistics.median(ex):.3f} ms/batch; regrows {regrows}, slowest batch {worst:.1f} ms", flush=True)

@@ -1,12 +1,8 @@
 #!/bin/bash
-run() { echo -n "$* : "; env "$@" timeout -k 10 120 python tools/ab_bench.py 20 || exit 1; }
-run X=0
-run RAFFT_CLS1_P=256
-run RAFFT_CLS1_P=256 RAFFT_C1_PER_CU=12
-run RAFFT_CLS1_P=256 RAFFT_C1_PER_CU=12 RAFFT_ADMIT_BELOW=1000000
-run RAFFT_CLS1_P=256 RAFFT_C1_PER_CU=12 RAFFT_ADMIT_BELOW=1000000 AB_DEPTH=3
-run RAFFT_CLS1_P=256 RAFFT_C1_PER_CU=8 RAFFT_ADMIT_BELOW=1000000 AB_DEPTH=3
-run RAFFT_CLS1_P=256 RAFFT_C1_PER_CU=16 RAFFT_ADMIT_BELOW=1000000 AB_DEPTH=3
-run RAFFT_ADMIT_BELOW=1000000 AB_DEPTH=3
-run RAFFT_ADMIT_BELOW=1000000 AB_DEPTH=4
-run RAFFT_C1_PER_CU=8 RAFFT_ADMIT_BELOW=1000000 AB_DEPTH=3
+run() { echo -n "$* : "; env "$@" timeout -k 10 120 python tools/ab_bench.py 40 2>/dev/null | sed 's/sequential.*; pipelined/pipelined/' || exit 1; }
+for rep in 1 2 3; do
+run AB_DEPTH=1
+run AB_DEPTH=4
+run AB_DEPTH=8
+run AB_DEPTH=12
+done

@@ -1,0 +1,90 @@
+"""rocprofv3 passes of tools/profile_r02.sh -> profiles/: kernel statistics of the timed loop, per-launch HBM
+traffic (FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 correction as MI355X_MICROARCH.md prescribes) and the
+instruction-issue roofline of every kernel from the SQ counters.
+
+issue roofline: wave-instructions issued (VALU + SALU + LDS + SMEM + VMEM + branch) / (CUs * 4 SIMDs * clock * kernel
+time) - the fraction of SIMD issue slots (one wave-instruction per SIMD per cycle) the kernel fills; beside it the
+VALU-only figure priced at 2 cycles per wave64 VALU instruction on the SIMD-32 (MI355X_MICROARCH.md), and the shares
+of wave cycles spent active / parked (s_waitcnt) / issue-stalled.
+
+usage: python tools/pmc_summary.py gpurun_out/r02_prof profiles r02"""
+import collections, csv, json, os, shutil, sys
+
+N_CU, SIMD_PER_CU = 256, 4
+
+
+def counters(dirname):
+    f = os.path.join(dirname, "p_counter_collection.csv")
+    tot = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.defaultdict(set)
+    dur = collections.defaultdict(float)
+    seen = set()
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        disp[k].add(r["Dispatch_Id"])
+        if r["Dispatch_Id"] not in seen:
+            seen.add(r["Dispatch_Id"])
+            dur[k] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    return tot, {k: len(v) for k, v in disp.items()}, dur
+
+
+def main(src, dst, tag):
+    shutil.copy(os.path.join(src, "trace", "t_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
+    bench = json.load(open(os.path.join(src, "trace_bench.json")))
+    json.dump(bench, open(os.path.join(dst, f"{tag}_trace_bench.json"), "w"), indent=1)
+    fe, nf, _ = counters(os.path.join(src, "pmc_fetch"))
+    wr, nw, _ = counters(os.path.join(src, "pmc_write"))
+    sq, ns, dur = counters(os.path.join(src, "pmc_sq"))
+    sq2, ns2, dur2 = ({}, {}, {})
+    if os.path.exists(os.path.join(src, "pmc_sq2", "p_counter_collection.csv")):
+        sq2, ns2, dur2 = counters(os.path.join(src, "pmc_sq2"))
+    clk_mhz = None
+    for r in csv.DictReader(open(os.path.join(src, "trace", "t_agent_info.csv"))):
+        if r.get("Agent_Type", "").upper() == "GPU" or r.get("Name", "").startswith("gfx"):
+            for key in ("Max_Engine_Clk_Fcompute", "Max_Engine_Clk_FCompute", "Max_Clock_Frequency"):
+                if r.get(key):
+                    clk_mhz = float(r[key]); break
+    clk = (clk_mhz or 2400.0) * 1e6
+    kernels, issue = {}, {}
+    for k in sorted(set(fe) | set(wr)):
+        f = fe[k]["FETCH_SIZE"] / max(nf.get(k, 1), 1) if k in fe else 0.0
+        w = wr[k]["WRITE_SIZE"] / max(nw.get(k, 1), 1) if k in wr else 0.0
+        kernels[k] = {"launches_profiled": nf.get(k, 0), "fetch_bytes_per_launch": round(2 * f * 1024), "write_bytes_per_launch": round(w * 1024),
+                      "hbm_bytes_per_launch": round((2 * f + w) * 1024), "raw_FETCH_SIZE_KiB": round(f, 3), "raw_WRITE_SIZE_KiB": round(w, 3)}
+    for k, c in sq.items():
+        t = dur[k] * 1e-9
+        if t <= 0 or c["SQ_WAVE_CYCLES"] <= 0:
+            continue
+        extra = sq2.get(k, {})
+        scale = (dur[k] / dur2[k]) if k in dur2 and dur2[k] > 0 else 1.0      # the second SQ pass is another run of the same work
+        n_inst = c["SQ_INSTS_VALU"] + c["SQ_INSTS_SALU"] + c["SQ_INSTS_LDS"] + scale * (
+            extra.get("SQ_INSTS_SMEM", 0) + extra.get("SQ_INSTS_VMEM_RD", 0) + extra.get("SQ_INSTS_VMEM_WR", 0))
+        slots = N_CU * SIMD_PER_CU * clk * t
+        issue[k] = {"launches_profiled": ns[k], "kernel_seconds": round(t, 6),
+                    "wave_instructions": int(n_inst), "issue_frac": round(n_inst / slots, 4),
+                    "valu_busy_frac_at_2_cycles_per_wave64_op": round(2 * c["SQ_INSTS_VALU"] / slots, 4),
+                    "insts": {n: int(c[n]) for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS")},
+                    "insts_second_pass": {n: int(v) for n, v in extra.items() if n.startswith("SQ_INSTS")},
+                    "wave_cycle_shares": {"active": round(c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], 4),
+                                          "parked_waitcnt_or_barrier": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4),
+                                          "issue_stalled": round(c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], 4)},
+                    # SQ_WAVE_CYCLES (like SQ_BUSY_CYCLES and the SQ_WAIT_* counters) ticks once per 4 cycles
+                    "mean_waves_resident_per_simd": round(4.0 * c["SQ_WAVE_CYCLES"] / slots, 3)}
+    ex = next((k for k in issue if k.startswith("void expand_kernel<64")), None)
+    out = {"source": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_* | SQ_* second set), each in its own run, "
+                     "bench.py --steps 3 --warmup 1 --no-extras with synchronous calls (BENCH_DEPTH=1); tools/profile_r02.sh",
+           "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE halving, MI355X_MICROARCH.md)",
+           "clock_hz_used": clk, "kernels": kernels, "issue": issue,
+           "issue_roofline": dict(kernel=ex, **{k: issue[ex][k] for k in ("issue_frac", "valu_busy_frac_at_2_cycles_per_wave64_op",
+                                                                             "wave_cycle_shares", "mean_waves_resident_per_simd")}) if ex else None}
+    json.dump(out, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
+    for k, v in sorted(issue.items(), key=lambda kv: -kv[1]["kernel_seconds"])[:8]:
+        print(k[:44].ljust(44), v["kernel_seconds"], v["issue_frac"], v["valu_busy_frac_at_2_cycles_per_wave64_op"], v["wave_cycle_shares"], v["mean_waves_resident_per_simd"])
+    for k, v in kernels.items():
+        if "expand" in k or "beam" in k or "material" in k:
+            print(k[:44].ljust(44), v["hbm_bytes_per_launch"], v["launches_profiled"])
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])

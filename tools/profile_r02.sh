@@ -1,0 +1,22 @@
+#!/bin/bash
+# rocprofv3 passes over the bench workload (run on the GPU box from the repo root):
+#   1. kernel trace + stats of the timed loop as the driver runs it (three batches in flight)
+#   2.-5. PMC passes, each in its own run, synchronous calls (one batch at a time): FETCH_SIZE | WRITE_SIZE | SQ issue | SQ mix
+set -e
+R=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$R/gpurun_out/r02_prof
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+B="python3 $R/bench.py --no-cpu-baseline --no-extras"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $B --steps 20 --warmup 5 > $OUT/trace_bench.json 2> $OUT/trace.err
+echo "trace done" >> $OUT/progress.log
+export BENCH_DEPTH=1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- $B --steps 3 --warmup 1 > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
+echo "fetch done" >> $OUT/progress.log
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- $B --steps 3 --warmup 1 > $OUT/pmc_write.json 2> $OUT/pmc_write.err
+echo "write done" >> $OUT/progress.log
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq -o p -- $B --steps 3 --warmup 1 > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err
+echo "sq done" >> $OUT/progress.log
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/pmc_sq2 -o p -- $B --steps 3 --warmup 1 > $OUT/pmc_sq2.json 2> $OUT/pmc_sq2.err || echo "sq2 failed" >> $OUT/progress.log
+echo "sq2 done" >> $OUT/progress.log
+find $OUT -name "*.csv" | head -30
