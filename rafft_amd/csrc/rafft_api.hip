@@ -438,7 +438,8 @@ struct Wave {
     Batch &bt;                                      // the first of them: carries the wave's timing spans and statistics
     std::vector<Span> &spans;
     const SeamIn *seam;
-    size_t S = 0, sumL = 0, B = 0, bs_lds[2] = {0, 0};
+    size_t S = 0, sumL = 0, B = 0, bs_lds[2] = {0, 0}, mat_lds = RAFFT_MAX_LEN;
+    unsigned dedupe_per_cu = 4;
     std::vector<int> off, len;
     ClsCfg cf[NCLS];
     Caps c;
@@ -590,6 +591,8 @@ int Wave::setup()
         const size_t nt = v ? 1024 : 256;
         bs_lds[v] = std::max((size_t)c.sort_cap * 8, 24 * nt) + RL_CAP * 12 + B * sizeof(ParentInfo) + (B + 1) * 8 + ((B + 3) & ~(size_t)3) * 4 + 128;
     }
+    mat_lds = ((size_t)maxL + 15) & ~(size_t)15;
+    if (const char *e = getenv("RAFFT_DEDUPE_PER_CU")) dedupe_per_cu = (unsigned)std::max(1, atoi(e));
     n_active = (unsigned)S;
     ms_setup = since(tw0);
     if (getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] setup: encode %.3f ms, plan+buffers %.3f ms, copies+init %.3f ms\n", ms_enc, ms_plan - ms_enc, ms_setup - ms_plan);
@@ -676,7 +679,7 @@ int Wave::after_beam()
     {
         Span sp{next_event(), next_event(), 2};
         SPAN_REC(sp.a, st, sp.kind);
-        hipLaunchKernelGGL(materialize_kernel, dim3(hc.n_mat), dim3(MAT_NT), 0, st, d);
+        hipLaunchKernelGGL(materialize_kernel, dim3(hc.n_mat), dim3(MAT_NT), mat_lds, st, d);
         HIPCHK(hipGetLastError());
         // tail of the batch: so few new structures that their regions fit one wave of workgroups of the widest class
         // (measured on the benchmark batch: 18.8 -> 17.3 ms; thresholds in new structures per step, per CU)
@@ -684,7 +687,7 @@ int Wave::after_beam()
         const unsigned merge2_below = getenv("RAFFT_MERGE2_BELOW") ? (unsigned)atoi(getenv("RAFFT_MERGE2_BELOW")) : 128u * (unsigned)::g.n_cu;
         d.merge_cls = seam ? 0 : hc.n_mat < merge_below ? merge_target : hc.n_mat < merge2_below ? 2 : 0;
         merged_now = d.merge_cls;
-        hipLaunchKernelGGL(dedupe_kernel, dim3(::g.n_cu * 4), dim3(256), 0, st, d);
+        hipLaunchKernelGGL(dedupe_kernel, dim3(::g.n_cu * dedupe_per_cu), dim3(256), 0, st, d);
         HIPCHK(hipGetLastError());
         SPAN_REC(sp.b, st, sp.kind);
         spans.push_back(sp);

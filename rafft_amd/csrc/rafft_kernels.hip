@@ -115,7 +115,7 @@ struct PlainView {
 // ------------------------------------------------------------ expand kernel
 
 #ifndef RAFFT_EXPAND64_WAVES
-#define RAFFT_EXPAND64_WAVES 4        // <= 128 VGPRs: four wavefronts per SIMD
+#define RAFFT_EXPAND64_WAVES 3        // <= 168 VGPRs (12 B/lane of scratch): its LDS allows three wavefronts per SIMD anyway; a cap of 128 spilled 152 B/lane
 #endif
 // Synchronisation inside one region's work.  The one-wavefront class needs no s_barrier: the LDS operations of a
 // wavefront execute in program order, so a compiler fence at wavefront scope is all it takes - and, unlike
@@ -1500,9 +1500,14 @@ __device__ inline MatDesc mat_describe(const Dev &d, int pn, int selk)
     return m;
 }
 
-__global__ __launch_bounds__(MAT_NT) void materialize_kernel(Dev d)
+#ifndef RAFFT_MAT_WAVES
+#define RAFFT_MAT_WAVES 1
+#endif
+// (dynamic LDS: the dot-bracket staging row, sized for the longest sequence of the wave - a latency-bound kernel of
+//  one-wavefront workgroups lives on the number of them a CU holds)
+__global__ __launch_bounds__(MAT_NT, RAFFT_MAT_WAVES) void materialize_kernel(Dev d)
 {
-    __shared__ uint8_t sdb[RAFFT_MAX_LEN];
+    extern __shared__ __align__(16) uint8_t sdb[];
     __shared__ int prod_node[MAX_PROD];
     __shared__ int prod_cnt[MAX_PROD];
     __shared__ int sel[MAX_PROD];

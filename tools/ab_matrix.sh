@@ -1,8 +1,8 @@
 #!/bin/bash
-run() { echo -n "$* : "; env "$@" timeout -k 10 120 python tools/ab_bench.py 40 2>/dev/null | sed 's/sequential.*; pipelined/pipelined/' || exit 1; }
-for rep in 1 2 3; do
-run AB_DEPTH=1
-run AB_DEPTH=4
-run AB_DEPTH=8
-run AB_DEPTH=12
-done
+run() { echo -n "$* : "; env "$@" AB_DEPTH=8 timeout -k 10 120 python tools/ab_bench.py 40 2>/dev/null | sed 's/sequential median/seq/; s/(min [0-9.]*)//; s/; regrows.*//' || exit 1; }
+run X=base
+run RAFFT_DEDUPE_PER_CU=8
+run AB_LIB=rafft_amd/libraffthip_m5.so
+run AB_LIB=rafft_amd/libraffthip_m6.so
+run AB_LIB=rafft_amd/libraffthip_m8.so
+run X=base
