@@ -207,12 +207,20 @@ int class_cfg(int K, int maxL, ClsCfg out[NCLS])
 {
     const int P[NCLS] = {CLS0_P, cls1_P(), CLS2_P, MAX_P}, LM[NCLS] = {CLS01_L, CLS01_L, RAFFT_MAX_LEN, RAFFT_MAX_LEN};
     const int NT[NCLS] = {64, 64, getenv("RAFFT_NT2") ? atoi(getenv("RAFFT_NT2")) : 256, 512}, BR[NCLS] = {CLS0_BR, cls1_br(), MAX_BR, MAX_BR};
-    // LDS-resident energy tables cost occupancy and measured slower on MI355X; class 0 (tiny regions in
-    // their own kernel) is kept compiled for experiments but receives no work (see node_class)
+    // class 0 (tiny regions in their own kernel) is kept compiled for experiments but receives no work (see node_class)
     const int tabm = getenv("RAFFT_TAB") ? atoi(getenv("RAFFT_TAB")) : 0;      // bit c: energy tables of class c in LDS
-    // the one-wavefront class packs WPB wavefronts into a workgroup that shares one LDS copy of the energy tables
-    const int wpb1 = getenv("RAFFT_WPB") ? atoi(getenv("RAFFT_WPB")) : 1;
-    const int WPB[NCLS] = {1, (wpb1 == 4 || wpb1 == 8) ? wpb1 : 1, 1, 1};
+    // The one-wavefront class packs 12 wavefronts - what a CU holds of them anyway - into one workgroup that shares ONE LDS
+    // copy of the energy tables and twiddles: the table look-ups of the dE phase stop being dependent L2 round trips
+    // (measured: 5.9 -> 5.4 ms per benchmark batch in this kernel; with 4 or 8 per workgroup a CU holds fewer wavefronts
+    // and loses more than it gains).  Falls back to one wavefront per workgroup, tables in L2, when nb_mode makes the
+    // per-wavefront arrays too big for 12 to fit.  RAFFT_WPB=1/4/8/12 overrides.
+    int wpb1 = getenv("RAFFT_WPB") ? atoi(getenv("RAFFT_WPB")) : 12;
+    if (!(wpb1 == 4 || wpb1 == 8 || wpb1 == 12)) wpb1 = 1;
+    if (wpb1 > 1) {
+        const int Kmax1 = std::max(1, std::min(K, cls1_P() - 1));
+        if (expand_lds(cls1_P(), CLS01_L, cls1_P() / 2, cls1_br(), Kmax1, true, wpb1).total > 160 * 1024) wpb1 = 1;
+    }
+    const int WPB[NCLS] = {1, wpb1, 1, 1};
     const bool TAB[NCLS] = {true, (tabm & 2) != 0 || WPB[1] > 1, (tabm & 4) != 0, (tabm & 8) != 0};
     for (int c = 0; c < NCLS; c++) {
         int nmax = P[c] / 2;
@@ -255,6 +263,7 @@ int launch_expand_cls(const Dev &d, int cls, const ClsCfg cf[NCLS], unsigned n_b
     if (cls == 1) {
         if (cf[1].wpb == 4) return launch_expand<64, true, 4>(d, 1, cf[1], n_blocks, st);
         if (cf[1].wpb == 8) return launch_expand<64, true, 8>(d, 1, cf[1], n_blocks, st);
+        if (cf[1].wpb == 12) return launch_expand<64, true, 12>(d, 1, cf[1], n_blocks, st);
         return cf[1].tab ? launch_expand<64, true>(d, 1, cf[1], n_blocks, st) : launch_expand<64, false>(d, 1, cf[1], n_blocks, st);
     }
     if (cls == 2) {
