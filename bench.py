@@ -337,7 +337,7 @@ def main():
     if rank == 0:
         # HBM traffic and SQ counters of the dominant kernel come from rocprofv3 PMC passes (separate runs,
         # gfx950 correction applied by tools/pmc_traffic.py); counters cannot be read in-process.
-        traffic, traffic_src, issue = None, None, None
+        traffic, traffic_src, issue, traffic_batch = None, None, None, None
         for name in ("r02_traffic.json", "r01_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tpath):
@@ -345,9 +345,15 @@ def main():
                 k = next((v for kn, v in tj["kernels"].items() if kn.startswith("void expand_kernel<64")), None)
                 if k:
                     traffic, traffic_src = k["hbm_bytes_per_launch"], f"profiles/{name}: " + tj["correction"]
+                    traffic_batch = k.get("hbm_bytes_per_batch")
                     issue = tj.get("issue_roofline")
                 break
         launches = max(1, agg.get("n_expand_launches", 0))
+        if traffic is not None and traffic_batch:
+            # the PMC passes run synchronous calls (7 launches of this kernel per batch); the timed loop folds several
+            # batches per wave, i.e. fewer and bigger launches: per launch LIKE `achieved` = bytes per batch / launches per step
+            traffic = round(traffic_batch * args.steps / launches)
+            traffic_src += "; per batch in the PMC run, divided by the launches per step of the timed loop"
         dur_s = agg.get("ms_expand", 0.0) / 1e3 / launches
         bytes_per_launch = agg.get("alg_bytes_expand", 0) / launches
         achieved = bytes_per_launch / dur_s / 1e9 if dur_s > 0 else 0.0
@@ -367,7 +373,7 @@ def main():
                        "sequences_per_step": n, "sequences_on_rank0": mine.n,
                        "parallelism": (f"LPT sequence shards x{world}, no collective" if world > 1 else "1 GPU"),
                        "batches_in_flight": PIPELINE_DEPTH},
-            "roofline": {"bound": "hbm", "kernel": "expand_kernel<64,false> (regions with FFT size <= 512)", "achieved": round(achieved, 3),
+            "roofline": {"bound": "hbm", "kernel": "expand_kernel<64,true,12> (regions with FFT size <= 512; 12 wavefronts per workgroup)", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": traffic, "traffic_source": traffic_src,
                          "alg_bytes_per_launch": round(bytes_per_launch, 1),

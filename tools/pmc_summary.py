@@ -11,6 +11,7 @@ usage: python tools/pmc_summary.py gpurun_out/r02_prof profiles r02"""
 import collections, csv, json, os, shutil, sys
 
 N_CU, SIMD_PER_CU = 256, 4
+N_BATCHES = 4          # bench.py --steps 3 --warmup 1 in every PMC pass
 
 
 def counters(dirname):
@@ -50,7 +51,7 @@ def main(src, dst, tag):
     for k in sorted(set(fe) | set(wr)):
         f = fe[k]["FETCH_SIZE"] / max(nf.get(k, 1), 1) if k in fe else 0.0
         w = wr[k]["WRITE_SIZE"] / max(nw.get(k, 1), 1) if k in wr else 0.0
-        kernels[k] = {"launches_profiled": nf.get(k, 0), "fetch_bytes_per_launch": round(2 * f * 1024), "write_bytes_per_launch": round(w * 1024),
+        kernels[k] = {"launches_profiled": nf.get(k, 0), "hbm_bytes_per_batch": round((2 * f + w) * 1024 * nf.get(k, 0) / N_BATCHES), "fetch_bytes_per_launch": round(2 * f * 1024), "write_bytes_per_launch": round(w * 1024),
                       "hbm_bytes_per_launch": round((2 * f + w) * 1024), "raw_FETCH_SIZE_KiB": round(f, 3), "raw_WRITE_SIZE_KiB": round(w, 3)}
     for k, c in sq.items():
         t = dur[k] * 1e-9
