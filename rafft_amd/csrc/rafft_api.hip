@@ -213,9 +213,9 @@ int class_cfg(int K, int maxL, ClsCfg out[NCLS])
     // copy of the energy tables and twiddles: the table look-ups of the dE phase stop being dependent L2 round trips
     // (measured: 5.9 -> 5.4 ms per benchmark batch in this kernel; with 4 or 8 per workgroup a CU holds fewer wavefronts
     // and loses more than it gains).  Falls back to one wavefront per workgroup, tables in L2, when nb_mode makes the
-    // per-wavefront arrays too big for 12 to fit.  RAFFT_WPB=1/4/8/12 overrides.
+    // per-wavefront arrays too big for 12 to fit.  RAFFT_WPB=1/4/12 overrides.
     int wpb1 = getenv("RAFFT_WPB") ? atoi(getenv("RAFFT_WPB")) : 12;
-    if (!(wpb1 == 4 || wpb1 == 8 || wpb1 == 12)) wpb1 = 1;
+    if (!(wpb1 == 4 || wpb1 == 12)) wpb1 = 1;
     if (wpb1 > 1) {
         const int Kmax1 = std::max(1, std::min(K, cls1_P() - 1));
         if (expand_lds(cls1_P(), CLS01_L, cls1_P() / 2, cls1_br(), Kmax1, true, wpb1).total > 160 * 1024) wpb1 = 1;
@@ -262,7 +262,6 @@ int launch_expand_cls(const Dev &d, int cls, const ClsCfg cf[NCLS], unsigned n_b
     if (cls == 0) return launch_expand<64, true>(d, 0, cf[0], n_blocks, st);
     if (cls == 1) {
         if (cf[1].wpb == 4) return launch_expand<64, true, 4>(d, 1, cf[1], n_blocks, st);
-        if (cf[1].wpb == 8) return launch_expand<64, true, 8>(d, 1, cf[1], n_blocks, st);
         if (cf[1].wpb == 12) return launch_expand<64, true, 12>(d, 1, cf[1], n_blocks, st);
         return cf[1].tab ? launch_expand<64, true>(d, 1, cf[1], n_blocks, st) : launch_expand<64, false>(d, 1, cf[1], n_blocks, st);
     }

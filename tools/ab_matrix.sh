@@ -1,8 +1,9 @@
 #!/bin/bash
-run() { echo -n "$* : "; env "$@" timeout -k 10 200 python tools/ab_cfg4.py 2>/dev/null || exit 1; }
-run RAFFT_TAB=0
-run RAFFT_TAB=4
-run RAFFT_TAB=8
-run RAFFT_TAB=12
-run RAFFT_TAB=12 RAFFT_NT2=512
-run RAFFT_TAB=0 RAFFT_NT2=512
+run() { echo -n "$* : "; env "$@" AB_DEPTH=8 timeout -k 10 120 python tools/ab_bench.py 40 2>/dev/null | sed 's/sequential median/seq/; s/(min [0-9.]*)//; s/; regrows.*//' || exit 1; }
+run X=base
+run RAFFT_MAX_WAVES=3
+run RAFFT_WPB=10
+run RAFFT_WPB=10 RAFFT_MAX_WAVES=3
+run RAFFT_WPB=10 RAFFT_MAX_WAVES=4
+run RAFFT_WPB=8 RAFFT_MAX_WAVES=3
+run RAFFT_WPB=8 RAFFT_MAX_WAVES=4
