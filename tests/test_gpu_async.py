@@ -121,3 +121,25 @@ def test_gpu_queued_batches_with_equal_parameters_are_merged_and_split_back(benc
             else:
                 assert key(res, False) == want[i], (rnd_, i)
         assert total == sum(single_structs)          # every wave's work is attributed to exactly one of its batches
+
+
+def test_gpu_merged_wave_overflow_regrows_and_stays_exact(bench_rows, monkeypatch):
+    """a wave that serves several batches and overflows its (starved) HBM arenas is re-run with larger ones - for all of
+    its batches - and every batch still gets exactly its result"""
+    base = [r["seq"] for r in bench_rows[::6]]
+    variants = [base, base[50:250], base[::-1], base[:100]]
+    kw = dict(nb_mode=100, max_stack=20, max_branch=1000, traj=True)
+    want = [key(rafft_amd.fold_batch(v, **kw), True) for v in variants]
+    monkeypatch.setenv("RAFFT_EST", "0.05")
+    regrows = 0
+    for rnd_ in range(2):
+        pend = [rafft_amd.submit_batch(v, **kw) for v in variants]
+        for i, pb in enumerate(pend):
+            assert key(pb.result(), True) == want[i], (rnd_, i)
+            regrows += rafft_amd.last_stats()["n_regrows"]
+    assert regrows > 0
+    monkeypatch.delenv("RAFFT_EST")
+    monkeypatch.setenv("RAFFT_TEST_OVF_AT", "5")       # pretend an overflow late in the first attempt of every job
+    pend = [rafft_amd.submit_batch(v, **kw) for v in variants]
+    for i, pb in enumerate(pend):
+        assert key(pb.result(), True) == want[i]
