@@ -350,6 +350,7 @@ Caps plan_caps(size_t S, size_t sumL, const rafft_params &p, double est)
     return c;
 }
 
+static size_t merge_cap();
 struct SeqIn { const char *s; int len; int idx; int bi; };   // bi: which member batch of the job the sequence belongs to
 
 struct HostOut {   // owner of a rafft_result
@@ -507,17 +508,29 @@ int Wave::setup()
         return fail(RAFFT_ERR_PARAM, "max_branch + 2*max_stack too large for the LDS-resident beam sort");
     B = (size_t)p.max_stack;
 
+    // Buffers are allocated for the wave that queued batches could be merged into (the scheduler folds up to merge_cap()
+    // sequences of equal-parameter batches as one wave), not just for this one: a hipFree + hipMalloc of a multi-GB arena
+    // in the middle of a stream of batches stalls every queue for tens of ms (now and then seconds).  Only when that
+    // reserve is small against the HBM (the benchmark set: 2.5 GB -> 10 GB).
+    size_t Sr = S;
+    Caps cr = c;
+    if (S >= 256 && S < merge_cap() && !seam) {
+        Sr = std::min(merge_cap(), 4 * S);
+        Caps big = plan_caps(Sr, (size_t)((double)sumL * (double)Sr / (double)S), p, est);
+        if (big.bytes <= (size_t)((double)::g.hbm_total * 0.06)) cr = big; else Sr = S;
+    }
+    const size_t sumLr = Sr == S ? sumL : (size_t)((double)sumL * (double)Sr / (double)S);
 #define ENS(buf, bytes) do { if (int rc_ = ensure(g.buf, (bytes))) return rc_; } while (0)
-    ENS(codes, sumL + 16); ENS(seq_off, S * 4); ENS(seq_len, S * 4);
-    ENS(beam, S * B * 4); ENS(beam_n, S * 4); ENS(done, S * 4); ENS(nsteps, S * 4);
-    ENS(ch_parent, S * c.ch_cap * 2); ENS(ch_combo, S * c.ch_cap * 8); ENS(ch_dcal, S * c.ch_cap * 4); ENS(ch_h, S * c.ch_cap * 16);
-    ENS(seen, c.seen * 16); ENS(seen_off, S * 8); ENS(seen_cap, S * 4); ENS(seen_cnt, S * 4);
-    ENS(st, c.st * sizeof(StRec)); ENS(prod, c.nd * 16);
-    ENS(nd, c.nd * sizeof(NodeRec)); ENS(nd_canon, c.nd * 4);
-    ENS(pos, c.pos * 2); ENS(br, c.br * 4); ENS(db, c.db); ENS(cand, c.cand * 32);
-    ENS(looptab, c.looptab * 8);
-    ENS(trec, c.trec * 16); ENS(tsid, c.tsid * 4);
-    ENS(work0, c.work * 4); ENS(work1, c.work * 4); ENS(work2, c.work * 4); ENS(work3, c.work * 4); ENS(mat, c.mat * sizeof(MatRec));
+    ENS(codes, sumLr + 16); ENS(seq_off, Sr * 4); ENS(seq_len, Sr * 4);
+    ENS(beam, Sr * B * 4); ENS(beam_n, Sr * 4); ENS(done, Sr * 4); ENS(nsteps, Sr * 4);
+    ENS(ch_parent, Sr * c.ch_cap * 2); ENS(ch_combo, Sr * c.ch_cap * 8); ENS(ch_dcal, Sr * c.ch_cap * 4); ENS(ch_h, Sr * c.ch_cap * 16);
+    ENS(seen, cr.seen * 16); ENS(seen_off, Sr * 8); ENS(seen_cap, Sr * 4); ENS(seen_cnt, Sr * 4);
+    ENS(st, cr.st * sizeof(StRec)); ENS(prod, cr.nd * 16);
+    ENS(nd, cr.nd * sizeof(NodeRec)); ENS(nd_canon, cr.nd * 4);
+    ENS(pos, cr.pos * 2); ENS(br, cr.br * 4); ENS(db, cr.db); ENS(cand, cr.cand * 32);
+    ENS(looptab, cr.looptab * 8);
+    ENS(trec, cr.trec * 16); ENS(tsid, cr.tsid * 4);
+    ENS(work0, cr.work * 4); ENS(work1, cr.work * 4); ENS(work2, cr.work * 4); ENS(work3, cr.work * 4); ENS(mat, cr.mat * sizeof(MatRec));
     ENS(counters, sizeof(Counters));
 #undef ENS
 
