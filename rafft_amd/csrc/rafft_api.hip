@@ -64,14 +64,14 @@ struct Workspace {
     Buf codes, seq_off, seq_len, beam, beam_n, done, nsteps, ch_parent, ch_combo, ch_dcal, ch_h, seen, seen_off,
         seen_cap, seen_cnt, st, prod, nd, nd_canon, pos, br, db, cand, looptab, trec, tsid,
         work0, work1, work2, work3, mat, counters,
-        row_sid, row_off, out_db, out_dcal, row_off2, out_db2, out_dcal2, dbg;
+        row_sid, row_off, out_db, out_dcal, row_off2, out_db2, out_dcal2, dbg, big;
     size_t bytes() const
     {
         size_t t = 0;
         for (const Buf *b : {&codes, &seq_off, &seq_len, &beam, &beam_n, &done, &nsteps, &ch_parent, &ch_combo, &ch_dcal, &ch_h, &seen,
                              &seen_off, &seen_cap, &seen_cnt, &st, &prod, &nd, &nd_canon, &pos, &br, &db, &cand, &looptab, &trec, &tsid,
                              &work0, &work1, &work2, &work3, &mat, &counters, &row_sid, &row_off, &out_db, &out_dcal, &row_off2, &out_db2,
-                             &out_dcal2, &dbg})
+                             &out_dcal2, &dbg, &big})
             t += b->cap;
         return t;
     }
@@ -205,8 +205,11 @@ static int cls1_br() { return std::min(CLS1_BR, (8 * cls1_P() - 16) / 10 - 1); }
 
 int class_cfg(int K, int maxL, ClsCfg out[NCLS])
 {
-    const int P[NCLS] = {CLS0_P, cls1_P(), CLS2_P, MAX_P}, LM[NCLS] = {CLS01_L, CLS01_L, RAFFT_MAX_LEN, RAFFT_MAX_LEN};
-    const int NT[NCLS] = {64, 64, getenv("RAFFT_NT2") ? atoi(getenv("RAFFT_NT2")) : 256, 512}, BR[NCLS] = {CLS0_BR, cls1_br(), MAX_BR, MAX_BR};
+    // sequences longer than LDS_SEQ: classes 2 and 3 read the bases of a loop from HBM/L2 (no LDS copy), class 0 takes the
+    // regions whose FFT would not fit
+    const bool longseq = maxL > LDS_SEQ;
+    const int P[NCLS] = {CLS0_P, cls1_P(), CLS2_P, MAX_P}, LM[NCLS] = {0, CLS01_L, longseq ? 0 : LDS_SEQ, longseq ? 0 : LDS_SEQ};
+    const int NT[NCLS] = {512, 64, getenv("RAFFT_NT2") ? atoi(getenv("RAFFT_NT2")) : 256, 512}, BR[NCLS] = {BIG_BR + 1, cls1_br(), MAX_BR, MAX_BR};
     // class 0 (tiny regions in their own kernel) is kept compiled for experiments but receives no work (see node_class)
     const int tabm = getenv("RAFFT_TAB") ? atoi(getenv("RAFFT_TAB")) : 0;      // bit c: energy tables of class c in LDS
     // The one-wavefront class packs 12 wavefronts - what a CU holds of them anyway - into one workgroup that shares ONE LDS
@@ -221,20 +224,22 @@ int class_cfg(int K, int maxL, ClsCfg out[NCLS])
         if (expand_lds(cls1_P(), CLS01_L, cls1_P() / 2, cls1_br(), Kmax1, true, wpb1).total > 160 * 1024) wpb1 = 1;
     }
     const int WPB[NCLS] = {1, wpb1, 1, 1};
-    const bool TAB[NCLS] = {true, (tabm & 2) != 0 || WPB[1] > 1, (tabm & 4) != 0, (tabm & 8) != 0};
+    const bool TAB[NCLS] = {false, (tabm & 2) != 0 || WPB[1] > 1, (tabm & 4) != 0, (tabm & 8) != 0};
     for (int c = 0; c < NCLS; c++) {
-        int nmax = P[c] / 2;
-        int Kmax = std::max(1, std::min(K, P[c] - 1));
+        int nmax = c == 0 ? BIG_N : P[c] / 2;
+        int Kmax = std::max(1, std::min(K, c == 0 ? 2 * BIG_N - 1 : P[c] - 1));
         ExpandLds l = expand_lds(P[c], LM[c], nmax, BR[c], Kmax, TAB[c], WPB[c]);
         // region A is time-shared: behind the fp64 lag values (8 P bytes) it must still hold the branch prefix sums
         // (10 bytes per branch), the select histogram and the window_slide scratch of this class
+        if (c == 0 && longseq && (80 * (BIG_N / 64) + 24 * 8 * std::max(Kmax, 1) + 4096 > 16 * P[c] || 10 * (BR[c] + 1) + 16 + 24 * Kmax + 2048 > 16 * P[c]))
+            return fail(RAFFT_ERR_PARAM, "nb_mode too large for the LDS scratch of the class for regions beyond 4096 positions");
         if (c >= 1 && (10 * (BR[c] + 1) + 16 > 8 * P[c] || 2 * P[c] + 1152 + 16 > 8 * P[c] || (NT[c] > 64 && NT[c] * 24 > 8 * P[c])))
             return fail(RAFFT_ERR_PARAM, "internal: expand LDS plan does not fit its size class");
         int per_cu = std::max(1, std::min(32 / (NT[c] / 64), WPB[c] * ((160 * 1024) / l.total)));      // teams per CU
         if (c == 1 && getenv("RAFFT_C1_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(getenv("RAFFT_C1_PER_CU"))));
         out[c] = {NT[c], P[c], LM[c], nmax, BR[c], Kmax, l.total, g.n_cu * per_cu, TAB[c], WPB[c]};
-        // a size class that no region of this batch can reach need not fit (class 3 needs n > 1024)
-        const bool reachable = c < 3 || maxL > CLS2_P / 2;
+        // a size class that no region of this batch can reach need not fit (class 3 needs n > 1024, class 0 n > 4096)
+        const bool reachable = c == 0 ? longseq : (c < 3 || maxL > CLS2_P / 2);
         if (l.total > 160 * 1024 && reachable)
             return fail(RAFFT_ERR_PARAM, "nb_mode too large for the LDS-resident expand kernel: with sequences longer than "
                                          "1024 nt nb_mode must stay below ~400, otherwise below 2048");
@@ -243,23 +248,26 @@ int class_cfg(int K, int maxL, ClsCfg out[NCLS])
     return 0;
 }
 
-template <int NT, bool TAB, int WPB = 1>
+template <int NT, bool TAB, int WPB = 1, int LONGSEQ = 0>
 int launch_expand(const Dev &d, int cls, const ClsCfg &cf, unsigned n_teams, hipStream_t st)
 {
     static int lds_set = 0;
     if (cf.lds > lds_set) {
-        HIPCHK(hipFuncSetAttribute((const void *)expand_kernel<NT, TAB, WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, cf.lds));
+        HIPCHK(hipFuncSetAttribute((const void *)expand_kernel<NT, TAB, WPB, LONGSEQ>, hipFuncAttributeMaxDynamicSharedMemorySize, cf.lds));
         lds_set = cf.lds;
     }
     const unsigned n_blocks = (n_teams + WPB - 1) / WPB;
-    hipLaunchKernelGGL((expand_kernel<NT, TAB, WPB>), dim3(n_blocks), dim3(NT * WPB), cf.lds, st, d, cls, cf.Pmax, cf.Lmax, cf.nmax, cf.brmax, cf.Kmax);
+    hipLaunchKernelGGL((expand_kernel<NT, TAB, WPB, LONGSEQ>), dim3(n_blocks), dim3(NT * WPB), cf.lds, st, d, cls, cf.Pmax, cf.Lmax, cf.nmax, cf.brmax, cf.Kmax);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
 int launch_expand_cls(const Dev &d, int cls, const ClsCfg cf[NCLS], unsigned n_blocks, hipStream_t st)
 {
-    if (cls == 0) return launch_expand<64, true>(d, 0, cf[0], n_blocks, st);
+    const bool longseq = cf[2].Lmax == 0;          // (class_cfg: no LDS copy of the bases)
+    if (cls == 0) return launch_expand<512, false, 1, 2>(d, 0, cf[0], n_blocks, st);
+    if (longseq && cls == 2 && cf[2].nt == 256) return launch_expand<256, false, 1, 1>(d, 2, cf[2], n_blocks, st);
+    if (longseq && cls >= 2) return launch_expand<512, false, 1, 1>(d, cls, cf[cls], n_blocks, st);
     if (cls == 1) {
         if (cf[1].wpb == 4) return launch_expand<64, true, 4>(d, 1, cf[1], n_blocks, st);
         if (cf[1].wpb == 12) return launch_expand<64, true, 12>(d, 1, cf[1], n_blocks, st);
@@ -448,6 +456,7 @@ struct Wave {
     std::vector<Span> &spans;
     const SeamIn *seam;
     size_t S = 0, sumL = 0, B = 0, bs_lds[2] = {0, 0}, mat_lds = RAFFT_MAX_LEN;
+    bool longseq = false;         // a sequence longer than LDS_SEQ: its loops' bases are read from HBM, regions beyond 4096 positions exist
     unsigned dedupe_per_cu = 4;
     std::vector<int> off, len;
     ClsCfg cf[NCLS];
@@ -546,6 +555,13 @@ int Wave::setup()
     if (const char *e = getenv("RAFFT_NO_MEMO")) if (atoi(e)) d.memo = 0;
     if (const char *e = getenv("RAFFT_FORCE_FFT")) if (atoi(e)) d.force_fft = 1;   // tests: FFT path for short regions too
     d.rl_cap = RL_CAP;
+    longseq = maxL > LDS_SEQ;
+    d.max_prod = longseq ? MAX_PROD_LONG : MAX_PROD;
+    if (longseq) {       // scratch of the class for regions beyond 4096 positions: lag values (fp64) + lag column, per workgroup
+        d.big_stride = (size_t)2 * BIG_N + (size_t)2 * BIG_N / 4;
+        if (int rc = ensure(g.big, (size_t)cf[0].grid * d.big_stride * 8)) return rc;
+        d.big_keyv = (double *)g.big.p;
+    }
     d.cls1_P = cls1_P(); d.cls1_br = cls1_br();
     d.mat_tile = 64;
     if (const char *e = getenv("RAFFT_MAT_TILE")) d.mat_tile = std::max(1, std::min(atoi(e), 64));   // tests: several tiles per structure
@@ -612,7 +628,7 @@ int Wave::setup()
         const size_t nt = v ? 1024 : 256;
         bs_lds[v] = std::max((size_t)c.sort_cap * 8, 24 * nt) + RL_CAP * 12 + B * sizeof(ParentInfo) + (B + 1) * 8 + ((B + 3) & ~(size_t)3) * 4 + 128;
     }
-    mat_lds = ((size_t)maxL + 15) & ~(size_t)15;
+    mat_lds = 12 * (size_t)d.max_prod + (((size_t)maxL + 15) & ~(size_t)15);
     if (const char *e = getenv("RAFFT_DEDUPE_PER_CU")) dedupe_per_cu = (unsigned)std::max(1, atoi(e));
     n_active = (unsigned)S;
     ms_setup = since(tw0);
@@ -633,11 +649,14 @@ int Wave::issue_step()
     HIPCHK(hipEventRecord(g.ev_fork, st));
     Span wall{next_event(), next_event(), 4};
     SPAN_REC(wall.a, st, 4);
-    for (int cls = NCLS - 1; cls >= 1; cls--) {   // big-LDS classes first; class 0 is unused (node_class)
+    static const int order[NCLS] = {3, 0, 2, 1};    // big-LDS classes first
+    for (int oi = 0; oi < NCLS; oi++) {
+        const int cls = order[oi];
+        if (cls == 0 && !longseq) continue;                      // regions beyond 4096 positions: only sequences longer than that have them
         if (cls == 3 && merge_target == 2) continue;             // no sequence long enough for a region of that class
-        if (merged_now == 3 && cls != 3) continue;               // the dedupe of the last step sent everything to one class
+        if (merged_now == 3 && cls != 3 && cls != 0) continue;   // the dedupe of the last step sent everything to one class
         if (merged_now == 2 && cls == 1) continue;               // ... or the one-wavefront class to the 256-thread one
-        const bool inline_ = serial || merged_now == 3;          // a single kernel: no fork/join through another stream
+        const bool inline_ = serial || (merged_now == 3 && !longseq);   // a single kernel: no fork/join through another stream
         hipStream_t cs = inline_ ? st : g.cls_stream[cls];
         if (!inline_) HIPCHK(hipStreamWaitEvent(cs, g.ev_fork, 0));
         Span sp{next_event(), next_event(), 10 + cls};
@@ -806,7 +825,7 @@ int Wave::finish()
         HIPCHK(hipStreamSynchronize(st));
         if (harvested) HIPCHK(hipStreamSynchronize(g.copy_stream));
         if (ovf & (OVF_PROD | OVF_SORT))
-            return result = fail(RAFFT_ERR_PARAM, "structure with more than 256 productive regions or sort capacity exceeded");
+            return result = fail(RAFFT_ERR_PARAM, "structure with more productive regions than the kernels hold (256; 1024 for sequences beyond 4096 nt) or sort capacity exceeded");
         return result = RAFFT_ERR_CAPACITY;
     }
     // statistics (SURVEY.md 8d algorithmic bytes; only expansions the kernels really executed)
@@ -861,6 +880,11 @@ int Wave::finish()
             fprintf(stderr, "[rafft] expand class %d phase shares (first wavefront of every workgroup, %llu Mcycles):", c, t / 1000000);
             for (int k = 0; k < 8; k++) fprintf(stderr, " %s %.1f%%", nm[k], t ? 100.0 * (double)pe[c * 16 + k] / (double)t : 0.0);
             fprintf(stderr, "\n");
+            unsigned long long hn = 0;
+            for (int k = 8; k < 14; k++) hn += pe[c * 16 + k];
+            fprintf(stderr, "[rafft] expand class %d region sizes (sampled): n<=8 %.1f%%  <=16 %.1f%%  <=32 %.1f%%  <=64 %.1f%%  <=128 %.1f%%  >128 %.1f%%\n", c,
+                    hn ? 100.0 * pe[c * 16 + 8] / hn : 0.0, hn ? 100.0 * pe[c * 16 + 9] / hn : 0.0, hn ? 100.0 * pe[c * 16 + 10] / hn : 0.0,
+                    hn ? 100.0 * pe[c * 16 + 11] / hn : 0.0, hn ? 100.0 * pe[c * 16 + 12] / hn : 0.0, hn ? 100.0 * pe[c * 16 + 13] / hn : 0.0);
         }
     }
     if (d.prof_ws) {
@@ -889,7 +913,7 @@ int Wave::finish()
     if (getenv("RAFFT_TRACE")) {
         auto mx = [&](const ShardCtr *sc) { unsigned long long m = 0, t = 0; for (int i = 0; i < NSHARD; i++) { m = std::max(m, sc[i].v); t += sc[i].v; } return std::make_pair(m, t); };
         auto nd = mx(hc.node), po = mx(hc.pos), br = mx(hc.br), db = mx(hc.db), ca = mx(hc.cand), pr = mx(hc.prod);
-        fprintf(stderr, "[rafft] max productive regions per structure: %u (limit %d)\n", hc.max_nprod, MAX_PROD);
+        fprintf(stderr, "[rafft] max productive regions per structure: %u (limit %d)\n", hc.max_nprod, d.max_prod);
         fprintf(stderr, "[rafft] arenas used/cap (max shard | total): st %llu/%zu  nd %llu/%llu|%llu  pos %llu/%llu|%llu  br %llu/%llu|%llu  db %llu/%llu  cand %llu/%llu|%llu  prod %llu/%llu  seen %llu/%zu  est %.1f\n",
                 hc.n_struct, c.st, nd.first, (unsigned long long)d.nd_shard_cap, nd.second, po.first, (unsigned long long)d.pos_shard_cap, po.second,
                 br.first, (unsigned long long)d.br_shard_cap, br.second, db.first, (unsigned long long)d.db_shard_cap,

@@ -25,18 +25,18 @@
 struct alignas(16) Cand {
     int32_t ddcal;
     uint16_t mi, mj, nb, cut_hi;      // stem: innermost pair (mi,mj) in region coordinates, nb stacked pairs
-    uint32_t cut_lo;                  // cut_hi:cut_lo = where the stem cuts the region's branch list, 4 x 11 bits
+    uint32_t cut_lo;                  // cut_hi:cut_lo = where the stem cuts the region's branch list, 4 x 12 bits
     uint64_t h1, h2;                  // 128-bit hash of the stem's pairs
     // number of branches starting before the innermost 5' / innermost 3' / outermost 5' / outermost 3' position
     __host__ __device__ void set_cuts(int lo0, int hi0, int loo, int hio)
     {
-        const unsigned long long v = (unsigned long long)lo0 | ((unsigned long long)hi0 << 11) | ((unsigned long long)loo << 22) | ((unsigned long long)hio << 33);
+        const unsigned long long v = (unsigned long long)lo0 | ((unsigned long long)hi0 << 12) | ((unsigned long long)loo << 24) | ((unsigned long long)hio << 36);
         cut_lo = (uint32_t)v; cut_hi = (uint16_t)(v >> 32);
     }
     __host__ __device__ void get_cuts(int &lo0, int &hi0, int &loo, int &hio) const
     {
         const unsigned long long v = (unsigned long long)cut_lo | ((unsigned long long)cut_hi << 32);
-        lo0 = (int)(v & 2047); hi0 = (int)((v >> 11) & 2047); loo = (int)((v >> 22) & 2047); hio = (int)((v >> 33) & 2047);
+        lo0 = (int)(v & 4095); hi0 = (int)((v >> 12) & 4095); loo = (int)((v >> 24) & 4095); hio = (int)((v >> 36) & 4095);
     }
 };
 static_assert(sizeof(Cand) == 32, "Cand must be 32 bytes");
@@ -100,6 +100,8 @@ struct Dev {
     const uint8_t *codes;
     const int *seq_off, *seq_len;
     int K, B, max_branch, min_hp, traj, memo, force_fft, rl_cap, mat_tile, merge_cls;
+    double *big_keyv; size_t big_stride;   // lag values of regions too big for LDS: one slice of `big_stride` doubles per workgroup
+    int max_prod;                // productive regions per structure that materialize_kernel's LDS lists hold
     int cls1_P, cls1_br;         // limits of the one-wavefront expand class (FFT size, branches): they set its LDS per wavefront
     double min_nrj, gc, au, gu;
     int *beam, *beam_n, *done, *nsteps;
@@ -139,17 +141,20 @@ struct Dev {
     int rep;                     // profiling only (RAFFT_REP env): bit k doubles phase k of expand_kernel
 };
 
-// expand-kernel size classes: 0 tiny (one wavefront, energy tables + twiddles in LDS),
-// 1 small (one wavefront), 2 medium (256 threads), 3 large (512 threads, one workgroup per CU)
-#define CLS0_P 128
-#define CLS0_BR 64
+// expand-kernel size classes: 1 small (FFT size P <= 512: one wavefront per region), 2 medium (P <= 2048: 256 threads),
+// 3 large (P <= 8192: 512 threads, one workgroup per CU), 0 regions beyond that (n > 4096; 512 threads, no FFT)
+#define CLS0_P 4096        // (only sizes the LDS scratch of class 0: 16 bytes x CLS0_P)
 #define CLS1_P 512
 #define CLS01_L 1280
 #define CLS1_BR 256
 #define CLS2_P 2048
 #define MAX_P 8192
-#define MAX_BR 1024
-#define MAX_PROD 256
+#define MAX_BR 1024        // branches of a loop, classes 1-3
+#define BIG_BR 4095        // ... of the class for the biggest regions (the 12-bit cut points of a candidate)
+#define BIG_N 16384        // positions of a region of that class = RAFFT_MAX_LEN
+#define LDS_SEQ 4096       // sequences up to this length have the bases of a loop staged in LDS by classes 2 and 3
+#define MAX_PROD 256       // productive regions per structure (sequences up to LDS_SEQ)
+#define MAX_PROD_LONG 1024 // ... for longer sequences
 #define RL_CAP 1024        // beam_step_kernel: regions with >= 2 candidates of all beam members, kept in LDS
 
 __host__ __device__ inline int next_pow2_ge(int x) { int p = 2; while (p < x) p <<= 1; return p; }
@@ -157,11 +162,12 @@ __host__ __device__ inline int node_class(int n, int L, int nbr, int merge_cls =
 {
     // few regions in this step (the tail of a batch): all of them go to one kernel, the widest one that is
     // configured - one launch and one region per workgroup instead of three nearly empty kernels in a row
-    if (merge_cls == 3) return 3;
-    if (merge_cls == 2) return next_pow2_ge(2 * n - 1) <= CLS2_P ? 2 : 3;
     int P = next_pow2_ge(2 * n - 1);
-    // class 0 is kept empty: measured on MI355X, running the tiny regions (P <= 128) in their own
-    // persistent kernel beside class 1 oversubscribes the wave slots and is slower than one kernel
+    // class 0: regions whose FFT buffers (P > 8192) or branch list do not fit the LDS plan of the other classes - exact
+    // direct correlation on bit masks, lag values in HBM.  Only sequences longer than 4096 nt can have such regions.
+    if (P > MAX_P || nbr > MAX_BR) return 0;
+    if (merge_cls == 3) return 3;
+    if (merge_cls == 2) return P <= CLS2_P ? 2 : 3;
     if (L <= CLS01_L && P <= cls1_P && nbr <= cls1_br) return 1;
     if (P <= CLS2_P) return 2;
     return 3;

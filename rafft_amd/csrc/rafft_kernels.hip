@@ -114,6 +114,41 @@ struct PlainView {
 
 // ------------------------------------------------------------ expand kernel
 
+// 64 bits of the bit string X (W words) starting at bit `start` (may be negative / past the end -> zeros)
+__device__ __forceinline__ unsigned long long mask_window(const unsigned long long *X, int W, int start)
+{
+    if (start >= 64 * W || start <= -64) return 0ULL;
+    const int q = start >> 6, bsh = start & 63;           // arithmetic shift: floor division
+    const unsigned long long lo = (q >= 0 && q < W) ? X[q] : 0ULL;
+    const unsigned long long hi = (q + 1 >= 0 && q + 1 < W) ? X[q + 1] : 0ULL;
+    return bsh ? (lo >> bsh) | (hi << (64 - bsh)) : lo;
+}
+
+// Bit masks of a region: forward masks F[0..3] = positions holding A, C, G, U, F[4] = contiguity with the previous
+// position; R[] = the same strings reversed (bit j of R = bit n-1-j of F).  W words each.  One synchronisation inside
+// (the caller adds the one behind).
+template <int NT>
+__device__ inline void build_masks(unsigned long long *F, unsigned long long *R, int W, int n, const uint8_t *code, const uint16_t *pos, int tid)
+{
+    for (int wq = tid >> 6; wq < W; wq += NT / 64) {       // each wavefront ballots whole 64-bit words
+        const int t = wq * 64 + (tid & 63);
+        const int c0 = t < n ? code[t] : 0;
+        const unsigned long long bA = __ballot(c0 == 1), bC = __ballot(c0 == 2), bG = __ballot(c0 == 3), bU = __ballot(c0 == 4);
+        const unsigned long long bg = __ballot(t >= 1 && t < n && (int)pos[t] - (int)pos[t > 0 ? t - 1 : 0] == 1);
+        if ((tid & 63) == 0) { F[0 * W + wq] = bA; F[1 * W + wq] = bC; F[2 * W + wq] = bG; F[3 * W + wq] = bU; F[4 * W + wq] = bg; }
+    }
+    if (NT == 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } else __syncthreads();
+    // reverse the whole 64 W-bit string (word order and bit order), then shift the n live bits down:
+    // R bit j = T bit (j + 64 W - n) with T[w] = brev(F[W-1-w]); bits of F past n are zero
+    for (int idx = tid; idx < 5 * W; idx += NT) {
+        const int which = idx / W, w = idx - which * W;
+        const int s0 = 64 * w + 64 * W - n, q = s0 >> 6, bsh = s0 & 63;
+        const unsigned long long lo = q < W ? __brevll(F[which * W + W - 1 - q]) : 0ULL;
+        const unsigned long long hi = q + 1 < W ? __brevll(F[which * W + W - 2 - q]) : 0ULL;
+        R[which * W + w] = bsh ? (lo >> bsh) | (hi << (64 - bsh)) : lo;
+    }
+}
+
 #ifndef RAFFT_EXPAND64_WAVES
 #define RAFFT_EXPAND64_WAVES 3        // <= 168 VGPRs (12 B/lane of scratch): its LDS allows three wavefronts per SIMD anyway; a cap of 128 spilled 152 B/lane
 #endif
@@ -129,10 +164,17 @@ __device__ __forceinline__ void wave_sync()
 }
 #define ESYNC() do { if (NT == 64) wave_sync(); else __syncthreads(); } while (0)
 
-template <int NT, bool TAB_LDS, int WPB>
+// LONGSEQ: 0 - the usual case: the bases of the loop are staged in LDS.
+//          1 - sequences longer than 4096 nt: the bases are read from HBM/L2 (no room for them beside the FFT buffers).
+//          2 - regions of more than 4096 positions (FFT size > 8192, whose two complex buffers exceed the LDS): the
+//              correlation is the exact direct form on multi-word bit masks - popcount(base mask AND shifted reversed base
+//              mask), the analogue of scipy's own direct branch (rafft/utils.py:121) - and the lag values live in a
+//              per-workgroup scratch in HBM instead of LDS.  Same integer pair counts, same fp64 values, same ranking.
+template <int NT, bool TAB_LDS, int WPB, int LONGSEQ = 0>
 __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 256 ? 3 : 2)) void expand_kernel(Dev d, int cls, int Pmax, int Lmax, int nmax, int brmax, int Kmax)
 {
     static_assert(WPB == 1 || NT == 64, "only the one-wavefront class packs several wavefronts into a workgroup");
+    static_assert(LONGSEQ == 0 || NT > 64, "long sequences never reach the one-wavefront class");
     extern __shared__ __align__(16) unsigned char lds_all[];
     const ExpandLds lay = expand_lds(Pmax, Lmax, nmax, brmax, Kmax, TAB_LDS, WPB);
     const int tid = threadIdx.x % NT;                 // position inside this region's team (a wavefront / the workgroup)
@@ -159,7 +201,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
     }
     uint16_t *pos = (uint16_t *)(lds + lay.off_pos);
     uint8_t *code = lds + lay.off_code;
-    uint8_t *Sl = lds + lay.off_S;
+    uint8_t *Sl_lds = lds + lay.off_S;
     uint32_t *brl = (uint32_t *)(lds + lay.off_br);
     uint16_t *rk = (uint16_t *)(lds + lay.off_rk);
     uint16_t *wnb = (uint16_t *)(lds + lay.off_nb);
@@ -209,10 +251,13 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
         const uint16_t *posg = d.pos + d.nd[nid].pos;
         const uint32_t *brg = d.br + d.nd[nid].br;
         const uint8_t *codes = d.codes + d.seq_off[sq];
+        const uint8_t *Sl = LONGSEQ ? codes : (const uint8_t *)Sl_lds;      // (the address space is known at compile time)
         const int m = 2 * n - 1;
         const int P = next_pow2_ge(m);
         const int logP = 31 - __clz(P);
+        const int Pk = LONGSEQ == 2 ? 0 : P;       // the lag values occupy 8 P bytes of region A - unless they live in HBM
         ESTAMP(0);   // fetch + header
+        if (eprof) { const int bk = n <= 8 ? 0 : n <= 16 ? 1 : n <= 32 ? 2 : n <= 64 ? 3 : n <= 128 ? 4 : 5; atomicAdd(&d.prof_e[cls * 16 + 8 + bk], 1ULL); }   // region sizes (diagnostic)
         const int Kp = d.K < m ? (d.K > 0 ? d.K : 0) : m;
 
         for (int rep_ = 0; rep_ < 1 + ((d.rep >> 4) & 1); rep_++) {
@@ -221,9 +266,9 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
             pos[t] = (uint16_t)p;
             code[t] = codes[p];
         }
-        {   // bases: only the span of this loop is ever looked at (closing pair, its neighbours inside, branches)
+        if (LONGSEQ == 0) {   // bases: only the span of this loop is ever looked at (closing pair, its neighbours inside, branches)
             const int x0 = ci < 0 ? 0 : ci, x1 = ci < 0 ? L : cj + 1;
-            for (int x = x0 + tid; x < x1; x += NT) Sl[x] = codes[x];
+            for (int x = x0 + tid; x < x1; x += NT) Sl_lds[x] = codes[x];
         }
         for (int t = tid; t < nbr; t += NT) brl[t] = brg[t];
         ESYNC();
@@ -238,7 +283,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
         const bool direct = (NT == 64) && n <= 64 && !d.force_fft;
         float2 *z1 = (float2 *)(lds + lay.offA);
         float2 *z2 = z1 + P;
-        if (!direct)
+        if (!direct && LONGSEQ != 2)
         for (int rep_ = 0; rep_ < 1 + (d.rep & 1); rep_++) {   // d.rep: profiling-only phase doubling
             for (int t = tid; t < P; t += NT) {
                 int c = t < n ? code[t] : 0;
@@ -351,9 +396,34 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
         const bool ranked = m > Kp;
         const bool selected = ranked && P >= 128;
         const bool inplace = (ranked && !selected) || (dbgrank && !selected);    // keys sorted in place, rk[] in rank order
-        double *keyv = (double *)(lds + lay.offA);
-        uint16_t *lagk = (uint16_t *)(lds + lay.offA + 8 * P);
-        if (direct) {
+        double *keyv = LONGSEQ == 2 ? d.big_keyv + (size_t)gteam * d.big_stride : (double *)(lds + lay.offA);
+        uint16_t *lagk = LONGSEQ == 2 ? (uint16_t *)(keyv + P) : (uint16_t *)(lds + lay.offA + 8 * P);
+        if (LONGSEQ == 2) {
+            // base masks of the region (the same arrays window_slide uses below, built once here) ...
+            const int W = (n + 63) >> 6;
+            unsigned long long *F = (unsigned long long *)(lds + lay.offA);
+            unsigned long long *R = F + 5 * W;
+            build_masks<NT>(F, R, W, n, code, pos, tid);
+            __syncthreads();
+            // ... and the three pair counts of every lag: bit ip of window(R_x, sft + 64 w) = base x at position k - ip
+            for (int k = tid; k < P; k += NT) {
+                double v = -INFINITY;
+                if (k < m) {
+                    const int sft = n - 1 - k;
+                    int cAU = 0, cGC = 0, cGU = 0;
+                    for (int w = 0; w < W; w++) {
+                        const unsigned long long xU = mask_window(R + 3 * W, W, (w << 6) + sft), xC = mask_window(R + 1 * W, W, (w << 6) + sft);
+                        const unsigned long long fA = F[0 * W + w], fG = F[2 * W + w];
+                        cAU += __popcll(fA & xU); cGC += __popcll(fG & xC); cGU += __popcll(fG & xU);
+                    }
+                    const double raw = (2.0 * (double)cAU) * d.au + (2.0 * (double)cGC) * d.gc + (2.0 * (double)cGU) * d.gu;
+                    const int nk = k < m - 1 - k ? k : m - 1 - k;
+                    v = raw / ((double)nk + 1.0);
+                }
+                keyv[k] = v;
+            }
+            __syncthreads();
+        } else if (direct) {
             const int c = tid < n ? code[tid] : 0;
             const unsigned long long mA = __ballot(c == 1), mC = __ballot(c == 2), mG = __ballot(c == 3), mU = __ballot(c == 4);
             const unsigned long long rU = __brevll(mU) >> (64 - n), rC = __brevll(mC) >> (64 - n);   // strand reversed
@@ -402,7 +472,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
         }
         ESTAMP(3);   // lag values
         if (selected) {
-            int *hist = (int *)(lds + lay.offA + 10 * P);          // 256 bins in the slack of region A
+            int *hist = (int *)(lds + lay.offA + (LONGSEQ == 2 ? lay.szA - 2048 : 10 * P));     // 256 bins in the slack of region A (its end when the masks are already there)
             int *shs = hist + 256;                                   // scan scratch [32]
             for (int rep_ = 0; rep_ < 1 + ((d.rep >> 1) & 1); rep_++) {
             auto ukey = [&](int i) -> unsigned long long {
@@ -519,7 +589,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
         // (chunking only for regions ranked by selection; the partial results go behind the lag values)
         const int C = (NT >= 256 && selected) ? max(1, min(8, NT / max(Kp, 1))) : 1;
         struct WsPart { double score; int nb, mi, mj, any; };
-        WsPart *parts = (WsPart *)(lds + lay.offA + 8 * P);       // big regions only: behind the lag values (and the masks)
+        WsPart *parts = (WsPart *)(lds + lay.offA + 8 * Pk);      // big regions only: behind the lag values (and the masks)
         // The diagonal of a lag as bit masks: pairing cells per pair type (base masks AND shifted reversed base
         // masks, 64 cells per word), contiguity with the previous cell as a mask too.  Only the pairing cells
         // are visited - zero cells never change the result: same fp64 recurrence on the visited cells in the
@@ -532,38 +602,15 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
             // Region A: behind the lag values (8 P bytes) unless those were sorted in place and are dead; the
             // partial results of chunked diagonals follow the masks.
             const int W = (n + 63) >> 6;
-            unsigned long long *F = (unsigned long long *)(lds + lay.offA + (inplace ? 0 : 8 * P));
+            unsigned long long *F = (unsigned long long *)(lds + lay.offA + (inplace ? 0 : 8 * Pk));
             unsigned long long *R = F + 5 * W;
             parts = (WsPart *)(R + 5 * W);
+            if (LONGSEQ != 2)          // (the direct correlation of the biggest regions has built them already)
             for (int rep_ = 0; rep_ < 1 + ((d.rep >> 7) & 1); rep_++) {
-            for (int wq = tid >> 6; wq < W; wq += NT / 64) {       // each wavefront ballots whole 64-bit words
-                const int t = wq * 64 + (tid & 63);
-                const int c0 = t < n ? code[t] : 0;
-                const unsigned long long bA = __ballot(c0 == 1), bC = __ballot(c0 == 2), bG = __ballot(c0 == 3), bU = __ballot(c0 == 4);
-                const unsigned long long bg = __ballot(t >= 1 && t < n && (int)pos[t] - (int)pos[t > 0 ? t - 1 : 0] == 1);
-                if ((tid & 63) == 0) { F[0 * W + wq] = bA; F[1 * W + wq] = bC; F[2 * W + wq] = bG; F[3 * W + wq] = bU; F[4 * W + wq] = bg; }
+                build_masks<NT>(F, R, W, n, code, pos, tid);
+                ESYNC();
             }
-            ESYNC();
-            // reversed strings: bit j of R = bit (n-1-j) of F.  Reverse the whole 64 W-bit string (word order and
-            // bit order), then shift the n live bits down: R bit j = T bit (j + 64 W - n) with T[w] = brev(F[W-1-w]);
-            // bits of F past n are zero.
-            for (int idx = tid; idx < 5 * W; idx += NT) {
-                const int which = idx / W, w = idx - which * W;
-                const int s0 = 64 * w + 64 * W - n, q = s0 >> 6, bsh = s0 & 63;
-                const unsigned long long lo = q < W ? __brevll(F[which * W + W - 1 - q]) : 0ULL;
-                const unsigned long long hi = q + 1 < W ? __brevll(F[which * W + W - 2 - q]) : 0ULL;
-                R[which * W + w] = bsh ? (lo >> bsh) | (hi << (64 - bsh)) : lo;
-            }
-            ESYNC();
-            }
-            // 64 bits of string X (W words) starting at bit `start` (may be negative / past the end -> zeros)
-            auto window = [&](const unsigned long long *X, int start) -> unsigned long long {
-                if (start >= 64 * W || start <= -64) return 0ULL;
-                const int q = start >> 6, bsh = start & 63;           // arithmetic shift: floor division
-                const unsigned long long lo = (q >= 0 && q < W) ? X[q] : 0ULL;
-                const unsigned long long hi = (q + 1 >= 0 && q + 1 < W) ? X[q + 1] : 0ULL;
-                return bsh ? (lo >> bsh) | (hi << (64 - bsh)) : lo;
-            };
+            auto window = [&](const unsigned long long *X, int start) -> unsigned long long { return mask_window(X, W, start); };
             for (int rep_ = 0; rep_ < 1 + ((d.rep >> 2) & 1); rep_++) {
             for (int q = tid; q < Kp * C; q += NT) {
                 const int r = q / C, c = q - r * C;
@@ -711,7 +758,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
         const double par_e = dcal_to_energy(par_dcal);
         // prefix sums of the branches' stem terms (region A is free now except, when nothing was ranked, the
         // lag values at its head), so that every loop below costs O(1) whatever its number of branches
-        int *pe_ext = (int *)(lds + lay.offA + (inplace ? 0 : 8 * P));
+        int *pe_ext = (int *)(lds + lay.offA + (inplace ? 0 : 8 * Pk));
         int *pe_ml = pe_ext + (nbr + 1);
         uint16_t *psp = (uint16_t *)(pe_ml + (nbr + 1));
         if (tid < 64) {
@@ -830,7 +877,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
         for (int rep_ = 0; rep_ < 1 + ((d.rep >> 6) & 1); rep_++) {
             // packed sort key of every kept candidate: (dE biased to unsigned) << 32 | lag rank.  (They take the place of
             // the branch prefix sums in region A, which dE is done with: 8 * Kp bytes behind the lag values.)
-            unsigned long long *ck = (unsigned long long *)(lds + lay.offA + (inplace ? 0 : 8 * P));
+            unsigned long long *ck = (unsigned long long *)(lds + lay.offA + (inplace ? 0 : 8 * Pk));
             for (int x = tid; x < nkept; x += NT) {
                 const int r = keep[x];
                 ck[x] = ((unsigned long long)((unsigned)dd[r] ^ 0x80000000u) << 32) | (unsigned)r;
@@ -1064,7 +1111,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
                     wpos += __popcll(bal);
                 }
                 if (pbase == ~0ULL) { pbase = 0; wpos = 0; nm = 0; }
-                if (wpos > MAX_PROD && gl == 0) atomicOr(&d.c->overflow, OVF_PROD);     // materialize_kernel's limit
+                if (wpos > d.max_prod && gl == 0) atomicOr(&d.c->overflow, OVF_PROD);     // materialize_kernel's limit
                 if (gl == 0) { d.st[sid].prod = pbase; d.st[sid].nprod = wpos; }
                 if (gl == 0 && wpos > 64) atomicMax(&d.c->max_nprod, (unsigned int)wpos);
                 for (int o = G >> 1; o > 0; o >>= 1) {
@@ -1507,10 +1554,12 @@ __device__ inline MatDesc mat_describe(const Dev &d, int pn, int selk)
 //  one-wavefront workgroups lives on the number of them a CU holds)
 __global__ __launch_bounds__(MAT_NT, RAFFT_MAT_WAVES) void materialize_kernel(Dev d)
 {
-    extern __shared__ __align__(16) uint8_t sdb[];
-    __shared__ int prod_node[MAX_PROD];
-    __shared__ int prod_cnt[MAX_PROD];
-    __shared__ int sel[MAX_PROD];
+    extern __shared__ __align__(16) uint8_t mat_dyn[];
+    // dynamic LDS: the productive-region lists (d.max_prod entries each), then the dot-bracket staging row
+    int *prod_node = (int *)mat_dyn;
+    int *prod_cnt = prod_node + d.max_prod;
+    int *sel = prod_cnt + d.max_prod;
+    uint8_t *sdb = (uint8_t *)(sel + d.max_prod);
     // per-tile descriptors (one lane per productive region) and the flat-copy prefix sums (two slots per region)
     __shared__ unsigned long long k_srcpos[64], k_srcbr[64];
     __shared__ int k_mi[64], k_mj[64], k_nb[64], k_lo0[64], k_loo[64], k_hio[64], k_newbr[64];
@@ -1525,7 +1574,7 @@ __global__ __launch_bounds__(MAT_NT, RAFFT_MAT_WAVES) void materialize_kernel(De
     const MatRec rec = d.mat[blockIdx.x];              // written by the beam step: no chain of look-ups to get started
     const int sid = rec.sid, sq = rec.sq, L = rec.L, my_dcal = rec.dcal;
     int mprod = rec.nprod;
-    if (mprod > MAX_PROD) mprod = MAX_PROD;
+    if (mprod > d.max_prod) mprod = d.max_prod;
     {
         const ProdEnt *pl = d.prod + rec.prod;             // the parent's productive regions (beam_step prepass)
         for (int k = tid; k < mprod; k += MAT_NT) { prod_node[k] = pl[k].node; prod_cnt[k] = (int)pl[k].cnt; sel[k] = 0; }
