@@ -65,6 +65,14 @@ struct Workspace {
         seen_cap, seen_cnt, st, prod, nd, nd_canon, pos, br, db, cand, looptab, trec, tsid,
         work0, work1, work2, work3, mat, counters,
         row_sid, row_off, out_db, out_dcal, row_off2, out_db2, out_dcal2, dbg, big;
+    void release_buffers()
+    {
+        for (Buf *b : {&codes, &seq_off, &seq_len, &beam, &beam_n, &done, &nsteps, &ch_parent, &ch_combo, &ch_dcal, &ch_h, &seen,
+                       &seen_off, &seen_cap, &seen_cnt, &st, &prod, &nd, &nd_canon, &pos, &br, &db, &cand, &looptab, &trec, &tsid,
+                       &work0, &work1, &work2, &work3, &mat, &counters, &row_sid, &row_off, &out_db, &out_dcal, &row_off2, &out_db2,
+                       &out_dcal2, &dbg, &big})
+            if (b->p) { hipError_t e_ = hipFree(b->p); (void)e_; b->p = nullptr; b->cap = 0; }
+    }
     size_t bytes() const
     {
         size_t t = 0;
@@ -91,6 +99,8 @@ struct Ctx {
     std::vector<PinBuf> pin_free;
     std::mutex pin_mu;                 // the pinned-chunk pool is used by the scheduler thread and by rafft_free_result
     std::vector<hipEvent_t> ev_free;   // timing events (scheduler thread only)
+    std::vector<void *> garbage;       // device buffers replaced by bigger ones: freed when no wave is running (hipFree waits
+    std::mutex gc_mu;                  //   for the whole device - tens of ms per regrown workspace while kernels are in flight)
     rafft_stats stats{};               // of the batch that was waited for last
     std::mutex mu;                     // serialises the C-ABI entry points
     // ---- scheduler: one thread drives every wave of every batch in flight (see `scheduler_main`)
@@ -109,8 +119,9 @@ int ensure(Buf &b, size_t bytes)
     if (bytes <= b.cap) return 0;
     const auto t0_ = std::chrono::steady_clock::now();
     const size_t old_cap = b.cap;
-    if (b.p) { hipError_t e = hipFree(b.p); (void)e; b.p = nullptr; b.cap = 0; }
-    size_t want = bytes + bytes / (old_cap ? 2 : 8) + 256;      // a buffer that had to grow once will grow again: leave room
+    if (b.p) { std::lock_guard<std::mutex> lk(g.gc_mu); g.garbage.push_back(b.p); b.p = nullptr; b.cap = 0; }
+    // a buffer that had to grow once will grow again: leave room (at most 256 MB of it)
+    size_t want = bytes + std::min<size_t>(bytes / (old_cap ? 2 : 8), (size_t)256 << 20) + 256;
     hipError_t e = hipMalloc(&b.p, want);
     if (getenv("RAFFT_TRACE_ALLOC")) fprintf(stderr, "[rafft] device buffer -> %.1f MB in %.3f ms\n", (double)want / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count());
     if (e != hipSuccess) {
@@ -456,6 +467,7 @@ struct Wave {
     std::vector<Span> &spans;
     const SeamIn *seam;
     size_t S = 0, sumL = 0, B = 0, bs_lds[2] = {0, 0}, mat_lds = RAFFT_MAX_LEN;
+    double reserve = 1.0;         // buffers are allocated for a wave this many times bigger (merged batches to come)
     bool longseq = false;         // a sequence longer than LDS_SEQ: its loops' bases are read from HBM, regions beyond 4096 positions exist
     unsigned dedupe_per_cu = 4;
     std::vector<int> off, len;
@@ -523,11 +535,13 @@ int Wave::setup()
     // reserve is small against the HBM (the benchmark set: 2.5 GB -> 10 GB).
     size_t Sr = S;
     Caps cr = c;
-    if (S >= 256 && S < merge_cap() && !seam) {
-        Sr = std::min(merge_cap(), 4 * S);
+    if (S < merge_cap() && !seam) {
+        // (a long-tail job has a few sequences per batch: sized once for 64 of them, whatever gets merged later)
+        Sr = S >= 256 ? std::min(merge_cap(), 4 * S) : std::max<size_t>(S, std::min<size_t>(64, 32 * S));
         Caps big = plan_caps(Sr, (size_t)((double)sumL * (double)Sr / (double)S), p, est);
         if (big.bytes <= (size_t)((double)::g.hbm_total * 0.06)) cr = big; else Sr = S;
     }
+    reserve = (double)Sr / (double)S;
     const size_t sumLr = Sr == S ? sumL : (size_t)((double)sumL * (double)Sr / (double)S);
 #define ENS(buf, bytes) do { if (int rc_ = ensure(g.buf, (bytes))) return rc_; } while (0)
     ENS(codes, sumLr + 16); ENS(seq_off, Sr * 4); ENS(seq_len, Sr * 4);
@@ -604,8 +618,8 @@ int Wave::setup()
         HIPCHK(hipMemset(ws_buf, 0, S * 24));
         d.prof_ws = ws_buf;
         static unsigned long long *pe_buf = nullptr;
-        if (!pe_buf) HIPCHK(hipMalloc((void **)&pe_buf, NCLS * 16 * 8));
-        HIPCHK(hipMemset(pe_buf, 0, NCLS * 16 * 8));
+        if (!pe_buf) HIPCHK(hipMalloc((void **)&pe_buf, NCLS * 32 * 8));
+        HIPCHK(hipMemset(pe_buf, 0, NCLS * 32 * 8));
         d.prof_e = pe_buf;
     }
 
@@ -776,9 +790,9 @@ int Wave::emit_rows(size_t first, size_t count, bool early, double *t_gather)
     }
     char *all_db = (char *)chunk.p;
     int *all_dcal = (int *)((char *)chunk.p + dcal_off);
-    if (int rc = ensure(b_rec, recs.size() * sizeof(OutRec))) return rc;
-    if (int rc = ensure(b_db, (size_t)tot_bytes)) return rc;
-    if (int rc = ensure(b_dc, nrows * 4)) return rc;
+    if (int rc = ensure(b_rec, (size_t)((double)(recs.size() * sizeof(OutRec)) * reserve))) return rc;
+    if (int rc = ensure(b_db, (size_t)((double)tot_bytes * reserve))) return rc;
+    if (int rc = ensure(b_dc, (size_t)((double)(nrows * 4) * reserve))) return rc;
     HIPCHK(hipMemcpyAsync(b_rec.p, recs.data(), recs.size() * sizeof(OutRec), hipMemcpyHostToDevice, st));
     Span sp{next_event(), next_event(), 3};
     SPAN_REC(sp.a, st, sp.kind);
@@ -863,7 +877,7 @@ int Wave::finish()
     const double tl_copy = since(tw2);
     const long long tot_bytes = last_rows_bytes;
     if (d.prof_e) {
-        unsigned long long pe[NCLS * 16];
+        unsigned long long pe[NCLS * 32];
         HIPCHK(hipMemcpy(pe, d.prof_e, sizeof pe, hipMemcpyDeviceToHost));
         static const char *nm[8] = {"fetch+header", "LDS fill", "FFT", "lag values", "ranking", "window_slide", "dE", "emit"};
         {
@@ -876,15 +890,18 @@ int Wave::finish()
         }
         for (int c = 1; c < NCLS; c++) {
             unsigned long long t = 0;
-            for (int k = 0; k < 8; k++) t += pe[c * 16 + k];
+            for (int k = 0; k < 8; k++) t += pe[c * 32 + k];
             fprintf(stderr, "[rafft] expand class %d phase shares (first wavefront of every workgroup, %llu Mcycles):", c, t / 1000000);
-            for (int k = 0; k < 8; k++) fprintf(stderr, " %s %.1f%%", nm[k], t ? 100.0 * (double)pe[c * 16 + k] / (double)t : 0.0);
+            for (int k = 0; k < 8; k++) fprintf(stderr, " %s %.1f%%", nm[k], t ? 100.0 * (double)pe[c * 32 + k] / (double)t : 0.0);
             fprintf(stderr, "\n");
-            unsigned long long hn = 0;
-            for (int k = 8; k < 14; k++) hn += pe[c * 16 + k];
-            fprintf(stderr, "[rafft] expand class %d region sizes (sampled): n<=8 %.1f%%  <=16 %.1f%%  <=32 %.1f%%  <=64 %.1f%%  <=128 %.1f%%  >128 %.1f%%\n", c,
-                    hn ? 100.0 * pe[c * 16 + 8] / hn : 0.0, hn ? 100.0 * pe[c * 16 + 9] / hn : 0.0, hn ? 100.0 * pe[c * 16 + 10] / hn : 0.0,
-                    hn ? 100.0 * pe[c * 16 + 11] / hn : 0.0, hn ? 100.0 * pe[c * 16 + 12] / hn : 0.0, hn ? 100.0 * pe[c * 16 + 13] / hn : 0.0);
+            unsigned long long hn = 0, hc_ = 0;
+            for (int k = 0; k < 6; k++) { hn += pe[c * 32 + 8 + k]; hc_ += pe[c * 32 + 16 + k]; }
+            static const char *bn[6] = {"n<=8", "<=16", "<=32", "<=64", "<=128", ">128"};
+            fprintf(stderr, "[rafft] expand class %d by region size (share of regions / share of cycles / kcycles per region):", c);
+            for (int k = 0; k < 6; k++)
+                fprintf(stderr, "  %s %.1f%% / %.1f%% / %.1f", bn[k], hn ? 100.0 * pe[c * 32 + 8 + k] / hn : 0.0, hc_ ? 100.0 * pe[c * 32 + 16 + k] / hc_ : 0.0,
+                        pe[c * 32 + 8 + k] ? (double)pe[c * 32 + 16 + k] / (double)pe[c * 32 + 8 + k] / 1e3 : 0.0);
+            fprintf(stderr, "\n");
         }
     }
     if (d.prof_ws) {
@@ -1044,6 +1061,23 @@ static void finalize_batch(const std::shared_ptr<Batch> &bp)
     g.qcv_done.notify_all();
 }
 
+static void free_garbage()
+{
+    std::vector<void *> junk;
+    { std::lock_guard<std::mutex> lk(g.gc_mu); junk.swap(g.garbage); }
+    for (void *p : junk) { hipError_t e_ = hipFree(p); (void)e_; }
+}
+
+// Nothing in flight: workspaces that grew beyond a quarter of the HBM for some huge batch are given back (other processes
+// may share the card; the next batch allocates what it needs).
+static void trim_workspaces()
+{
+    size_t held = 0;
+    for (int i = 0; i < MAX_PIPES; i++) held += g.ws[i].bytes();
+    if (held <= g.hbm_total / 4) return;
+    for (int i = 0; i < MAX_PIPES; i++) g.ws[i].release_buffers();
+}
+
 static void scheduler_main()
 {
     { hipError_t e_ = hipSetDevice(g.device); (void)e_; }
@@ -1064,8 +1098,18 @@ static void scheduler_main()
     };
     for (;;) {
         {
+            if (n_active_batches == 0) free_garbage();            // nothing in flight: the device is idle, hipFree is cheap
             std::unique_lock<std::mutex> lk(g.qmu);
-            if (n_active_batches == 0 && g.submitted.empty()) g.qcv_sched.wait(lk, [] { return !g.submitted.empty(); });
+            if (n_active_batches == 0 && g.submitted.empty()) {
+                // idle for a second: give back workspaces that grew huge (re-allocating 80 GB costs seconds, so not between
+                // back-to-back batches)
+                if (!g.qcv_sched.wait_for(lk, std::chrono::seconds(1), [] { return !g.submitted.empty(); })) {
+                    lk.unlock();
+                    trim_workspaces();
+                    lk.lock();
+                    g.qcv_sched.wait(lk, [] { return !g.submitted.empty(); });
+                }
+            }
             while (!g.submitted.empty()) {
                 std::shared_ptr<Batch> bp = g.submitted.front();
                 g.submitted.pop_front();
@@ -1147,7 +1191,12 @@ static void scheduler_main()
                 size_t others = 0;
                 for (int k = 0; k < MAX_PIPES; k++) if (k != w) others += g.ws[k].bytes();
                 const size_t budget = (size_t)((double)g.hbm_total * 0.55 / 2.0);
-                const bool fits_now = std::max(cc.bytes, g.ws[w].bytes()) + others <= (size_t)((double)g.hbm_total * 0.85);
+                bool fits_now = std::max(cc.bytes, g.ws[w].bytes()) + others <= (size_t)((double)g.hbm_total * 0.85);
+                // waves whose arenas take more than a tenth of the HBM run one at a time (the halves of a split job would
+                // otherwise fill two workspaces of that size)
+                const size_t big_wave = g.hbm_total / 10;
+                if (cc.bytes > big_wave)
+                    for (int k = 0; k < MAX_PIPES; k++) if (slot[k].wave && slot[k].wave->c.bytes > big_wave) fits_now = false;
                 if ((cc.bytes > budget || (!fits_now && n_running == 0)) && job.seqs.size() > 1) {
                     const size_t h = job.seqs.size() / 2;          // too big for one wave: two jobs, one after the other
                     Job a{std::vector<SeqIn>(job.seqs.begin(), job.seqs.begin() + h), job.est, job.depth, job.members, true};

@@ -136,7 +136,7 @@ struct Dev {
     Counters *c;
     DebugOut dbg;
     unsigned long long *prof; int prof_seq;   // diagnostic stamps of beam_step_kernel (RAFFT_TRACE=3)
-    unsigned long long *prof_e;               // RAFFT_TRACE=3: expand_kernel phase cycles [NCLS][16]
+    unsigned long long *prof_e;               // RAFFT_TRACE=3: expand_kernel phase cycles, regions and cycles by region size [NCLS][32]
     unsigned long long *prof_ws;              // RAFFT_TRACE=3: per sequence [cycles, chunks, max cycles of one step]
     int rep;                     // profiling only (RAFFT_REP env): bit k doubles phase k of expand_kernel
 };

@@ -257,7 +257,8 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
         const int logP = 31 - __clz(P);
         const int Pk = LONGSEQ == 2 ? 0 : P;       // the lag values occupy 8 P bytes of region A - unless they live in HBM
         ESTAMP(0);   // fetch + header
-        if (eprof) { const int bk = n <= 8 ? 0 : n <= 16 ? 1 : n <= 32 ? 2 : n <= 64 ? 3 : n <= 128 ? 4 : 5; atomicAdd(&d.prof_e[cls * 16 + 8 + bk], 1ULL); }   // region sizes (diagnostic)
+        const int size_bk = n <= 8 ? 0 : n <= 16 ? 1 : n <= 32 ? 2 : n <= 64 ? 3 : n <= 128 ? 4 : 5;      // (diagnostic: regions and cycles by size)
+        const unsigned long long t_region0 = eprof ? clock64() : 0;
         const int Kp = d.K < m ? (d.K > 0 ? d.K : 0) : m;
 
         for (int rep_ = 0; rep_ < 1 + ((d.rep >> 4) & 1); rep_++) {
@@ -924,8 +925,11 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
             if (d.dbg.n_ranked) d.dbg.n_ranked[1] = nkept;
         }
         ESTAMP(7);   // emit
+        if (eprof) { atomicAdd(&d.prof_e[cls * 32 + 8 + size_bk], 1ULL); atomicAdd(&d.prof_e[cls * 32 + 16 + size_bk], (unsigned long long)(clock64() - t_region0)); }
     }
-    if (eprof) for (int k = 0; k < 8; k++) atomicAdd(&d.prof_e[cls * 16 + k], eacc[k]);
+    if (eprof) {
+        for (int k = 0; k < 8; k++) atomicAdd(&d.prof_e[cls * 32 + k], eacc[k]);
+    }
 #undef ESTAMP
     if (tid == 0 && st_items) {
         atomicAdd(&d.c->n_expand, st_items);
