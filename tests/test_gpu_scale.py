@@ -62,11 +62,16 @@ def test_gpu_cfg3_benchmark_set_properties(bench_rows):
 
 
 def test_gpu_cfg2_full_1000_random_L200():
+    """BASELINE configs[1]: all 1000 sequences, the whole final beam of each against the oracle (worker processes)"""
+    from _oracle_pool import fold_many
     rng = np.random.default_rng(200)
     seqs = ["".join(rng.choice(list("ACGU"), 200)) for _ in range(1000)]
+    want = fold_many([(s, 100, 50, 1000, False) for s in seqs])
     res = rafft_amd.fold_batch(seqs, 100, 50, 1000)
     for s, beam in zip(seqs, res):
         check_structures(s, beam, 50)
+    bad = [k for k, (beam, w) in enumerate(zip(res, want)) if [(x.str_struct, x.dcal) for x in beam] != w]
+    assert not bad, (len(bad), bad[:10])
     flat = [(s, x.str_struct, x.dcal) for s, beam in zip(seqs, res) for x in beam]
     got, st = R.eval_structures([f[0] for f in flat], [f[1] for f in flat])
     assert got == [f[2] for f in flat]
