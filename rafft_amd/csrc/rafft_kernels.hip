@@ -240,10 +240,13 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
             fetch_base = (unsigned)misc[8];
             fetch_left = FETCH;
         }
-        const unsigned item = fetch_base;
+        // (the work item is the same for the whole team: saying so - readfirstlane - turns the header loads below into scalar
+        //  loads, off the vector memory queue and out of the vector registers; only for the one-wavefront class, where a
+        //  team IS a wavefront)
+        const unsigned item = NT == 64 ? (unsigned)__builtin_amdgcn_readfirstlane((int)fetch_base) : fetch_base;
         fetch_base++; fetch_left--;
         if (item >= n_items) break;
-        const int nid = d.work[cls][item];
+        const int nid = NT == 64 ? __builtin_amdgcn_readfirstlane(d.work[cls][item]) : d.work[cls][item];
         const int sq = d.nd[nid].seq;
         const int L = d.seq_len[sq];
         const int n = d.nd[nid].n, ci = d.nd[nid].ci, cj = d.nd[nid].cj, nbr = d.nd[nid].nbr;
