@@ -101,6 +101,7 @@ struct Ctx {
     std::vector<hipEvent_t> ev_free;   // timing events (scheduler thread only)
     std::vector<void *> garbage;       // device buffers replaced by bigger ones: freed when no wave is running (hipFree waits
     std::mutex gc_mu;                  //   for the whole device - tens of ms per regrown workspace while kernels are in flight)
+    std::mutex ws_mu;                  // held by the seam calls that borrow workspace 0 on the caller's thread (vs idle trimming)
     rafft_stats stats{};               // of the batch that was waited for last
     std::mutex mu;                     // serialises the C-ABI entry points
     // ---- scheduler: one thread drives every wave of every batch in flight (see `scheduler_main`)
@@ -1072,6 +1073,8 @@ static void free_garbage()
 // may share the card; the next batch allocates what it needs).
 static void trim_workspaces()
 {
+    std::unique_lock<std::mutex> lk(g.ws_mu, std::try_to_lock);
+    if (!lk.owns_lock()) return;              // a seam call is using workspace 0 right now
     size_t held = 0;
     for (int i = 0; i < MAX_PIPES; i++) held += g.ws[i].bytes();
     if (held <= g.hbm_total / 4) return;
@@ -1430,10 +1433,14 @@ static int parse_db(const char *seq, const char *db, int L, std::vector<int16_t>
     return stk.empty() ? 0 : RAFFT_ERR_STRUCT;
 }
 
+static thread_local bool g_ws_locked_by_me = false;     // rafft_expand_node holds ws_mu across its nested evaluation
+
 static int eval_structures_impl(int n, const char *const *seqs, const char *const *dbs, int *dcal_out, int *status_out, double temp = 37.0)
 {
     if (int rc = init_ctx(-1)) return rc;
     drain();                                   // (g.mu is held: nothing new is submitted meanwhile)
+    std::unique_lock<std::mutex> ws_lk(g.ws_mu, std::defer_lock);
+    if (!g_ws_locked_by_me) ws_lk.lock();
     if (int rc = ensure_tables(temp)) return rc;
     if (int rc = init_ws(g.ws[0])) return rc;
     std::vector<long long> off(n);
@@ -1605,6 +1612,9 @@ int rafft_expand_node(const rafft_params *p, const char *seq, const char *db, co
 {
     std::lock_guard<std::mutex> lk(g.mu);
     if (int rc = init_ctx(-1)) return rc;
+    drain();
+    std::lock_guard<std::mutex> ws_lk(g.ws_mu);
+    struct Flag { Flag() { g_ws_locked_by_me = true; } ~Flag() { g_ws_locked_by_me = false; } } flag_;
     const int L = (int)strlen(seq);
     if (L == 0 || L > RAFFT_MAX_LEN || n < 1 || n > L) return fail(RAFFT_ERR_PARAM, "bad node");
     std::vector<int16_t> pt;
