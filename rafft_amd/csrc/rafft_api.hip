@@ -124,7 +124,7 @@ int ensure(Buf &b, size_t bytes)
     // a buffer that had to grow once will grow again: leave room (at most 256 MB of it)
     size_t want = bytes + std::min<size_t>(bytes / (old_cap ? 2 : 8), (size_t)256 << 20) + 256;
     hipError_t e = hipMalloc(&b.p, want);
-    if (getenv("RAFFT_TRACE_ALLOC")) fprintf(stderr, "[rafft] device buffer -> %.1f MB in %.3f ms\n", (double)want / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count());
+    if (getenv("RAFFT_TRACE_ALLOC")) fprintf(stderr, "[rafft] t=%.3f device buffer -> %.1f MB in %.3f ms\n", std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(), (double)want / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count());
     if (e != hipSuccess) {
         b.p = nullptr;
         return fail(RAFFT_ERR_HIP, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
@@ -398,7 +398,7 @@ PinBuf pin_acquire(size_t bytes)
     PinBuf b;
     const auto t0_ = std::chrono::steady_clock::now();
     if (hipHostMalloc(&b.p, want, hipHostMallocDefault) != hipSuccess) { b.p = nullptr; return b; }
-    if (getenv("RAFFT_TRACE_ALLOC")) fprintf(stderr, "[rafft] pinned chunk %.1f MB in %.3f ms (pool %zu)\n", (double)want / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count(), g.pin_free.size());
+    if (getenv("RAFFT_TRACE_ALLOC")) fprintf(stderr, "[rafft] t=%.3f pinned chunk %.1f MB in %.3f ms (pool %zu)\n", std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(), (double)want / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count(), g.pin_free.size());
     b.cap = want;
     return b;
 }
