@@ -228,7 +228,7 @@ def main():
     # (a fresh box hands over a GPU in its low-power state: half a second of the same work, untimed, before the W warm-up
     #  steps, so that the clocks have ramped whatever W is)
     t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < 0.5:
+    while time.perf_counter() - t_pre < float(os.environ.get("BENCH_PREWARM_S", "0.5")):
         mine.run(4)
     mine.run(args.warmup)
     mine.agg = {}

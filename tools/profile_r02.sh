@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --no-cpu-baseline --no-extras"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $B --steps 20 --warmup 5 > $OUT/trace_bench.json 2> $OUT/trace.err
 echo "trace done" >> $OUT/progress.log
-export BENCH_DEPTH=1
+export BENCH_DEPTH=1 BENCH_PREWARM_S=0     # PMC passes: synchronous calls, exactly steps + warmup = 4 batches
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- $B --steps 3 --warmup 1 > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
 echo "fetch done" >> $OUT/progress.log
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- $B --steps 3 --warmup 1 > $OUT/pmc_write.json 2> $OUT/pmc_write.err
