@@ -236,7 +236,7 @@ int class_cfg(int K, int maxL, ClsCfg out[NCLS])
         if (expand_lds(cls1_P(), CLS01_L, cls1_P() / 2, cls1_br(), Kmax1, true, wpb1).total > 160 * 1024) wpb1 = 1;
     }
     const int WPB[NCLS] = {1, wpb1, 1, 1};
-    const bool TAB[NCLS] = {false, (tabm & 2) != 0 || WPB[1] > 1, (tabm & 4) != 0, (tabm & 8) != 0};
+    const bool TAB[NCLS] = {false, (tabm & 2) != 0 || WPB[1] > 1, (tabm & 4) != 0, false};    // (LDS tables come with LDS twiddles: FFT sizes <= CLS2_P only)
     for (int c = 0; c < NCLS; c++) {
         int nmax = c == 0 ? BIG_N : P[c] / 2;
         int Kmax = std::max(1, std::min(K, c == 0 ? 2 * BIG_N - 1 : P[c] - 1));
@@ -571,6 +571,7 @@ int Wave::setup()
     if (const char *e = getenv("RAFFT_FORCE_FFT")) if (atoi(e)) d.force_fft = 1;   // tests: FFT path for short regions too
     d.rl_cap = RL_CAP;
     longseq = maxL > LDS_SEQ;
+    d.pos_packed = longseq ? 0 : 1;          // 12 bits of position leave room for the base code (Dev::pos_packed)
     d.max_prod = longseq ? MAX_PROD_LONG : MAX_PROD;
     if (longseq) {       // scratch of the class for regions beyond 4096 positions: lag values (fp64) + lag column, per workgroup
         d.big_stride = (size_t)2 * BIG_N + (size_t)2 * BIG_N / 4;
@@ -619,8 +620,8 @@ int Wave::setup()
         HIPCHK(hipMemset(ws_buf, 0, S * 24));
         d.prof_ws = ws_buf;
         static unsigned long long *pe_buf = nullptr;
-        if (!pe_buf) HIPCHK(hipMalloc((void **)&pe_buf, NCLS * 32 * 8));
-        HIPCHK(hipMemset(pe_buf, 0, NCLS * 32 * 8));
+        if (!pe_buf) HIPCHK(hipMalloc((void **)&pe_buf, NCLS * PROF_E * 8));
+        HIPCHK(hipMemset(pe_buf, 0, NCLS * PROF_E * 8));
         d.prof_e = pe_buf;
     }
 
@@ -684,6 +685,11 @@ int Wave::issue_step()
             if (bound < grid) grid = (unsigned)bound;
         }
         if (int rc = launch_expand_cls(d, cls, cf, grid, cs)) return rc;
+        static const int twice = getenv("RAFFT_TWICE") ? atoi(getenv("RAFFT_TWICE")) : 0;   // diagnostic: the same work again, caches warm
+        if (twice && cls == 1) {
+            HIPCHK(hipMemsetAsync((char *)g.counters.p + offsetof(Counters, next_work) + 4 * cls, 0, 4, cs));
+            if (int rc = launch_expand_cls(d, cls, cf, grid, cs)) return rc;
+        }
         if (cls == 1) bt.stats.n_expand_launches++;       // launches of the dominant kernel (ms_expand is their sum)
         SPAN_REC(sp.b, cs, sp.kind);
         spans.push_back(sp);
@@ -878,7 +884,7 @@ int Wave::finish()
     const double tl_copy = since(tw2);
     const long long tot_bytes = last_rows_bytes;
     if (d.prof_e) {
-        unsigned long long pe[NCLS * 32];
+        unsigned long long pe[NCLS * PROF_E];
         HIPCHK(hipMemcpy(pe, d.prof_e, sizeof pe, hipMemcpyDeviceToHost));
         static const char *nm[8] = {"fetch+header", "LDS fill", "FFT", "lag values", "ranking", "window_slide", "dE", "emit"};
         {
@@ -891,18 +897,34 @@ int Wave::finish()
         }
         for (int c = 1; c < NCLS; c++) {
             unsigned long long t = 0;
-            for (int k = 0; k < 8; k++) t += pe[c * 32 + k];
-            fprintf(stderr, "[rafft] expand class %d phase shares (first wavefront of every workgroup, %llu Mcycles):", c, t / 1000000);
-            for (int k = 0; k < 8; k++) fprintf(stderr, " %s %.1f%%", nm[k], t ? 100.0 * (double)pe[c * 32 + k] / (double)t : 0.0);
+            for (int k = 0; k < 8; k++) t += pe[c * PROF_E + k];
+            fprintf(stderr, "[rafft] expand class %d phase shares (lane 0 of every wavefront, %llu Mcycles):", c, t / 1000000);
+            for (int k = 0; k < 8; k++) fprintf(stderr, " %s %.1f%%", nm[k], t ? 100.0 * (double)pe[c * PROF_E + k] / (double)t : 0.0);
             fprintf(stderr, "\n");
             unsigned long long hn = 0, hc_ = 0;
-            for (int k = 0; k < 6; k++) { hn += pe[c * 32 + 8 + k]; hc_ += pe[c * 32 + 16 + k]; }
+            for (int k = 0; k < 6; k++) { hn += pe[c * PROF_E + 8 + k]; hc_ += pe[c * PROF_E + 16 + k]; }
             static const char *bn[6] = {"n<=8", "<=16", "<=32", "<=64", "<=128", ">128"};
             fprintf(stderr, "[rafft] expand class %d by region size (share of regions / share of cycles / kcycles per region):", c);
             for (int k = 0; k < 6; k++)
-                fprintf(stderr, "  %s %.1f%% / %.1f%% / %.1f", bn[k], hn ? 100.0 * pe[c * 32 + 8 + k] / hn : 0.0, hc_ ? 100.0 * pe[c * 32 + 16 + k] / hc_ : 0.0,
-                        pe[c * 32 + 8 + k] ? (double)pe[c * 32 + 16 + k] / (double)pe[c * 32 + 8 + k] / 1e3 : 0.0);
+                fprintf(stderr, "  %s %.1f%% / %.1f%% / %.1f", bn[k], hn ? 100.0 * pe[c * PROF_E + 8 + k] / hn : 0.0, hc_ ? 100.0 * pe[c * PROF_E + 16 + k] / hc_ : 0.0,
+                        pe[c * PROF_E + 8 + k] ? (double)pe[c * PROF_E + 16 + k] / (double)pe[c * PROF_E + 8 + k] / 1e3 : 0.0);
             fprintf(stderr, "\n");
+            if (c == 1) {
+                fprintf(stderr, "[rafft]   class 1, regions without any stem / without a kept candidate (share of the size class):");
+                for (int k = 0; k < 6; k++) {
+                    const double nreg = (double)pe[c * PROF_E + 8 + k];
+                    fprintf(stderr, "  %s %.1f%% / %.1f%%", bn[k], nreg ? 100.0 * pe[c * PROF_E + 80 + k] / nreg : 0.0, nreg ? 100.0 * pe[c * PROF_E + 88 + k] / nreg : 0.0);
+                }
+                fprintf(stderr, "\n");
+            }
+            for (int b = 0; b < 6; b++) {
+                unsigned long long tb = 0;
+                for (int k = 0; k < 8; k++) tb += pe[c * PROF_E + 32 + b * 8 + k];
+                if (!tb) continue;
+                fprintf(stderr, "[rafft]   class %d, regions %s:", c, bn[b]);
+                for (int k = 0; k < 8; k++) fprintf(stderr, " %s %.1f%%", nm[k], 100.0 * (double)pe[c * PROF_E + 32 + b * 8 + k] / (double)tb);
+                fprintf(stderr, "\n");
+            }
         }
     }
     if (d.prof_ws) {
@@ -950,7 +972,13 @@ int run_seam(Batch &bt, const std::vector<SeqIn> &one, const SeamIn &sm)
     if (int rc = w.setup()) return rc;
     Workspace &W = g.ws[0];
     // overwrite the root region of sequence 0 with the given loop of the given structure
-    HIPCHK(hipMemcpy(W.pos.p, sm.pos.data(), sm.pos.size() * 2, hipMemcpyHostToDevice));
+    {
+        std::vector<uint16_t> packed(sm.pos);
+        if (w.d.pos_packed) {
+            for (auto &v : packed) v = (uint16_t)(v | (kBaseCode[(unsigned char)one[0].s[v]] << 12));
+        }
+        HIPCHK(hipMemcpy(W.pos.p, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+    }
     if (!sm.br.empty()) HIPCHK(hipMemcpy(W.br.p, sm.br.data(), sm.br.size() * 4, hipMemcpyHostToDevice));
     int n = (int)sm.pos.size(), nbr = (int)sm.br.size();
     {
@@ -959,7 +987,7 @@ int run_seam(Batch &bt, const std::vector<SeqIn> &one, const SeamIn &sm)
         root.n = n; root.nbr = nbr; root.ci = sm.ci; root.cj = sm.cj; root.pdcal = sm.pdcal;
         HIPCHK(hipMemcpy(W.nd.p, &root, sizeof root, hipMemcpyHostToDevice));
     }
-    int cls = node_class(n, one[0].len, nbr, 0, w.d.cls1_P, w.d.cls1_br);
+    int cls = node_class(n, (sm.ci < 0 || one[0].len > LDS_SEQ) ? one[0].len : sm.cj + 1 - sm.ci, nbr, 0, w.d.cls1_P, w.d.cls1_br);
     int zero = 0;
     memset(&w.hc.n_work, 0, sizeof w.hc.n_work);
     w.hc.n_work[cls] = 1;

@@ -44,6 +44,7 @@ static_assert(sizeof(Cand) == 32, "Cand must be 32 bytes");
 #define NSHARD 64
 #define SEEN0 8192      // initial slots of a sequence's `seen` set (grows x2 by rehash)
 #define NCLS 4
+#define PROF_E 96      // RAFFT_TRACE=3: 64-bit diagnostic slots per expand class (Dev::prof_e)
 struct ShardCtr { unsigned long long v; unsigned long long pad[7]; };   // one 64-byte line each
 
 // structure row: one beam survivor (see the file header)
@@ -59,8 +60,8 @@ static_assert(sizeof(StRec) == 128, "StRec is two cache lines");
 
 // region row: one loop of one structure (see the file header)
 struct alignas(64) NodeRec {
-    int32_t seq, pdcal, n, ci, cj, nbr, ncand, pad;
-    uint64_t pos, br, cand, pad2;
+    int32_t seq, pdcal, n, ci, cj, nbr, ncand, L;      // (L, soff: the sequence's length and offset into the base codes, so that
+    uint64_t pos, br, cand, soff;                      //  expanding a region needs no second look-up keyed on `seq`)
 };
 static_assert(sizeof(NodeRec) == 64, "NodeRec must be one cache line");
 
@@ -124,6 +125,8 @@ struct Dev {
     unsigned long long *looptab; uint64_t looptab_cap;   // power of two
     // arenas
     uint16_t *pos; uint64_t pos_cap;
+    int pos_packed;              // no sequence beyond 4096 nt: an entry of `pos` is position | base code << 12 (the code rides along:
+                                 // expanding a region reads it with the position instead of through a dependent second load)
     uint32_t *br; uint64_t br_cap;
     uint8_t *db; uint64_t db_cap;
     Cand *cand; uint64_t cand_cap;
@@ -136,7 +139,7 @@ struct Dev {
     Counters *c;
     DebugOut dbg;
     unsigned long long *prof; int prof_seq;   // diagnostic stamps of beam_step_kernel (RAFFT_TRACE=3)
-    unsigned long long *prof_e;               // RAFFT_TRACE=3: expand_kernel phase cycles, regions and cycles by region size [NCLS][32]
+    unsigned long long *prof_e;               // RAFFT_TRACE=3: expand_kernel phase cycles, regions and cycles by region size, phase cycles by region size [NCLS][PROF_E]
     unsigned long long *prof_ws;              // RAFFT_TRACE=3: per sequence [cycles, chunks, max cycles of one step]
     int rep;                     // profiling only (RAFFT_REP env): bit k doubles phase k of expand_kernel
 };
@@ -158,7 +161,10 @@ struct Dev {
 #define RL_CAP 1024        // beam_step_kernel: regions with >= 2 candidates of all beam members, kept in LDS
 
 __host__ __device__ inline int next_pow2_ge(int x) { int p = 2; while (p < x) p <<= 1; return p; }
-__host__ __device__ inline int node_class(int n, int L, int nbr, int merge_cls = 0, int cls1_P = CLS1_P, int cls1_br = CLS1_BR)
+// `span`: the stretch of the sequence the loop lies in (closing pair to closing pair; the whole sequence for the exterior
+// loop) - the bases the expand kernel stages in LDS.  The one-wavefront class has room for CLS01_L of them, so a small
+// loop of a LONG sequence (the inside of a hairpin of a 16S rRNA) still is one wavefront's work, not a workgroup's.
+__host__ __device__ inline int node_class(int n, int span, int nbr, int merge_cls = 0, int cls1_P = CLS1_P, int cls1_br = CLS1_BR)
 {
     // few regions in this step (the tail of a batch): all of them go to one kernel, the widest one that is
     // configured - one launch and one region per workgroup instead of three nearly empty kernels in a row
@@ -168,7 +174,7 @@ __host__ __device__ inline int node_class(int n, int L, int nbr, int merge_cls =
     if (P > MAX_P || nbr > MAX_BR) return 0;
     if (merge_cls == 3) return 3;
     if (merge_cls == 2) return P <= CLS2_P ? 2 : 3;
-    if (L <= CLS01_L && P <= cls1_P && nbr <= cls1_br) return 1;
+    if (span <= CLS01_L && P <= cls1_P && nbr <= cls1_br) return 1;
     if (P <= CLS2_P) return 2;
     return 3;
 }

@@ -191,7 +191,8 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
         const int *src = (const int *)&d.T->s;
         for (int i = threadIdx.x; i < (int)(sizeof(SmallT) / 4); i += NT * WPB) dst[i] = src[i];
         T = (const SmallT *)dst;
-        if (Pmax <= CLS2_P) {
+        {   // (always, so that the compiler knows `tw` for an LDS pointer: a pointer that may be either makes every twiddle
+            //  read a FLAT load, and a flat load waits for every global load in flight; the host keeps Pmax <= CLS2_P here)
             float2 *twl = (float2 *)(shared + lay.off_tw);
             for (int m = threadIdx.x; m < Pmax / 2; m += NT * WPB) twl[m] = d.tw[m * (MAX_P / Pmax)];
             tw = twl;
@@ -226,8 +227,9 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
     // two atomics with a returned value (a full L2 round trip each) are paid once per several regions.
     // (only when there is plenty of work: with fewer regions than workgroups every region gets its own)
     const bool eprof = d.prof_e != nullptr && tid == 0;      // diagnostic phase stamps (RAFFT_TRACE=3)
-    unsigned long long eacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, et = eprof ? clock64() : 0;
-#define ESTAMP(k) do { if (eprof) { const unsigned long long tn_ = clock64(); eacc[k] += tn_ - et; et = tn_; } } while (0)
+    unsigned long long eacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ereg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, et = eprof ? clock64() : 0;
+    unsigned eregions = 0;
+#define ESTAMP(k) do { if (eprof) { const unsigned long long tn_ = clock64(); eacc[k] += tn_ - et; ereg[k] = tn_ - et; et = tn_; } } while (0)
     const unsigned FETCH = (NT == 64 && n_items > 4u * n_teams) ? 4u : 1u;
     unsigned fetch_base = 0, fetch_left = 0;                 // uniform across the workgroup
     unsigned long long slab_base = 0; unsigned slab_left = 0;   // thread 0 only
@@ -247,32 +249,34 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
         fetch_base++; fetch_left--;
         if (item >= n_items) break;
         const int nid = NT == 64 ? __builtin_amdgcn_readfirstlane(d.work[cls][item]) : d.work[cls][item];
-        const int sq = d.nd[nid].seq;
-        const int L = d.seq_len[sq];
+        const int L = d.nd[nid].L;                 // (the record carries its sequence's length and offset: no look-up keyed on `seq`)
         const int n = d.nd[nid].n, ci = d.nd[nid].ci, cj = d.nd[nid].cj, nbr = d.nd[nid].nbr;
         const int par_dcal = d.nd[nid].pdcal;
         const uint16_t *posg = d.pos + d.nd[nid].pos;
         const uint32_t *brg = d.br + d.nd[nid].br;
-        const uint8_t *codes = d.codes + d.seq_off[sq];
-        const uint8_t *Sl = LONGSEQ ? codes : (const uint8_t *)Sl_lds;      // (the address space is known at compile time)
+        const uint8_t *codes = d.codes + d.nd[nid].soff;
+        // (LDS copy of the bases: only the loop's span [sx0, sx1) is staged, at Sl_lds[x - sx0]; the pointer is shifted so
+        //  that it still takes sequence positions - sx0 < 4096 never exceeds the offset of that area, the shifted pointer stays
+        //  inside the LDS.  The address space is known at compile time either way.)
+        const int sx0 = ci < 0 ? 0 : ci, sx1 = ci < 0 ? L : cj + 1;
+        const uint8_t *Sl = LONGSEQ ? codes : (const uint8_t *)Sl_lds - sx0;
         const int m = 2 * n - 1;
         const int P = next_pow2_ge(m);
         const int logP = 31 - __clz(P);
         const int Pk = LONGSEQ == 2 ? 0 : P;       // the lag values occupy 8 P bytes of region A - unless they live in HBM
-        ESTAMP(0);   // fetch + header
         const int size_bk = n <= 8 ? 0 : n <= 16 ? 1 : n <= 32 ? 2 : n <= 64 ? 3 : n <= 128 ? 4 : 5;      // (diagnostic: regions and cycles by size)
+        ESTAMP(0);   // fetch + header
         const unsigned long long t_region0 = eprof ? clock64() : 0;
         const int Kp = d.K < m ? (d.K > 0 ? d.K : 0) : m;
 
         for (int rep_ = 0; rep_ < 1 + ((d.rep >> 4) & 1); rep_++) {
         for (int t = tid; t < n; t += NT) {
-            int p = posg[t];
-            pos[t] = (uint16_t)p;
-            code[t] = codes[p];
+            const int p = posg[t];
+            if (LONGSEQ == 0 && d.pos_packed) { pos[t] = (uint16_t)(p & 0x0FFF); code[t] = (uint8_t)(p >> 12); }   // (Dev::pos_packed)
+            else { pos[t] = (uint16_t)p; code[t] = codes[p]; }
         }
         if (LONGSEQ == 0) {   // bases: only the span of this loop is ever looked at (closing pair, its neighbours inside, branches)
-            const int x0 = ci < 0 ? 0 : ci, x1 = ci < 0 ? L : cj + 1;
-            for (int x = x0 + tid; x < x1; x += NT) Sl_lds[x] = codes[x];
+            for (int x = sx0 + tid; x < sx1; x += NT) Sl_lds[x - sx0] = codes[x];
         }
         for (int t = tid; t < nbr; t += NT) brl[t] = brg[t];
         ESYNC();
@@ -928,10 +932,19 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
             if (d.dbg.n_ranked) d.dbg.n_ranked[1] = nkept;
         }
         ESTAMP(7);   // emit
-        if (eprof) { atomicAdd(&d.prof_e[cls * 32 + 8 + size_bk], 1ULL); atomicAdd(&d.prof_e[cls * 32 + 16 + size_bk], (unsigned long long)(clock64() - t_region0)); }
+        if (NT == 64 && d.prof_e != nullptr) {         // diagnostic: regions without any candidate stem / without a kept one, by size
+            int has = 0;
+            for (int r = tid; r < Kp; r += NT) has |= wnb[r] > 0 ? 1 : 0;
+            const bool anystem = __ballot(has) != 0ULL;
+            if (tid == 0 && !anystem) atomicAdd(&d.prof_e[cls * PROF_E + 80 + size_bk], 1ULL);
+            if (tid == 0 && nkept == 0) atomicAdd(&d.prof_e[cls * PROF_E + 88 + size_bk], 1ULL);
+        }
+        if (eprof && (eregions++ & 7) == 0)            // phase cycles by region size: a sample (every flush is eight more atomics in flight)
+            for (int k = 0; k < 8; k++) atomicAdd(&d.prof_e[cls * PROF_E + 32 + size_bk * 8 + k], ereg[k]);
+        if (eprof) { atomicAdd(&d.prof_e[cls * PROF_E + 8 + size_bk], 1ULL); atomicAdd(&d.prof_e[cls * PROF_E + 16 + size_bk], (unsigned long long)(clock64() - t_region0)); }
     }
     if (eprof) {
-        for (int k = 0; k < 8; k++) atomicAdd(&d.prof_e[cls * 32 + k], eacc[k]);
+        for (int k = 0; k < 8; k++) atomicAdd(&d.prof_e[cls * PROF_E + k], eacc[k]);
     }
 #undef ESTAMP
     if (tid == 0 && st_items) {
@@ -1544,7 +1557,8 @@ __device__ inline MatDesc mat_describe(const Dev &d, int pn, int selk)
     const Cand cd = d.cand[coff + selk];
     m.mi = cd.mi; m.mj = cd.mj; m.nb = cd.nb;
     const uint16_t *pp = d.pos + m.srcpos;
-    m.a0 = pp[m.mi]; m.b0 = pp[m.mj]; m.ao = pp[m.mi - m.nb + 1]; m.bo = pp[m.mj + m.nb - 1];
+    const int pm = d.pos_packed ? 0x0FFF : 0xFFFF;
+    m.a0 = pp[m.mi] & pm; m.b0 = pp[m.mj] & pm; m.ao = pp[m.mi - m.nb + 1] & pm; m.bo = pp[m.mj + m.nb - 1] & pm;
     cd.get_cuts(m.lo0, m.hi0, m.loo, m.hio);      // where the stem cuts the branch list (found by expand_kernel)
     m.flags = 0; m.nnod = 0; m.npos_in = m.npos_out = m.nbr_in = m.nbr_out = 0;
     if (m.mj - m.mi > 1) { m.flags |= 1; m.nnod++; m.npos_in = m.mj - m.mi - 1; m.nbr_in = m.hi0 - m.lo0; }
@@ -1580,6 +1594,8 @@ __global__ __launch_bounds__(MAT_NT, RAFFT_MAT_WAVES) void materialize_kernel(De
 #define MSTAMP(k) do { if (mprof) { const unsigned long long tn_ = clock64(); macc[k] += tn_ - mt; mt = tn_; } } while (0)
     const MatRec rec = d.mat[blockIdx.x];              // written by the beam step: no chain of look-ups to get started
     const int sid = rec.sid, sq = rec.sq, L = rec.L, my_dcal = rec.dcal;
+    const uint64_t soff = (uint64_t)d.seq_off[sq];
+    const int pmask = d.pos_packed ? 0x0FFF : 0xFFFF;
     int mprod = rec.nprod;
     if (mprod > d.max_prod) mprod = d.max_prod;
     {
@@ -1677,12 +1693,14 @@ __global__ __launch_bounds__(MAT_NT, RAFFT_MAT_WAVES) void materialize_kernel(De
             const unsigned long long poff = pbase + run_pos + p0, boff = bbase + run_br + b0;
             if (md.flags & 1) {
                 d.nd[nid].seq = sq; d.nd[nid].pdcal = my_dcal; d.nd[nid].pos = poff; d.nd[nid].n = md.npos_in;
+                d.nd[nid].L = L; d.nd[nid].soff = soff;
                 d.nd[nid].ci = md.a0; d.nd[nid].cj = md.b0; d.nd[nid].br = boff; d.nd[nid].nbr = md.nbr_in;
                 d.nd[nid].ncand = -1; d.nd[nid].cand = 0; d.nd_canon[nid] = nid;
                 nid++;
             }
             if (md.flags & 2) {
                 d.nd[nid].seq = sq; d.nd[nid].pdcal = my_dcal; d.nd[nid].pos = poff + md.npos_in; d.nd[nid].n = md.npos_out;
+                d.nd[nid].L = L; d.nd[nid].soff = soff;
                 d.nd[nid].ci = md.ci; d.nd[nid].cj = md.cj; d.nd[nid].br = boff + md.nbr_in; d.nd[nid].nbr = md.nbr_out;
                 d.nd[nid].ncand = -1; d.nd[nid].cand = 0; d.nd_canon[nid] = nid;
             }
@@ -1720,7 +1738,7 @@ __global__ __launch_bounds__(MAT_NT, RAFFT_MAT_WAVES) void materialize_kernel(De
             while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (ns[mid] <= f) lo = mid; else hi = mid - 1; }
             const int t = f - ns[lo];
             const uint16_t *pp = d.pos + k_srcpos[lo];
-            sdb[pp[k_mi[lo] - t]] = '('; sdb[pp[k_mj[lo] + t]] = ')';
+            sdb[pp[k_mi[lo] - t] & pmask] = '('; sdb[pp[k_mj[lo] + t] & pmask] = ')';
         }
         run_nodes += tn; run_pos += tp; run_br += tb;
         __syncthreads();
@@ -1798,8 +1816,13 @@ __global__ __launch_bounds__(256) void dedupe_kernel(Dev d)
             }
             if (canon == nid) {
                 // a stem needs two unpaired positions: a lone position (bulge remnant) has no candidates
-                if (d.nd[nid].n < 2) d.nd[nid].ncand = 0;
-                else cls = node_class(d.nd[nid].n, d.seq_len[d.nd[nid].seq], d.nd[nid].nbr, d.merge_cls, d.cls1_P, d.cls1_br);
+                const int n = d.nd[nid].n;
+                if (n < 2) d.nd[nid].ncand = 0;
+                else {
+                    // (sequences beyond 4096 nt keep out of the one-wavefront class whatever the span: see expand_kernel's Sl)
+                    const int Ls = d.nd[nid].L, span = (d.nd[nid].ci < 0 || Ls > LDS_SEQ) ? Ls : d.nd[nid].cj + 1 - d.nd[nid].ci;
+                    cls = node_class(n, span, d.nd[nid].nbr, d.merge_cls, d.cls1_P, d.cls1_br);
+                }
             }
             else { d.nd_canon[nid] = canon; aliases++; }
         }
@@ -1827,13 +1850,17 @@ __global__ void init_roots_kernel(Dev d)
     const int L = d.seq_len[sq];
     // structure sq / node sq are the unfolded structure and its single region (rafft.py:224-231)
     const unsigned long long off = (unsigned long long)d.seq_off[sq];
-    for (int x = tid; x < L; x += blockDim.x) { d.db[off + x] = '.'; d.pos[off + x] = (uint16_t)x; }
+    for (int x = tid; x < L; x += blockDim.x) {
+        d.db[off + x] = '.';
+        d.pos[off + x] = (uint16_t)(d.pos_packed ? x | (d.codes[off + x] << 12) : x);
+    }
 
     if (tid == 0) {
         d.st[sq].seq = sq; d.st[sq].dcal = 0; d.st[sq].h1 = 0; d.st[sq].h2 = 0;
         d.st[sq].db = off; d.st[sq].node0 = sq; d.st[sq].nnodes = L > 0 ? 1 : 0; d.st[sq].cursor = 0; d.st[sq].total = 0;
         d.st[sq].parent = -1; d.st[sq].combo = 0;
         d.nd[sq].seq = sq; d.nd[sq].pdcal = 0; d.nd[sq].pos = off; d.nd[sq].n = L; d.nd[sq].ci = -1; d.nd[sq].cj = L;
+        d.nd[sq].L = L; d.nd[sq].soff = off;
         d.nd[sq].br = 0; d.nd[sq].nbr = 0; d.nd_canon[sq] = sq;
         d.nd[sq].ncand = -1; d.nd[sq].cand = 0;
         d.beam[(size_t)sq * d.B] = sq; d.beam_n[sq] = 1; d.nsteps[sq] = 0;
