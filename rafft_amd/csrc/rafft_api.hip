@@ -917,14 +917,6 @@ int Wave::finish()
                 }
                 fprintf(stderr, "\n");
             }
-            for (int b = 0; b < 6; b++) {
-                unsigned long long tb = 0;
-                for (int k = 0; k < 8; k++) tb += pe[c * PROF_E + 32 + b * 8 + k];
-                if (!tb) continue;
-                fprintf(stderr, "[rafft]   class %d, regions %s:", c, bn[b]);
-                for (int k = 0; k < 8; k++) fprintf(stderr, " %s %.1f%%", nm[k], 100.0 * (double)pe[c * PROF_E + 32 + b * 8 + k] / (double)tb);
-                fprintf(stderr, "\n");
-            }
         }
     }
     if (d.prof_ws) {

@@ -227,9 +227,8 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
     // two atomics with a returned value (a full L2 round trip each) are paid once per several regions.
     // (only when there is plenty of work: with fewer regions than workgroups every region gets its own)
     const bool eprof = d.prof_e != nullptr && tid == 0;      // diagnostic phase stamps (RAFFT_TRACE=3)
-    unsigned long long eacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ereg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, et = eprof ? clock64() : 0;
-    unsigned eregions = 0;
-#define ESTAMP(k) do { if (eprof) { const unsigned long long tn_ = clock64(); eacc[k] += tn_ - et; ereg[k] = tn_ - et; et = tn_; } } while (0)
+    unsigned long long eacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, et = eprof ? clock64() : 0;
+#define ESTAMP(k) do { if (eprof) { const unsigned long long tn_ = clock64(); eacc[k] += tn_ - et; et = tn_; } } while (0)
     const unsigned FETCH = (NT == 64 && n_items > 4u * n_teams) ? 4u : 1u;
     unsigned fetch_base = 0, fetch_left = 0;                 // uniform across the workgroup
     unsigned long long slab_base = 0; unsigned slab_left = 0;   // thread 0 only
@@ -939,8 +938,6 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
             if (tid == 0 && !anystem) atomicAdd(&d.prof_e[cls * PROF_E + 80 + size_bk], 1ULL);
             if (tid == 0 && nkept == 0) atomicAdd(&d.prof_e[cls * PROF_E + 88 + size_bk], 1ULL);
         }
-        if (eprof && (eregions++ & 7) == 0)            // phase cycles by region size: a sample (every flush is eight more atomics in flight)
-            for (int k = 0; k < 8; k++) atomicAdd(&d.prof_e[cls * PROF_E + 32 + size_bk * 8 + k], ereg[k]);
         if (eprof) { atomicAdd(&d.prof_e[cls * PROF_E + 8 + size_bk], 1ULL); atomicAdd(&d.prof_e[cls * PROF_E + 16 + size_bk], (unsigned long long)(clock64() - t_region0)); }
     }
     if (eprof) {

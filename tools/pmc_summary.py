@@ -65,6 +65,10 @@ def main(src, dst, tag):
         issue[k] = {"launches_profiled": ns[k], "kernel_seconds": round(t, 6),
                     "wave_instructions": int(n_inst), "issue_frac": round(n_inst / slots, 4),
                     "valu_busy_frac_at_2_cycles_per_wave64_op": round(2 * c["SQ_INSTS_VALU"] / slots, 4),
+                    # measured pipe occupancy (second pass): SQ_ACTIVE_INST_* tick in quad-cycles while an instruction of that
+                    # kind executes - for VALU it equals the instruction count, i.e. a vector instruction holds its SIMD 4 cycles
+                    "pipe_busy_frac_measured": {n[len("SQ_ACTIVE_INST_"):].lower(): round(4.0 * scale * extra[n] / slots, 4)
+                                                for n in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS") if n in extra},
                     "insts": {n: int(c[n]) for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS")},
                     "insts_second_pass": {n: int(v) for n, v in extra.items() if n.startswith("SQ_INSTS")},
                     "wave_cycle_shares": {"active": round(c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], 4),
@@ -77,7 +81,7 @@ def main(src, dst, tag):
                      "bench.py --steps 3 --warmup 1 --no-extras with synchronous calls (BENCH_DEPTH=1); tools/profile_r02.sh",
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE halving, MI355X_MICROARCH.md)",
            "clock_hz_used": clk, "kernels": kernels, "issue": issue,
-           "issue_roofline": dict(kernel=ex, **{k: issue[ex][k] for k in ("issue_frac", "valu_busy_frac_at_2_cycles_per_wave64_op",
+           "issue_roofline": dict(kernel=ex, **{k: issue[ex][k] for k in ("issue_frac", "valu_busy_frac_at_2_cycles_per_wave64_op", "pipe_busy_frac_measured",
                                                                              "wave_cycle_shares", "mean_waves_resident_per_simd")}) if ex else None}
     json.dump(out, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
     for k, v in sorted(issue.items(), key=lambda kv: -kv[1]["kernel_seconds"])[:8]:

@@ -9,6 +9,7 @@ rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --no-cpu-baseline --no-extras"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $B --steps 20 --warmup 5 > $OUT/trace_bench.json 2> $OUT/trace.err
+python3 $R/tools/cu_share.py $OUT/trace/t_kernel_trace.csv > $OUT/cu_share.json || true
 echo "trace done" >> $OUT/progress.log
 export BENCH_DEPTH=1 BENCH_PREWARM_S=0     # PMC passes: synchronous calls, exactly steps + warmup = 4 batches
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- $B --steps 3 --warmup 1 > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
