@@ -20,6 +20,8 @@ for case in range(n_cases):
     w = [(3.0, 2.0, 1.0), (3.0, 2.0, 1.0), (1.0, 1.0, 1.0), (2.5, 1.5, 0.25), (3.0, 2.0, 0.0)][int(rng.integers(0, 5))]
     alpha = [list("ACGU"), list("GC"), list("AU"), list("GGGCCCAU"), list("ACGUN")][int(rng.integers(0, 5))]
     lens = [int(x) for x in rng.integers(5, 260, size=6)] + [int(rng.integers(300, 700))]
+    if ms <= 20:      # a long sequence too: its small loops take the one-wavefront class by their span, its big ones the wide classes
+        lens.append(int(rng.integers(1300, 2600)))
     seqs = ["".join(rng.choice(alpha, n)) for n in lens]
     for mode in (0, 1):
         if mode == 0:
