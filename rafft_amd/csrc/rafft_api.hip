@@ -274,7 +274,7 @@ int launch_expand(const Dev &d, int cls, const ClsCfg &cf, unsigned n_teams, hip
     return 0;
 }
 
-int launch_expand_cls(const Dev &d, int cls, const ClsCfg cf[NCLS], unsigned n_blocks, hipStream_t st)
+int launch_expand_cls(const Dev &d, int cls, const ClsCfg cf[NCLS], unsigned n_blocks, hipStream_t st, bool dry = false)
 {
     const bool longseq = cf[2].Lmax == 0;          // (class_cfg: no LDS copy of the bases)
     if (cls == 0) return launch_expand<512, false, 1, 2>(d, 0, cf[0], n_blocks, st);
@@ -282,7 +282,7 @@ int launch_expand_cls(const Dev &d, int cls, const ClsCfg cf[NCLS], unsigned n_b
     if (longseq && cls >= 2) return launch_expand<512, false, 1, 1>(d, cls, cf[cls], n_blocks, st);
     if (cls == 1) {
         if (cf[1].wpb == 4) return launch_expand<64, true, 4>(d, 1, cf[1], n_blocks, st);
-        if (cf[1].wpb == 12) return launch_expand<64, true, 12>(d, 1, cf[1], n_blocks, st);
+        if (cf[1].wpb == 12) return launch_expand<64, true, 12>(d, dry ? 0x101 : 1, cf[1], n_blocks, st);
         return cf[1].tab ? launch_expand<64, true>(d, 1, cf[1], n_blocks, st) : launch_expand<64, false>(d, 1, cf[1], n_blocks, st);
     }
     if (cls == 2) {
@@ -688,7 +688,7 @@ int Wave::issue_step()
         static const int twice = getenv("RAFFT_TWICE") ? atoi(getenv("RAFFT_TWICE")) : 0;   // diagnostic: the same work again, caches warm
         if (twice && cls == 1) {
             HIPCHK(hipMemsetAsync((char *)g.counters.p + offsetof(Counters, next_work) + 4 * cls, 0, 4, cs));
-            if (int rc = launch_expand_cls(d, cls, cf, grid, cs)) return rc;
+            if (int rc = launch_expand_cls(d, cls, cf, grid, cs, twice == 2)) return rc;
         }
         if (cls == 1) bt.stats.n_expand_launches++;       // launches of the dominant kernel (ms_expand is their sum)
         SPAN_REC(sp.b, cs, sp.kind);
@@ -909,6 +909,7 @@ int Wave::finish()
                 fprintf(stderr, "  %s %.1f%% / %.1f%% / %.1f", bn[k], hn ? 100.0 * pe[c * PROF_E + 8 + k] / hn : 0.0, hc_ ? 100.0 * pe[c * PROF_E + 16 + k] / hc_ : 0.0,
                         pe[c * PROF_E + 8 + k] ? (double)pe[c * PROF_E + 16 + k] / (double)pe[c * PROF_E + 8 + k] / 1e3 : 0.0);
             fprintf(stderr, "\n");
+            if (pe[c * PROF_E + 32]) fprintf(stderr, "[rafft]   class %d: draining the previous region's stores (RAFFT_REP=256): %llu Mcycles\n", c, pe[c * PROF_E + 32] / 1000000);
             if (c == 1) {
                 fprintf(stderr, "[rafft]   class 1, regions without any stem / without a kept candidate (share of the size class):");
                 for (int k = 0; k < 6; k++) {

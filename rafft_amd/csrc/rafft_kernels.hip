@@ -171,8 +171,11 @@ __device__ __forceinline__ void wave_sync()
 //              mask), the analogue of scipy's own direct branch (rafft/utils.py:121) - and the lag values live in a
 //              per-workgroup scratch in HBM instead of LDS.  Same integer pair counts, same fp64 values, same ranking.
 template <int NT, bool TAB_LDS, int WPB, int LONGSEQ = 0>
-__global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 256 ? 3 : 2)) void expand_kernel(Dev d, int cls, int Pmax, int Lmax, int nmax, int brmax, int Kmax)
+__global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 256 ? 3 : 2)) void expand_kernel(Dev d, int cls_arg, int Pmax, int Lmax, int nmax, int brmax, int Kmax)
 {
+    const int cls = cls_arg & 0xFF;
+    const bool dry = (cls_arg & 0x100) != 0;      // diagnostic (RAFFT_TWICE=2): everything but the result stores
+
     static_assert(WPB == 1 || NT == 64, "only the one-wavefront class packs several wavefronts into a workgroup");
     static_assert(LONGSEQ == 0 || NT > 64, "long sequences never reach the one-wavefront class");
     extern __shared__ __align__(16) unsigned char lds_all[];
@@ -235,6 +238,11 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
 
     for (;;) {
         ESYNC();                       // previous region's LDS use is over
+        if (d.prof_e != nullptr && (d.rep & 256)) {      // diagnostic: how long the previous region's stores take to drain
+            const unsigned long long t0_ = clock64();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (tid == 0) atomicAdd(&d.prof_e[cls * PROF_E + 32], (unsigned long long)(clock64() - t0_));
+        }
         if (fetch_left == 0) {
             if (tid == 0) misc[8] = (int)atomicAdd(&d.c->next_work[cls], FETCH);
             ESYNC();
@@ -921,11 +929,11 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
                 cd.ddcal = my; cd.mi = (uint16_t)mi; cd.mj = (uint16_t)mj; cd.nb = (uint16_t)nb;
                 cd.set_cuts(br_lower(brl, nbr, pos[mi]), br_lower(brl, nbr, pos[mj]), br_lower(brl, nbr, pos[mi - nb + 1]), br_lower(brl, nbr, pos[mj + nb - 1]));
                 cd.h1 = h1; cd.h2 = h2;
-                d.cand[cbase + rank] = cd;
+                if (!dry) d.cand[cbase + rank] = cd;
                 if (d.dbg.kept) d.dbg.kept[rank] = r;
             }
         }
-        if (tid == 0) {
+        if (tid == 0 && !dry) {
             d.nd[nid].cand = cbase;
             d.nd[nid].ncand = ovf ? 0 : nkept;
             if (d.dbg.n_ranked) d.dbg.n_ranked[1] = nkept;

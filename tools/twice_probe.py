@@ -7,7 +7,7 @@ seqs = [l.split("\t")[1] for l in gzip.open("tests/golden/bench_inputs.tsv.gz", 
 for i in range(3): rafft_amd.fold_batch(seqs, 100, 50, 1000)
 print(json.dumps(rafft_amd.last_stats()))
 '''
-for tw in ("0", "1"):
+for tw in ("0", "1", "2"):
     env = dict(os.environ, RAFFT_TWICE=tw, RAFFT_SERIAL="1", RAFFT_SPANS="2")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip().split("\n")[-1]
     st = json.loads(out)
