@@ -225,18 +225,22 @@ def main():
                   "energy_mae_kcal_per_mol": abs_err / max(rows, 1)}
 
     # ---------------------------------------------------------------- the timed region
+    # Steps in flight: PIPELINE_DEPTH at one GPU.  With N ranks a step hands every rank 1/N of the set, so N times as
+    # many steps are kept in flight - the scheduler then still folds waves of the size the single GPU folds
+    # (~9000 sequences), instead of N times smaller ones whose lock-step steps no longer fill the chip.
+    DEPTH_RUN = PIPELINE_DEPTH * max(1, world)
     # (a fresh box hands over a GPU in its low-power state: half a second of the same work, untimed, before the W warm-up
     #  steps, so that the clocks have ramped whatever W is)
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < float(os.environ.get("BENCH_PREWARM_S", "0.5")):
-        mine.run(4)
-    mine.run(args.warmup)
+        mine.run(4, depth=DEPTH_RUN)
+    mine.run(args.warmup, depth=DEPTH_RUN)
     mine.agg = {}
     barrier()
     if os.environ.get("RAFFT_TRACE_ALLOC"):
         print(f"[bench] timed region starts t={time.monotonic():.3f}", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
-    mine.run(args.steps)
+    mine.run(args.steps, depth=DEPTH_RUN)
     barrier()
     el = allmax(time.perf_counter() - t0)
     if os.environ.get("RAFFT_TRACE_ALLOC"):
@@ -381,7 +385,7 @@ def main():
                        "nb_mode": args.nb_mode, "max_stack": args.max_stack, "max_branch": args.max_branch,
                        "sequences_per_step": n, "sequences_on_rank0": mine.n,
                        "parallelism": (f"LPT sequence shards x{world}, no collective" if world > 1 else "1 GPU"),
-                       "batches_in_flight": PIPELINE_DEPTH},
+                       "batches_in_flight": DEPTH_RUN},
             "roofline": {"bound": "hbm", "kernel": "expand_kernel<64,true,12> (regions with FFT size <= 512; 12 wavefronts per workgroup)", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": traffic, "traffic_source": traffic_src,
