@@ -212,7 +212,9 @@ int init_ctx(int device)
 struct ClsCfg { int nt, Pmax, Lmax, nmax, brmax, Kmax, lds, grid; bool tab; int wpb; };   // grid: teams (wavefronts of the packed one-wavefront class, workgroups otherwise)
 
 // limits of the one-wavefront class: its LDS per wavefront (hence its occupancy) follows from them
-static int cls1_P() { static const int v = getenv("RAFFT_CLS1_P") ? std::max(128, std::min(next_pow2_ge(atoi(getenv("RAFFT_CLS1_P"))), CLS1_P)) : CLS1_P; return v; }
+// (not below 256: the kernel addresses the staged bases through a pointer shifted back by up to 4095 positions, which must stay
+//  inside the LDS - the 16 * P bytes in front of that area see to it)
+static int cls1_P() { static const int v = getenv("RAFFT_CLS1_P") ? std::max(256, std::min(next_pow2_ge(atoi(getenv("RAFFT_CLS1_P"))), CLS1_P)) : CLS1_P; return v; }
 static int cls1_br() { return std::min(CLS1_BR, (8 * cls1_P() - 16) / 10 - 1); }
 
 int class_cfg(int K, int maxL, ClsCfg out[NCLS])
