@@ -249,6 +249,8 @@ int class_cfg(int K, int maxL, ClsCfg out[NCLS])
             return fail(RAFFT_ERR_PARAM, "nb_mode too large for the LDS scratch of the class for regions beyond 4096 positions");
         if (c >= 1 && (10 * (BR[c] + 1) + 16 > 8 * P[c] || 2 * P[c] + 1152 + 16 > 8 * P[c] || (NT[c] > 64 && NT[c] * 24 > 8 * P[c])))
             return fail(RAFFT_ERR_PARAM, "internal: expand LDS plan does not fit its size class");
+        if (c >= 1 && LM[c] > 0 && l.off_S < LDS_SEQ)      // (expand_kernel's Sl: the staged bases are addressed by sequence position)
+            return fail(RAFFT_ERR_PARAM, "internal: the LDS copy of the bases sits too low for its shifted pointer");
         int per_cu = std::max(1, std::min(32 / (NT[c] / 64), WPB[c] * ((160 * 1024) / l.total)));      // teams per CU
         if (c == 1 && getenv("RAFFT_C1_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(getenv("RAFFT_C1_PER_CU"))));
         out[c] = {NT[c], P[c], LM[c], nmax, BR[c], Kmax, l.total, g.n_cu * per_cu, TAB[c], WPB[c]};
