@@ -343,10 +343,15 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
                 }
                 ESYNC();
             }
-            for (int k = tid; k <= (P >> 1); k += NT) {   // separate the packed real spectra, multiply
-                int km = (P - k) & (P - 1);
-                int jk = (int)(__brev((unsigned)k) >> (32 - logP));
-                int jm = (int)(__brev((unsigned)km) >> (32 - logP));
+            // separate the packed real spectra, multiply.  The spectra sit in bit-reversed order: walking k = 0, 1, 2 ... would
+            // send the 64 lanes of a wavefront to addresses P/2, P/4 ... apart - one LDS bank for all of them.  So the walk is
+            // over the POSITIONS: the even ones hold exactly the k < P/2 (top bit of k = lowest bit of the position), position 1
+            // holds k = P/2; neighbours in the walk are neighbours in LDS, and the mirror position of -k runs the other way.
+            for (int t = tid; t <= (P >> 1); t += NT) {
+                const int jk = t == (P >> 1) ? 1 : 2 * t;
+                const int k = (int)(__brev((unsigned)jk) >> (32 - logP));
+                const int km = (P - k) & (P - 1);
+                const int jm = (int)(__brev((unsigned)km) >> (32 - logP));
                 float2 A1 = z1[jk], B1 = z1[jm], A2 = z2[jk], B2 = z2[jm];
                 float2 Fa = make_float2(0.5f * (A1.x + B1.x), 0.5f * (A1.y - B1.y));
                 float2 Fg = make_float2(0.5f * (A1.y + B1.y), -0.5f * (A1.x - B1.x));
