@@ -59,17 +59,17 @@ struct Workspace {
     hipStream_t cls_stream[NCLS] = {};
     hipStream_t copy_stream = nullptr;   // result rows of sequences that finish early leave while the others still fold
     hipEvent_t ev_fork = nullptr, ev_join[NCLS] = {}, ev_hot = nullptr;
-    void *hot = nullptr;                 // pinned, 256 B
+    void *hot = nullptr;                 // pinned, 512 B
     // named device buffers (grow-only)
     Buf codes, seq_off, seq_len, beam, beam_n, done, nsteps, ch_parent, ch_combo, ch_dcal, ch_h, seen, seen_off,
         seen_cap, seen_cnt, st, prod, nd, nd_canon, pos, br, db, cand, looptab, trec, tsid,
-        work0, work1, work2, work3, mat, counters,
+        work0, work1, work2, work3, work4, work5, mat, counters,
         row_sid, row_off, out_db, out_dcal, row_off2, out_db2, out_dcal2, dbg, big;
     void release_buffers()
     {
         for (Buf *b : {&codes, &seq_off, &seq_len, &beam, &beam_n, &done, &nsteps, &ch_parent, &ch_combo, &ch_dcal, &ch_h, &seen,
                        &seen_off, &seen_cap, &seen_cnt, &st, &prod, &nd, &nd_canon, &pos, &br, &db, &cand, &looptab, &trec, &tsid,
-                       &work0, &work1, &work2, &work3, &mat, &counters, &row_sid, &row_off, &out_db, &out_dcal, &row_off2, &out_db2,
+                       &work0, &work1, &work2, &work3, &work4, &work5, &mat, &counters, &row_sid, &row_off, &out_db, &out_dcal, &row_off2, &out_db2,
                        &out_dcal2, &dbg, &big})
             if (b->p) { hipError_t e_ = hipFree(b->p); (void)e_; b->p = nullptr; b->cap = 0; }
     }
@@ -78,7 +78,7 @@ struct Workspace {
         size_t t = 0;
         for (const Buf *b : {&codes, &seq_off, &seq_len, &beam, &beam_n, &done, &nsteps, &ch_parent, &ch_combo, &ch_dcal, &ch_h, &seen,
                              &seen_off, &seen_cap, &seen_cnt, &st, &prod, &nd, &nd_canon, &pos, &br, &db, &cand, &looptab, &trec, &tsid,
-                             &work0, &work1, &work2, &work3, &mat, &counters, &row_sid, &row_off, &out_db, &out_dcal, &row_off2, &out_db2,
+                             &work0, &work1, &work2, &work3, &work4, &work5, &mat, &counters, &row_sid, &row_off, &out_db, &out_dcal, &row_off2, &out_db2,
                              &out_dcal2, &dbg, &big})
             t += b->cap;
         return t;
@@ -172,7 +172,8 @@ int init_ws(Workspace &w)
     HIPCHK(hipStreamCreateWithFlags(&w.copy_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&w.ev_hot, hipEventDisableTiming));
-    HIPCHK(hipHostMalloc(&w.hot, 256, hipHostMallocDefault));
+    static_assert(offsetof(Counters, node) <= 512, "hot counters must fit the pinned read-back slot");
+    HIPCHK(hipHostMalloc(&w.hot, 512, hipHostMallocDefault));
     w.ready = true;
     return 0;
 }
@@ -217,13 +218,13 @@ struct ClsCfg { int nt, Pmax, Lmax, nmax, brmax, Kmax, lds, grid; bool tab; int 
 static int cls1_P() { static const int v = getenv("RAFFT_CLS1_P") ? std::max(256, std::min(next_pow2_ge(atoi(getenv("RAFFT_CLS1_P"))), CLS1_P)) : CLS1_P; return v; }
 static int cls1_br() { return std::min(CLS1_BR, (8 * cls1_P() - 16) / 10 - 1); }
 
-int class_cfg(int K, int maxL, ClsCfg out[NCLS])
+int class_cfg(int K, int maxL, ClsCfg out[NGEN])
 {
     // sequences longer than LDS_SEQ: classes 2 and 3 read the bases of a loop from HBM/L2 (no LDS copy), class 0 takes the
     // regions whose FFT would not fit
     const bool longseq = maxL > LDS_SEQ;
-    const int P[NCLS] = {CLS0_P, cls1_P(), CLS2_P, MAX_P}, LM[NCLS] = {0, CLS01_L, longseq ? 0 : LDS_SEQ, longseq ? 0 : LDS_SEQ};
-    const int NT[NCLS] = {512, 64, getenv("RAFFT_NT2") ? atoi(getenv("RAFFT_NT2")) : 256, 512}, BR[NCLS] = {BIG_BR + 1, cls1_br(), MAX_BR, MAX_BR};
+    const int P[NGEN] = {CLS0_P, cls1_P(), CLS2_P, MAX_P}, LM[NGEN] = {0, CLS01_L, longseq ? 0 : LDS_SEQ, longseq ? 0 : LDS_SEQ};
+    const int NT[NGEN] = {512, 64, getenv("RAFFT_NT2") ? atoi(getenv("RAFFT_NT2")) : 256, 512}, BR[NGEN] = {BIG_BR + 1, cls1_br(), MAX_BR, MAX_BR};
     // class 0 (tiny regions in their own kernel) is kept compiled for experiments but receives no work (see node_class)
     const int tabm = getenv("RAFFT_TAB") ? atoi(getenv("RAFFT_TAB")) : 0;      // bit c: energy tables of class c in LDS
     // The one-wavefront class packs 12 wavefronts - what a CU holds of them anyway - into one workgroup that shares ONE LDS
@@ -237,9 +238,9 @@ int class_cfg(int K, int maxL, ClsCfg out[NCLS])
         const int Kmax1 = std::max(1, std::min(K, cls1_P() - 1));
         if (expand_lds(cls1_P(), CLS01_L, cls1_P() / 2, cls1_br(), Kmax1, true, wpb1).total > 160 * 1024) wpb1 = 1;
     }
-    const int WPB[NCLS] = {1, wpb1, 1, 1};
-    const bool TAB[NCLS] = {false, (tabm & 2) != 0 || WPB[1] > 1, (tabm & 4) != 0, false};    // (LDS tables come with LDS twiddles: FFT sizes <= CLS2_P only)
-    for (int c = 0; c < NCLS; c++) {
+    const int WPB[NGEN] = {1, wpb1, 1, 1};
+    const bool TAB[NGEN] = {false, (tabm & 2) != 0 || WPB[1] > 1, (tabm & 4) != 0, false};    // (LDS tables come with LDS twiddles: FFT sizes <= CLS2_P only)
+    for (int c = 0; c < NGEN; c++) {
         int nmax = c == 0 ? BIG_N : P[c] / 2;
         int Kmax = std::max(1, std::min(K, c == 0 ? 2 * BIG_N - 1 : P[c] - 1));
         ExpandLds l = expand_lds(P[c], LM[c], nmax, BR[c], Kmax, TAB[c], WPB[c]);
@@ -278,8 +279,15 @@ int launch_expand(const Dev &d, int cls, const ClsCfg &cf, unsigned n_teams, hip
     return 0;
 }
 
-int launch_expand_cls(const Dev &d, int cls, const ClsCfg cf[NCLS], unsigned n_blocks, hipStream_t st, bool dry = false)
+int launch_expand_cls(const Dev &d, int cls, const ClsCfg cf[NGEN], unsigned n_blocks, hipStream_t st, bool dry = false)
 {
+    if (cls >= NGEN) {        // small regions: teams of 16 / 32 lanes, four wavefronts per workgroup (n_blocks = workgroups)
+        const int arg = cls | ((getenv("RAFFT_SMALL_DIAG") ? atoi(getenv("RAFFT_SMALL_DIAG")) : 0) << 8);
+        if (cls == 4) hipLaunchKernelGGL(expand_small_kernel<16>, dim3(n_blocks), dim3(64 * SM_WG_WAVES), small_lds_bytes<16>(), st, d, arg);
+        else hipLaunchKernelGGL(expand_small_kernel<32>, dim3(n_blocks), dim3(64 * SM_WG_WAVES), small_lds_bytes<32>(), st, d, arg);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     const bool longseq = cf[2].Lmax == 0;          // (class_cfg: no LDS copy of the bases)
     if (cls == 0) return launch_expand<512, false, 1, 2>(d, 0, cf[0], n_blocks, st);
     if (longseq && cls == 2 && cf[2].nt == 256) return launch_expand<256, false, 1, 1>(d, 2, cf[2], n_blocks, st);
@@ -474,9 +482,9 @@ struct Wave {
     size_t S = 0, sumL = 0, B = 0, bs_lds[2] = {0, 0}, mat_lds = RAFFT_MAX_LEN;
     double reserve = 1.0;         // buffers are allocated for a wave this many times bigger (merged batches to come)
     bool longseq = false;         // a sequence longer than LDS_SEQ: its loops' bases are read from HBM, regions beyond 4096 positions exist
-    unsigned dedupe_per_cu = 4;
+    unsigned dedupe_per_cu = 1;
     std::vector<int> off, len;
-    ClsCfg cf[NCLS];
+    ClsCfg cf[NGEN];
     Caps c;
     Dev d;
     Counters hc;
@@ -558,7 +566,8 @@ int Wave::setup()
     ENS(pos, cr.pos * 2); ENS(br, cr.br * 4); ENS(db, cr.db); ENS(cand, cr.cand * 32);
     ENS(looptab, cr.looptab * 8);
     ENS(trec, cr.trec * 16); ENS(tsid, cr.tsid * 4);
-    ENS(work0, cr.work * 4); ENS(work1, cr.work * 4); ENS(work2, cr.work * 4); ENS(work3, cr.work * 4); ENS(mat, cr.mat * sizeof(MatRec));
+    ENS(work0, cr.work * 4); ENS(work1, cr.work * 4); ENS(work2, cr.work * 4); ENS(work3, cr.work * 4); ENS(work4, cr.work * 4); ENS(work5, cr.work * 4);
+    ENS(mat, cr.mat * sizeof(MatRec));
     ENS(counters, sizeof(Counters));
 #undef ENS
 
@@ -583,6 +592,11 @@ int Wave::setup()
         d.big_keyv = (double *)g.big.p;
     }
     d.cls1_P = cls1_P(); d.cls1_br = cls1_br();
+    // small-region classes (expand_small_kernel): packed positions (no sequence beyond 4096 nt), the bit-mask form of
+    // window_slide (non-negative weights, no forced FFT).  RAFFT_SMALL="n4,n5" moves the limits ("0,0": off).
+    d.sm_n4 = 16; d.sm_n5 = 32;
+    if (const char *e = getenv("RAFFT_SMALL")) { int a = 16, b = 32; if (sscanf(e, "%d,%d", &a, &b) >= 1) { d.sm_n4 = std::max(0, std::min(a, 16)); d.sm_n5 = std::max(d.sm_n4, std::min(b, 32)); } }
+    if (!d.pos_packed || d.force_fft || !(p.gc_wei >= 0.0 && p.au_wei >= 0.0 && p.gu_wei >= 0.0)) d.sm_n4 = d.sm_n5 = 0;
     d.mat_tile = 64;
     if (const char *e = getenv("RAFFT_MAT_TILE")) d.mat_tile = std::max(1, std::min(atoi(e), 64));   // tests: several tiles per structure
     if (const char *e = getenv("RAFFT_RL_CAP")) d.rl_cap = std::max(0, std::min(atoi(e), RL_CAP));   // tests: region lists not resident in LDS
@@ -601,7 +615,8 @@ int Wave::setup()
     d.db = (uint8_t *)g.db.p; d.db_cap = c.db;
     d.cand = (Cand *)g.cand.p; d.cand_cap = c.cand;
     d.trec = (int4 *)g.trec.p; d.trec_cap = (uint32_t)c.trec; d.tsid = (int *)g.tsid.p; d.tsid_cap = c.tsid;
-    d.work[0] = (int *)g.work0.p; d.work[1] = (int *)g.work1.p; d.work[2] = (int *)g.work2.p; d.work[3] = (int *)g.work3.p; d.work_cap = (uint32_t)c.work;
+    d.work[0] = (int *)g.work0.p; d.work[1] = (int *)g.work1.p; d.work[2] = (int *)g.work2.p; d.work[3] = (int *)g.work3.p;
+    d.work[4] = (int *)g.work4.p; d.work[5] = (int *)g.work5.p; d.work_cap = (uint32_t)c.work;
     d.mat = (MatRec *)g.mat.p; d.mat_cap = (uint32_t)c.mat;
     d.c = (Counters *)g.counters.p;
     d.nd_base = S; d.nd_shard_cap = (c.nd - S) / NSHARD;
@@ -665,17 +680,21 @@ int Wave::issue_step()
     hipStream_t st = g.stream;
     static const unsigned wide_below = getenv("RAFFT_WIDE_BELOW") ? (unsigned)atoi(getenv("RAFFT_WIDE_BELOW")) : 600u;
     static const bool serial = getenv("RAFFT_SERIAL") && atoi(getenv("RAFFT_SERIAL"));
+    static const unsigned small_wg_per_cu = getenv("RAFFT_SMALL_WG") ? (unsigned)std::max(1, atoi(getenv("RAFFT_SMALL_WG"))) : 4u;   // 4 wavefronts each
     const size_t hot_len = offsetof(Counters, node);
     HIPCHK(hipEventRecord(g.ev_fork, st));
     Span wall{next_event(), next_event(), 4};
     SPAN_REC(wall.a, st, 4);
-    static const int order[NCLS] = {3, 0, 2, 1};    // big-LDS classes first
+    static const int order_big_first[NCLS] = {3, 0, 2, 1, 5, 4}, order_small_first[NCLS] = {5, 4, 3, 0, 2, 1};    // big-LDS classes first
+    static const int *order = getenv("RAFFT_SMALL_FIRST") && atoi(getenv("RAFFT_SMALL_FIRST")) ? order_small_first : order_big_first;
     for (int oi = 0; oi < NCLS; oi++) {
         const int cls = order[oi];
         if (cls == 0 && !longseq) continue;                      // regions beyond 4096 positions: only sequences longer than that have them
         if (cls == 3 && merge_target == 2) continue;             // no sequence long enough for a region of that class
         if (merged_now == 3 && cls != 3 && cls != 0) continue;   // the dedupe of the last step sent everything to one class
         if (merged_now == 2 && cls == 1) continue;               // ... or the one-wavefront class to the 256-thread one
+        static const bool small_step0 = getenv("RAFFT_SMALL_STEP0") != nullptr;      // diagnostic: empty launches (their fixed cost)
+        if (cls >= NGEN && (merged_now != 0 || (steps == 0 && !small_step0) || (cls == 4 ? d.sm_n4 : d.sm_n5) == 0 || (cls == 5 && d.sm_n5 == d.sm_n4))) continue;   // small-region classes: off, or nothing was sent there
         const bool inline_ = serial || (merged_now == 3 && !longseq);   // a single kernel: no fork/join through another stream
         hipStream_t cs = inline_ ? st : g.cls_stream[cls];
         if (!inline_) HIPCHK(hipStreamWaitEvent(cs, g.ev_fork, 0));
@@ -683,7 +702,7 @@ int Wave::issue_step()
         SPAN_REC(sp.a, cs, sp.kind);
         // persistent workgroups loop over the work list, so any grid is correct: when few structures were
         // materialized (the tail of a batch) a small grid avoids dispatching thousands of empty workgroups
-        unsigned grid = (unsigned)cf[cls].grid;
+        unsigned grid = cls >= NGEN ? (unsigned)::g.n_cu * small_wg_per_cu : (unsigned)cf[cls].grid;
         if (steps > 0) {
             const unsigned long long bound = (unsigned long long)last_mat * (cls == 1 ? 8ULL : 4ULL) + 32ULL;
             if (bound < grid) grid = (unsigned)bound;
@@ -691,7 +710,7 @@ int Wave::issue_step()
         if (int rc = launch_expand_cls(d, cls, cf, grid, cs)) return rc;
         static const int twice = getenv("RAFFT_TWICE") ? atoi(getenv("RAFFT_TWICE")) : 0;   // diagnostic: the same work again, caches warm
         if (twice && cls == 1) {
-            HIPCHK(hipMemsetAsync((char *)g.counters.p + offsetof(Counters, next_work) + 4 * cls, 0, 4, cs));
+            HIPCHK(hipMemsetAsync((char *)g.counters.p + offsetof(Counters, wcur) + sizeof(ShardCtr) * NSHARD * cls, 0, sizeof(ShardCtr) * NSHARD, cs));
             if (int rc = launch_expand_cls(d, cls, cf, grid, cs, twice == 2)) return rc;
         }
         if (cls == 1) bt.stats.n_expand_launches++;       // launches of the dominant kernel (ms_expand is their sum)
@@ -752,7 +771,7 @@ int Wave::after_beam()
         const unsigned merge2_below = getenv("RAFFT_MERGE2_BELOW") ? (unsigned)atoi(getenv("RAFFT_MERGE2_BELOW")) : 128u * (unsigned)::g.n_cu;
         d.merge_cls = seam ? 0 : hc.n_mat < merge_below ? merge_target : hc.n_mat < merge2_below ? 2 : 0;
         merged_now = d.merge_cls;
-        hipLaunchKernelGGL(dedupe_kernel, dim3(::g.n_cu * dedupe_per_cu), dim3(256), 0, st, d);
+        hipLaunchKernelGGL(dedupe_kernel, dim3(::g.n_cu * dedupe_per_cu), dim3(DEDUPE_NT), 0, st, d);
         HIPCHK(hipGetLastError());
         SPAN_REC(sp.b, st, sp.kind);
         spans.push_back(sp);
@@ -761,7 +780,7 @@ int Wave::after_beam()
         Counters h2;
         HIPCHK(hipMemcpyAsync(&h2, g.counters.p, hot_len, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        fprintf(stderr, "[rafft] step %d: n_mat %u -> work %u %u %u %u\n", steps, hc.n_mat, h2.n_work[0], h2.n_work[1], h2.n_work[2], h2.n_work[3]);
+        fprintf(stderr, "[rafft] step %d: n_mat %u -> work %u %u %u %u | small %u %u\n", steps, hc.n_mat, h2.n_work[0], h2.n_work[1], h2.n_work[2], h2.n_work[3], h2.n_work[4], h2.n_work[5]);
     }
     return issue_step();
 }
@@ -855,6 +874,13 @@ int Wave::finish()
     }
     // statistics (SURVEY.md 8d algorithmic bytes; only expansions the kernels really executed)
     HIPCHK(hipMemcpy(&hc, g.counters.p, sizeof hc, hipMemcpyDeviceToHost));
+    for (int c = 0; c < NCLS; c++)            // the sharded statistics lines (Counters::xstat)
+        for (int i = 0; i < NSHARD; i++) {
+            const Counters::StatLine &x = hc.xstat[c][i];
+            hc.n_expand += x.items; hc.sum_n += x.n; hc.sum_lags += x.lags; hc.sum_nbr += x.nbr;
+            hc.cls_items[c] += x.items; hc.cls_sum_n[c] += x.n; hc.cls_sum_lags[c] += x.lags;
+            hc.n_alias += x.alias; hc.n_children += x.children; hc.sum_struct_len += x.struct_len;
+        }
     {
         unsigned long long nn = S;
         for (int i = 0; i < NSHARD; i++) nn += hc.node[i].v;
@@ -976,7 +1002,12 @@ int run_seam(Batch &bt, const std::vector<SeqIn> &one, const SeamIn &sm)
         }
         HIPCHK(hipMemcpy(W.pos.p, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
     }
-    if (!sm.br.empty()) HIPCHK(hipMemcpy(W.br.p, sm.br.data(), sm.br.size() * 4, hipMemcpyHostToDevice));
+    if (!sm.br.empty()) {
+        std::vector<uint32_t> pb(sm.br);
+        if (w.d.pos_packed)      // (the base codes of a helix's outermost pair ride in bits 12-15 and 28-31)
+            for (auto &v : pb) v |= ((uint32_t)kBaseCode[(unsigned char)one[0].s[v & 0xFFFFu]] << 12) | ((uint32_t)kBaseCode[(unsigned char)one[0].s[v >> 16]] << 28);
+        HIPCHK(hipMemcpy(W.br.p, pb.data(), pb.size() * 4, hipMemcpyHostToDevice));
+    }
     int n = (int)sm.pos.size(), nbr = (int)sm.br.size();
     {
         NodeRec root;                                       // region 0 as init_roots_kernel left it, with the given loop
@@ -984,7 +1015,7 @@ int run_seam(Batch &bt, const std::vector<SeqIn> &one, const SeamIn &sm)
         root.n = n; root.nbr = nbr; root.ci = sm.ci; root.cj = sm.cj; root.pdcal = sm.pdcal;
         HIPCHK(hipMemcpy(W.nd.p, &root, sizeof root, hipMemcpyHostToDevice));
     }
-    int cls = node_class(n, (sm.ci < 0 || one[0].len > LDS_SEQ) ? one[0].len : sm.cj + 1 - sm.ci, nbr, 0, w.d.cls1_P, w.d.cls1_br);
+    int cls = node_class(n, (sm.ci < 0 || one[0].len > LDS_SEQ) ? one[0].len : sm.cj + 1 - sm.ci, nbr, 0, w.d.cls1_P, w.d.cls1_br, w.d.K, w.d.sm_n4, w.d.sm_n5);
     int zero = 0;
     memset(&w.hc.n_work, 0, sizeof w.hc.n_work);
     w.hc.n_work[cls] = 1;
@@ -1056,7 +1087,8 @@ static void finalize_batch(const std::shared_ptr<Batch> &bp)
         for (auto &sp : b.spans) {
             float ms = 0;
             if (span_on(sp.kind) && hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
-                if (sp.kind == 10) b.stats.ms_expand_c1 += ms;   /* class 0: unused */
+                if (sp.kind == 14 || sp.kind == 15) b.stats.ms_expand_c1 += ms;   /* small-region classes 4 and 5 (expand_small_kernel) */
+                else if (sp.kind == 10) b.stats.ms_expand_c3 += ms;   /* class 0 (regions beyond 4096 positions) rides with the widest class */
                 else if (sp.kind == 11) b.stats.ms_expand += ms;   /* dominant kernel: regions with P <= 512 */
                 else if (sp.kind == 12) b.stats.ms_expand_c2 += ms;
                 else if (sp.kind == 13) b.stats.ms_expand_c3 += ms;

@@ -43,7 +43,8 @@ static_assert(sizeof(Cand) == 32, "Cand must be 32 bytes");
 
 #define NSHARD 64
 #define SEEN0 8192      // initial slots of a sequence's `seen` set (grows x2 by rehash)
-#define NCLS 4
+#define NCLS 6          // expand size classes: 0-3 the general kernel (NGEN), 4-5 the small-region kernel (teams of 16 / 32 lanes)
+#define NGEN 4
 #define PROF_E 96      // RAFFT_TRACE=3: 64-bit diagnostic slots per expand class (Dev::prof_e)
 struct ShardCtr { unsigned long long v; unsigned long long pad[7]; };   // one 64-byte line each
 
@@ -73,17 +74,25 @@ struct Counters {
     // hot part: read back by the host once per folding step (first 64 bytes)
     unsigned int n_work[NCLS];     // expand work items per size class (filled by dedupe_kernel)
     unsigned int n_mat;            // structures to materialize (filled by beam_step_kernel)
-    unsigned int next_work[NCLS];  // dynamic fetch cursors of the persistent expand kernels
+    unsigned int pad_[6];
     unsigned int overflow;         // bit mask of which arena overflowed
     unsigned int n_done;
     unsigned int max_nprod;        // largest number of productive regions seen in one structure
-    unsigned int pad_[4];
     unsigned long long n_struct, seen_top, trec_n, tsid_top;
     // statistics
     unsigned long long n_expand, sum_n, sum_lags, n_children, sum_struct_len, n_alias, sum_nbr;
     unsigned long long cls_items[NCLS], cls_sum_n[NCLS], cls_sum_lags[NCLS];   // per size class
     // sharded bump pointers of the arenas filled by materialize / expand
     ShardCtr node[NSHARD], pos[NSHARD], br[NSHARD], db[NSHARD], cand[NSHARD], node_prev[NSHARD], prod[NSHARD];
+    // statistics the kernels add to once per wavefront / workgroup: one 64-byte line per (size class, shard), summed by the
+    // host at the end of the wave.  (As single counters they were a same-address atomic storm at the end of every expand
+    // launch - 3000-4000 wavefronts x 7 atomics on one line - a fixed 150-300 us per launch.)
+    // Work cursors of the persistent expand kernels: the work list of a class is cut in chunks, chunk c belongs to shard
+    // c % NSHARD, and wcur[cls][s] counts the chunks of shard s handed out (see fetch_chunk).  ONE cursor per class was a
+    // same-address returning atomic per wavefront and round: ~12 ns each, served one after the other - 50 us for the 4096
+    // wavefronts of a launch to learn that there is nothing (left) to do, and as much for every round they start together.
+    ShardCtr wcur[NCLS][NSHARD];
+    struct StatLine { unsigned long long items, n, lags, nbr, alias, children, struct_len, pad; } xstat[NCLS][NSHARD];
 };
 
 enum { OVF_STRUCT = 1, OVF_NODE = 2, OVF_POS = 4, OVF_DB = 8, OVF_CAND = 16, OVF_SEEN = 32,
@@ -103,6 +112,8 @@ struct Dev {
     int K, B, max_branch, min_hp, traj, memo, force_fft, rl_cap, mat_tile, merge_cls;
     double *big_keyv; size_t big_stride;   // lag values of regions too big for LDS: one slice of `big_stride` doubles per workgroup
     int max_prod;                // productive regions per structure that materialize_kernel's LDS lists hold
+    int sm_n4, sm_n5;            // small-region classes: regions of up to sm_n4 positions go to class 4 (teams of 16 lanes), up to
+                                 // sm_n5 to class 5 (teams of 32); 0 = class unused (see node_class)
     int cls1_P, cls1_br;         // limits of the one-wavefront expand class (FFT size, branches): they set its LDS per wavefront
     double min_nrj, gc, au, gu;
     int *beam, *beam_n, *done, *nsteps;
@@ -164,8 +175,16 @@ __host__ __device__ inline int next_pow2_ge(int x) { int p = 2; while (p < x) p 
 // `span`: the stretch of the sequence the loop lies in (closing pair to closing pair; the whole sequence for the exterior
 // loop) - the bases the expand kernel stages in LDS.  The one-wavefront class has room for CLS01_L of them, so a small
 // loop of a LONG sequence (the inside of a hairpin of a 16S rRNA) still is one wavefront's work, not a workgroup's.
-__host__ __device__ inline int node_class(int n, int span, int nbr, int merge_cls = 0, int cls1_P = CLS1_P, int cls1_br = CLS1_BR)
+// Small regions (classes 4 and 5, expand_small_kernel): every lag is searched (2n-1 <= nb_mode: nothing to rank), the whole
+// region sits in one team of 16 / 32 lanes, its loop spans at most SM_SPAN bases and has at most one branch per lane.
+#define SM_SPAN 448
+__host__ __device__ inline int node_class(int n, int span, int nbr, int merge_cls = 0, int cls1_P = CLS1_P, int cls1_br = CLS1_BR,
+                                          int K = 0, int sm_n4 = 0, int sm_n5 = 0)
 {
+    if (merge_cls == 0 && n >= 2 && n <= sm_n5 && 2 * n - 1 <= K && span <= SM_SPAN) {
+        if (n <= sm_n4 && nbr <= 16) return 4;
+        if (nbr <= 32) return 5;
+    }
     // few regions in this step (the tail of a batch): all of them go to one kernel, the widest one that is
     // configured - one launch and one region per workgroup instead of three nearly empty kernels in a row
     int P = next_pow2_ge(2 * n - 1);

@@ -149,6 +149,30 @@ __device__ inline void build_masks(unsigned long long *F, unsigned long long *R,
     }
 }
 
+// Next chunk of CH work items of class `cls` for this wavefront (all 64 lanes call it; `shard` is the wavefront's current
+// shard, kept between calls): returns the first item of the chunk, or ~0u when every chunk of the list has been handed
+// out.  The 64 cursors are looked at with ONE load (lane l reads shard l), then one lane claims from the next shard that
+// still has chunks - the atomics of a launch spread over 64 cache lines instead of queueing on one address.
+__device__ inline unsigned fetch_chunk(const Dev &d, int cls, unsigned n_items, unsigned CH, int &shard)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned chunks_total = (n_items + CH - 1) / CH;
+    const unsigned mine = (unsigned)lane < chunks_total ? (chunks_total - (unsigned)lane + (NSHARD - 1)) / NSHARD : 0u;   // chunks of shard `lane`
+    for (;;) {
+        const unsigned cur = (unsigned)__hip_atomic_load(&d.c->wcur[cls][lane].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long live = __ballot(cur < mine);
+        if (!live) return ~0u;
+        const unsigned long long rot = shard ? ((live >> shard) | (live << (64 - shard))) : live;
+        shard = (shard + __ffsll((long long)rot) - 1) & (NSHARD - 1);
+        unsigned k = 0;
+        if (lane == 0) k = (unsigned)atomicAdd(&d.c->wcur[cls][shard].v, 1ULL);
+        k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
+        const unsigned chunk = (unsigned)shard + NSHARD * k;
+        if (chunk < chunks_total) return chunk * CH;
+    }
+}
+static_assert(NSHARD == 64, "fetch_chunk reads one work cursor per lane");
+
 #ifndef RAFFT_EXPAND64_WAVES
 #define RAFFT_EXPAND64_WAVES 3        // <= 168 VGPRs (12 B/lane of scratch): its LDS allows three wavefronts per SIMD anyway; a cap of 128 spilled 152 B/lane
 #endif
@@ -234,6 +258,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
 #define ESTAMP(k) do { if (eprof) { const unsigned long long tn_ = clock64(); eacc[k] += tn_ - et; et = tn_; } } while (0)
     const unsigned FETCH = (NT == 64 && n_items > 4u * n_teams) ? 4u : 1u;
     unsigned fetch_base = 0, fetch_left = 0;                 // uniform across the workgroup
+    int fshard = (int)(gteam & (NSHARD - 1));                // work-cursor shard this team claims from next (fetch_chunk)
     unsigned long long slab_base = 0; unsigned slab_left = 0;   // thread 0 only
 
     for (;;) {
@@ -244,9 +269,13 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
             if (tid == 0) atomicAdd(&d.prof_e[cls * PROF_E + 32], (unsigned long long)(clock64() - t0_));
         }
         if (fetch_left == 0) {
-            if (tid == 0) misc[8] = (int)atomicAdd(&d.c->next_work[cls], FETCH);
-            ESYNC();
-            fetch_base = (unsigned)misc[8];
+            if (NT == 64) fetch_base = fetch_chunk(d, cls, n_items, FETCH, fshard);
+            else {
+                if (tid < 64) { const unsigned b_ = fetch_chunk(d, cls, n_items, FETCH, fshard); if (tid == 0) misc[8] = (int)b_; }
+                ESYNC();
+                fetch_base = (unsigned)misc[8];
+            }
+            if (fetch_base == ~0u) break;
             fetch_left = FETCH;
         }
         // (the work item is the same for the whole team: saying so - readfirstlane - turns the header loads below into scalar
@@ -254,7 +283,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
         //  team IS a wavefront)
         const unsigned item = NT == 64 ? (unsigned)__builtin_amdgcn_readfirstlane((int)fetch_base) : fetch_base;
         fetch_base++; fetch_left--;
-        if (item >= n_items) break;
+        if (item >= n_items) { fetch_left = 0; continue; }       // (tail of the list's last chunk; other shards may still hold chunks)
         const int nid = NT == 64 ? __builtin_amdgcn_readfirstlane(d.work[cls][item]) : d.work[cls][item];
         const int L = d.nd[nid].L;                 // (the record carries its sequence's length and offset: no look-up keyed on `seq`)
         const int n = d.nd[nid].n, ci = d.nd[nid].ci, cj = d.nd[nid].cj, nbr = d.nd[nid].nbr;
@@ -285,7 +314,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
         if (LONGSEQ == 0) {   // bases: only the span of this loop is ever looked at (closing pair, its neighbours inside, branches)
             for (int x = sx0 + tid; x < sx1; x += NT) Sl_lds[x - sx0] = codes[x];
         }
-        for (int t = tid; t < nbr; t += NT) brl[t] = brg[t];
+        for (int t = tid; t < nbr; t += NT) brl[t] = (LONGSEQ == 0 && d.pos_packed) ? (brg[t] & 0x0FFF0FFFu) : brg[t];   // (Dev::pos_packed: the codes ride along)
         ESYNC();
         }
 
@@ -958,15 +987,15 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
     }
 #undef ESTAMP
     if (tid == 0 && st_items) {
-        atomicAdd(&d.c->n_expand, st_items);
-        atomicAdd(&d.c->sum_n, st_n);
-        atomicAdd(&d.c->sum_lags, st_lags);
-        atomicAdd(&d.c->sum_nbr, st_nbr);
-        atomicAdd(&d.c->cls_items[cls], st_items);
-        atomicAdd(&d.c->cls_sum_n[cls], st_n);
-        atomicAdd(&d.c->cls_sum_lags[cls], st_lags);
+        Counters::StatLine *sl = &d.c->xstat[cls][gteam & (NSHARD - 1)];
+        atomicAdd(&sl->items, st_items);
+        atomicAdd(&sl->n, st_n);
+        atomicAdd(&sl->lags, st_lags);
+        atomicAdd(&sl->nbr, st_nbr);
     }
 }
+
+#include "rafft_expand_small.hip"
 
 // --------------------------------------------------------- beam step kernel
 
@@ -1044,7 +1073,8 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
     // snapshot of the region allocators: whatever materialize adds after this kernel is "new"
     if (sq == 0 && tid < NSHARD) d.c->node_prev[tid].v = d.c->node[tid].v;
     // the expand kernels of this step are done with their work lists: reset them for dedupe_kernel / the next step
-    if (sq == 0 && tid < NCLS) { d.c->n_work[tid] = 0; d.c->next_work[tid] = 0; }
+    if (sq == 0 && tid < NCLS) d.c->n_work[tid] = 0;
+    if (sq == 0) for (int i = tid; i < NCLS * NSHARD; i += BS_NT) d.c->wcur[i / NSHARD][i % NSHARD].v = 0;
     if (d.done[sq]) return;
     const bool prof = d.prof && sq == d.prof_seq && tid == 0;   // diagnostic stamps (RAFFT_TRACE=3)
     unsigned long long tprev = prof ? clock64() : 0;
@@ -1427,7 +1457,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
         }
     }
     STAMP(2);
-    if (tid == 0) { d.seen_cnt[sq] = scnt; atomicAdd(&d.c->n_children, (unsigned long long)nchild); }
+    if (tid == 0) { d.seen_cnt[sq] = scnt; atomicAdd(&d.c->xstat[1][sq & (NSHARD - 1)].children, (unsigned long long)nchild); }
     if (nchild > d.ch_cap) nchild = d.ch_cap;
 
     // ---- new = children + beam, stable sort by energy, cut (rafft/rafft.py:206-210)
@@ -1492,7 +1522,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
     if (tid == 0) {
         unsigned long long sb = atomicAdd(&d.c->n_struct, (unsigned long long)nsurv_child);
         unsigned int mb = atomicAdd(&d.c->n_mat, (unsigned int)nsurv_child);
-        atomicAdd(&d.c->sum_struct_len, (unsigned long long)nsurv_child * (unsigned long long)d.seq_len[sq]);
+        atomicAdd(&d.c->xstat[1][sq & (NSHARD - 1)].struct_len, (unsigned long long)nsurv_child * (unsigned long long)d.seq_len[sq]);
         if (sb + nsurv_child > d.st_cap || mb + nsurv_child > d.mat_cap) { atomicOr(&d.c->overflow, OVF_STRUCT); sh[24] = -1; }
         else { sh[24] = (int)sb; sh[25] = (int)mb; }
     }
@@ -1555,6 +1585,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
 struct MatDesc {
     unsigned long long srcpos, srcbr;
     int pn, mi, mj, nb, n, nbr, ci, cj, lo0, hi0, loo, hio, a0, b0, ao, bo, flags;
+    uint32_t newbr;        // the stem as a branch of the outer child: outermost pair, in the arena's (packed) form
     int nnod, npos_in, npos_out, nbr_in, nbr_out;
 };
 __device__ inline MatDesc mat_describe(const Dev &d, int pn, int selk)
@@ -1568,7 +1599,9 @@ __device__ inline MatDesc mat_describe(const Dev &d, int pn, int selk)
     m.mi = cd.mi; m.mj = cd.mj; m.nb = cd.nb;
     const uint16_t *pp = d.pos + m.srcpos;
     const int pm = d.pos_packed ? 0x0FFF : 0xFFFF;
-    m.a0 = pp[m.mi] & pm; m.b0 = pp[m.mj] & pm; m.ao = pp[m.mi - m.nb + 1] & pm; m.bo = pp[m.mj + m.nb - 1] & pm;
+    const uint32_t rao = pp[m.mi - m.nb + 1], rbo = pp[m.mj + m.nb - 1];
+    m.a0 = pp[m.mi] & pm; m.b0 = pp[m.mj] & pm; m.ao = (int)rao & pm; m.bo = (int)rbo & pm;
+    m.newbr = rao | (rbo << 16);          // (with Dev::pos_packed the base codes ride in bits 12-15 and 28-31)
     cd.get_cuts(m.lo0, m.hi0, m.loo, m.hio);      // where the stem cuts the branch list (found by expand_kernel)
     m.flags = 0; m.nnod = 0; m.npos_in = m.npos_out = m.nbr_in = m.nbr_out = 0;
     if (m.mj - m.mi > 1) { m.flags |= 1; m.nnod++; m.npos_in = m.mj - m.mi - 1; m.nbr_in = m.hi0 - m.lo0; }
@@ -1697,7 +1730,7 @@ __global__ __launch_bounds__(MAT_NT, RAFFT_MAT_WAVES) void materialize_kernel(De
         if (act) {
             k_srcpos[tid] = md.srcpos; k_srcbr[tid] = md.srcbr;
             k_mi[tid] = md.mi; k_mj[tid] = md.mj; k_nb[tid] = md.nb; k_lo0[tid] = md.lo0; k_loo[tid] = md.loo; k_hio[tid] = md.hio;
-            k_newbr[tid] = (int)((uint32_t)md.ao | ((uint32_t)md.bo << 16));
+            k_newbr[tid] = (int)md.newbr;
             // region records (rafft/utils.py:141-152): inner, then outer
             int nid = (int)(nbase + run_nodes + (xn - vn));
             const unsigned long long poff = pbase + run_pos + p0, boff = bbase + run_br + b0;
@@ -1778,11 +1811,13 @@ __device__ inline bool same_loop(const Dev &d, int a, int b)
 // materialize kernel bumped in each allocation shard since the last snapshot).  The first
 // region to claim a loop key becomes canonical and goes to the expand work list; later
 // identical loops alias it.  Work-list appends are aggregated per wavefront.
-__global__ __launch_bounds__(256) void dedupe_kernel(Dev d)
+#define DEDUPE_NT 1024
+__global__ __launch_bounds__(DEDUPE_NT) void dedupe_kernel(Dev d)
 {
     __shared__ unsigned int pre[NSHARD + 1];
     __shared__ unsigned int prev[NSHARD];
-    const int tid = threadIdx.x, lane = tid & 63;
+    __shared__ unsigned int wcnt[DEDUPE_NT / 64][NCLS], wbase[DEDUPE_NT / 64][NCLS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // an arena overflowed while materializing: some region records of this step were never written.
     // Nothing may be read from them; the host sees the flag at its next read-back and regrows.
     if (d.c->overflow) return;
@@ -1831,25 +1866,34 @@ __global__ __launch_bounds__(256) void dedupe_kernel(Dev d)
                 else {
                     // (sequences beyond 4096 nt keep out of the one-wavefront class whatever the span: see expand_kernel's Sl)
                     const int Ls = d.nd[nid].L, span = (d.nd[nid].ci < 0 || Ls > LDS_SEQ) ? Ls : d.nd[nid].cj + 1 - d.nd[nid].ci;
-                    cls = node_class(n, span, d.nd[nid].nbr, d.merge_cls, d.cls1_P, d.cls1_br);
+                    cls = node_class(n, span, d.nd[nid].nbr, d.merge_cls, d.cls1_P, d.cls1_br, d.K, d.sm_n4, d.sm_n5);
                 }
             }
             else { d.nd_canon[nid] = canon; aliases++; }
         }
+        // work-list appends, aggregated over the WORKGROUP: one atomic per class and pass (per wavefront they were
+        // 4096 x 4-6 returning atomics on one cache line per pass - the kernel's whole duration)
+        unsigned long long mybal = 0;
         for (int c = 0; c < NCLS; c++) {
-            unsigned long long bal = __ballot(cls == c);
-            if (!bal) continue;
-            unsigned int w0 = 0;
-            if (lane == 0) w0 = atomicAdd(&d.c->n_work[c], (unsigned int)__popcll(bal));
-            w0 = __shfl(w0, 0, 64);
-            if (cls == c) {
-                unsigned int w = w0 + (unsigned int)__popcll(bal & ((1ULL << lane) - 1));
-                if (w < d.work_cap) d.work[c][w] = nid; else atomicOr(&d.c->overflow, OVF_WORK);
-            }
+            const unsigned long long bal = __ballot(cls == c);
+            if (cls == c) mybal = bal;
+            if (lane == 0) wcnt[wv][c] = (unsigned int)__popcll(bal);
+        }
+        __syncthreads();
+        if (tid < NCLS) {
+            unsigned int tot = 0;
+            for (int w = 0; w < DEDUPE_NT / 64; w++) tot += wcnt[w][tid];
+            unsigned int b = tot ? atomicAdd(&d.c->n_work[tid], tot) : 0u;
+            for (int w = 0; w < DEDUPE_NT / 64; w++) { wbase[w][tid] = b; b += wcnt[w][tid]; }
+        }
+        __syncthreads();
+        if (cls >= 0) {
+            const unsigned int w = wbase[wv][cls] + (unsigned int)__popcll(mybal & ((1ULL << lane) - 1));
+            if (w < d.work_cap) d.work[cls][w] = nid; else atomicOr(&d.c->overflow, OVF_WORK);
         }
     }
     for (int o = 32; o > 0; o >>= 1) aliases += __shfl_xor(aliases, o, 64);
-    if (lane == 0 && aliases) atomicAdd(&d.c->n_alias, aliases);
+    if (lane == 0 && aliases) atomicAdd(&d.c->xstat[0][blockIdx.x & (NSHARD - 1)].alias, aliases);
 }
 
 // ------------------------------------------------------------- init kernel

@@ -173,6 +173,34 @@ def test_gpu_fft_and_direct_correlation_agree(monkeypatch, node_records):
         assert as_lists(t1) == as_lists(t2)
 
 
+def test_gpu_small_region_kernel_is_interchangeable(monkeypatch, node_records):
+    """regions of up to 32 positions whose every lag is searched go to expand_small_kernel (teams of 16 / 32 lanes);
+    with the class switched off, or its limits moved, the general kernel expands them: same trajectories, same
+    per-region records (reference-Python fixtures), both equal to the oracle"""
+    rng = np.random.default_rng(1632)
+    seqs = ["".join(rng.choice(list("ACGU"), int(n))) for n in rng.integers(9, 420, size=40)]
+    seqs += ["GGGAAACCC", "GCGCGCGCGCGCGC", "GGGNNNNCCC", "AUAUAUAUAUAUAUAUAUAU", "".join(rng.choice(list("ACGUN"), 150, p=[.23, .23, .23, .23, .08]))]
+    runs = {}
+    for lim in ("16,32", "0,0", "8,16", "0,32", "16,16"):
+        monkeypatch.setenv("RAFFT_SMALL", lim)
+        runs[lim] = [as_lists(t) for _, t in rafft_amd.fold_batch(seqs, 100, 12, 1000, traj=True)]
+        small = [r for r in node_records if len(r["pos"]) <= 32 and 2 * len(r["pos"]) - 1 <= r["nb_mode"]]
+        assert len(small) > 20
+        for r in small:
+            g = R.expand_node(r["seq"], r["db"], r["pos"], r["nb_mode"], r["min_hp"], r["min_nrj"], r["gc"], r["au"], r["gu"])
+            assert g["lag"] == r["lags"] and g["cor"] == [r["cor"][k] for k in r["lags"]]
+            assert [[a, b, c, d] for a, b, c, d in zip(g["nb"], g["mi"], g["mj"], g["score"])] == r["ws"]
+            assert [[g["nb"][k], g["score"][k], g["mi"][k], g["mj"][k], g["ddcal"][k]] for k in g["kept"]] == r["sol"]
+    monkeypatch.delenv("RAFFT_SMALL")
+    for lim, t in runs.items():
+        assert t == runs["0,0"], lim
+    for s, t in zip(seqs[:12] + seqs[40:], runs["16,32"][:12] + runs["16,32"][40:]):
+        _, o = oracle.fold(s, 100, 12, 1000, traj=True)
+        assert t == as_lists(o), len(s)
+    st = rafft_amd.last_stats()
+    assert st["n_node_expansions"] > 0
+
+
 def test_gpu_beam_region_lists_not_resident(monkeypatch):
     """the beam step keeps every member's regions-with-a-choice in LDS; members that do not fit are decoded
     from the productive-region list in HBM instead - same trajectories either way, and both equal the oracle"""

@@ -1,10 +1,11 @@
 """A/B comparisons of builds on the benchmark set: latency of one synchronous call, throughput with two batches in
 flight (the bench loop), and the summed duration of the dominant kernel per batch.  AB_LIB=<path> picks the build."""
 import ctypes as C, gzip, os, statistics, sys, time
-sys.path.insert(0, ".")
+ROOT = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, ROOT)
 from rafft_amd import _native as N
 from rafft_amd.rafft import _params
-seqs = [l.split("\t")[1] for l in gzip.open("tests/golden/bench_inputs.tsv.gz", "rt")]
+seqs = [l.split("\t")[1] for l in gzip.open(os.path.join(ROOT, "tests/golden/bench_inputs.tsv.gz"), "rt")]
 if os.environ.get('AB_LIB'):
     N.LIB_PATH = os.path.abspath(os.environ['AB_LIB'])
 lib = N.lib(); N.check(lib.rafft_init(0))
