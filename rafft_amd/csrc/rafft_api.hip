@@ -123,7 +123,9 @@ int ensure(Buf &b, size_t bytes)
     if (b.p) { std::lock_guard<std::mutex> lk(g.gc_mu); g.garbage.push_back(b.p); b.p = nullptr; b.cap = 0; }
     // a buffer that had to grow once will grow again: leave room (at most 256 MB of it)
     size_t want = bytes + std::min<size_t>(bytes / (old_cap ? 2 : 8), (size_t)256 << 20) + 256;
+    want = (want + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);      // whole 2 MiB fragments
     hipError_t e = hipMalloc(&b.p, want);
+    if (getenv("RAFFT_TRACE_ALLOC")) fprintf(stderr, "[rafft] ptr %p (mod 2MiB %zu KiB) ", b.p, ((size_t)(uintptr_t)b.p & (((size_t)2 << 20) - 1)) >> 10);
     if (getenv("RAFFT_TRACE_ALLOC")) fprintf(stderr, "[rafft] t=%.3f device buffer -> %.1f MB in %.3f ms\n", std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(), (double)want / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count());
     if (e != hipSuccess) {
         b.p = nullptr;
@@ -294,7 +296,7 @@ int launch_expand_cls(const Dev &d, int cls, const ClsCfg cf[NGEN], unsigned n_b
     if (longseq && cls >= 2) return launch_expand<512, false, 1, 1>(d, cls, cf[cls], n_blocks, st);
     if (cls == 1) {
         if (cf[1].wpb == 4) return launch_expand<64, true, 4>(d, 1, cf[1], n_blocks, st);
-        if (cf[1].wpb == 12) return launch_expand<64, true, 12>(d, dry ? 0x101 : 1, cf[1], n_blocks, st);
+        if (cf[1].wpb == 12) return launch_expand<64, true, 12>(d, dry ? (0x101 | (std::max(0, atoi(getenv("RAFFT_TWICE")) - 2) << 9)) : 1, cf[1], n_blocks, st);
         return cf[1].tab ? launch_expand<64, true>(d, 1, cf[1], n_blocks, st) : launch_expand<64, false>(d, 1, cf[1], n_blocks, st);
     }
     if (cls == 2) {
@@ -711,7 +713,8 @@ int Wave::issue_step()
         static const int twice = getenv("RAFFT_TWICE") ? atoi(getenv("RAFFT_TWICE")) : 0;   // diagnostic: the same work again, caches warm
         if (twice && cls == 1) {
             HIPCHK(hipMemsetAsync((char *)g.counters.p + offsetof(Counters, wcur) + sizeof(ShardCtr) * NSHARD * cls, 0, sizeof(ShardCtr) * NSHARD, cs));
-            if (int rc = launch_expand_cls(d, cls, cf, grid, cs, twice == 2)) return rc;
+            HIPCHK(hipMemsetAsync((char *)g.counters.p + offsetof(Counters, wdone) + 8 * cls, 0, 8, cs));
+            if (int rc = launch_expand_cls(d, cls, cf, grid, cs, twice >= 2)) return rc;
         }
         if (cls == 1) bt.stats.n_expand_launches++;       // launches of the dominant kernel (ms_expand is their sum)
         SPAN_REC(sp.b, cs, sp.kind);
@@ -925,7 +928,16 @@ int Wave::finish()
             for (int k = 0; k < 7; k++) fprintf(stderr, " %s %.1f%%", mn[k], t ? 100.0 * (double)pe[k] / (double)t : 0.0);
             fprintf(stderr, "\n");
         }
-        for (int c = 1; c < NCLS; c++) {
+        for (int c = NGEN; c < NCLS; c++) {
+            static const char *sn[7] = {"fetch", "header+fill+masks", "window_slide", "branch prefix sums", "dE", "values+compaction+slots", "order+emit"};
+            unsigned long long t = 0;
+            for (int k = 0; k < 7; k++) t += pe[c * PROF_E + k];
+            fprintf(stderr, "[rafft] small-region class %d (lane 0 of every wavefront, %llu Mcycles, %llu rounds by %llu wavefronts = %.1f kcycles per round):", c, t / 1000000,
+                    pe[c * PROF_E + 8], pe[c * PROF_E + 9], pe[c * PROF_E + 8] ? (double)t / (double)pe[c * PROF_E + 8] / 1e3 : 0.0);
+            for (int k = 0; k < 7; k++) fprintf(stderr, " %s %.1f%%", sn[k], t ? 100.0 * (double)pe[c * PROF_E + k] / (double)t : 0.0);
+            fprintf(stderr, "\n");
+        }
+        for (int c = 1; c < NGEN; c++) {
             unsigned long long t = 0;
             for (int k = 0; k < 8; k++) t += pe[c * PROF_E + k];
             fprintf(stderr, "[rafft] expand class %d phase shares (lane 0 of every wavefront, %llu Mcycles):", c, t / 1000000);
@@ -939,6 +951,7 @@ int Wave::finish()
                 fprintf(stderr, "  %s %.1f%% / %.1f%% / %.1f", bn[k], hn ? 100.0 * pe[c * PROF_E + 8 + k] / hn : 0.0, hc_ ? 100.0 * pe[c * PROF_E + 16 + k] / hc_ : 0.0,
                         pe[c * PROF_E + 8 + k] ? (double)pe[c * PROF_E + 16 + k] / (double)pe[c * PROF_E + 8 + k] / 1e3 : 0.0);
             fprintf(stderr, "\n");
+            fprintf(stderr, "[rafft]   class %d: inside fetch+header: claiming items %llu Mcycles, work-list entry %llu Mcycles (of %llu)\n", c, pe[c * PROF_E + 40] / 1000000, pe[c * PROF_E + 41] / 1000000, pe[c * PROF_E] / 1000000);
             if (pe[c * PROF_E + 32]) fprintf(stderr, "[rafft]   class %d: draining the previous region's stores (RAFFT_REP=256): %llu Mcycles\n", c, pe[c * PROF_E + 32] / 1000000);
             if (c == 1) {
                 fprintf(stderr, "[rafft]   class 1, regions without any stem / without a kept candidate (share of the size class):");

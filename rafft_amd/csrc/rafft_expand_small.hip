@@ -84,21 +84,27 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
     const unsigned FETCH = n_items > 4u * TPW * n_waves ? 4u : 1u;            // groups of TPW regions claimed per atomic
     unsigned fetch_base = 0, fetch_left = 0;                                  // uniform across the wavefront
     int fshard = (int)(gw & (NSHARD - 1));
+    unsigned long long ffailed = 0;
     unsigned long long slab_base = 0; unsigned slab_left = 0;                 // lane 0 only: reserved candidate slots
     const bool dbg = d.dbg.lag != nullptr;                                    // kernel-level seam (one region, team 0)
     const double par_none = 0.0; (void)par_none;
 
     if (diag == 4) return;
+    const bool eprof = d.prof_e != nullptr && lane == 0;      // diagnostic phase stamps (RAFFT_TRACE=3)
+    unsigned long long eacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, et = eprof ? clock64() : 0, n_rounds = 0;
+#define SSTAMP(k) do { if (eprof) { const unsigned long long tn_ = clock64(); eacc[k] += tn_ - et; et = tn_; } } while (0)
     for (;;) {
         wave_sync();                                   // the previous regions' LDS use is over
         if (fetch_left == 0) {
-            fetch_base = fetch_chunk(d, cls, n_items, FETCH * TPW, fshard);
+            fetch_base = fetch_chunk(d, cls, n_items, FETCH * TPW, fshard, ffailed);
             if (fetch_base == ~0u) break;
             fetch_left = FETCH;
         }
         const unsigned item0 = fetch_base;
         fetch_base += TPW; fetch_left--;
         if (item0 >= n_items) { fetch_left = 0; continue; }      // (tail of the list's last chunk; other shards may still hold chunks)
+        SSTAMP(0);   // fetch
+        n_rounds++;
         const bool act = item0 + (unsigned)tq < n_items;           // a team without a region idles through this round
         const int nid = d.work[cls][act ? item0 + tq : item0];
         const NodeRec *nr = &d.nd[nid];
@@ -135,6 +141,7 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
         const int rs = 32 - n;                                      // strand reversed: bit j of r? = bit n-1-j of m?
         const uint32_t rA = __brev(mA) >> rs, rC = __brev(mC) >> rs, rG = __brev(mG) >> rs, rU = __brev(mU) >> rs, rg = __brev(mg) >> rs;
         wave_sync();
+        SSTAMP(1);   // header + loop fill + masks
 
         // ---- window_slide of every lag (rafft/rafft.py:36-83); a lane owns lags tl and tl + TL
         int w_nb[2], w_mi[2], w_mj[2];
@@ -184,6 +191,7 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
             w_nb[s] = mx_nb; w_mi[s] = mx_i; w_mj[s] = mx_j; w_sc[s] = mx_s;
         }
 
+        SSTAMP(2);   // window_slide
         // ---- dE of every candidate stem: only the loops it changes (rafft/rafft.py:97-98 evaluates the whole structure)
         // prefix sums of the branches' stem terms: every loop below costs O(1) whatever its number of branches
         {
@@ -209,6 +217,7 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
             }
         }
         wave_sync();
+        SSTAMP(3);   // branch prefix sums
         const double par_e = dcal_to_energy(par_dcal);
         const BrPrefix pf{pe_ext, pe_ml, psp};
         int w_dd[2];
@@ -254,6 +263,7 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
                 }
             }
         }
+        SSTAMP(4);   // dE
         // lag values (rafft/utils.py:125-132: exact pair counts, fp64 divide) - of the kept candidates only, they break dE ties
         double w_val[2] = {0.0, 0.0};
 #pragma unroll
@@ -316,6 +326,7 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
                 val[slot[s]] = w_val[s];
             }
         wave_sync();
+        SSTAMP(5);   // lag values, compaction, slot reservation
         if (!ovf) {
 #pragma unroll
             for (int s = 0; s < 2; s++)
@@ -354,7 +365,14 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
             if (dbg && d.dbg.n_ranked) d.dbg.n_ranked[1] = nkept;
             st_items++; st_n += n; st_lags += m; st_nbr += nbr;
         }
+        SSTAMP(6);   // order + emit
     }
+    if (eprof) {
+        for (int k = 0; k < 7; k++) atomicAdd(&d.prof_e[cls * PROF_E + k], eacc[k]);
+        atomicAdd(&d.prof_e[cls * PROF_E + 8], n_rounds);
+        atomicAdd(&d.prof_e[cls * PROF_E + 9], 1ULL);
+    }
+#undef SSTAMP
     // statistics: one atomic per wavefront and counter
     for (int o = 32; o > 0; o >>= 1) {
         st_items += __shfl_xor(st_items, o, 64); st_n += __shfl_xor(st_n, o, 64);

@@ -92,6 +92,8 @@ struct Counters {
     // same-address returning atomic per wavefront and round: ~12 ns each, served one after the other - 50 us for the 4096
     // wavefronts of a launch to learn that there is nothing (left) to do, and as much for every round they start together.
     ShardCtr wcur[NCLS][NSHARD];
+    unsigned long long wdone[NCLS];           // bit s: the last chunk of shard s has been claimed
+    unsigned long long wdone_pad[8 - NCLS];
     struct StatLine { unsigned long long items, n, lags, nbr, alias, children, struct_len, pad; } xstat[NCLS][NSHARD];
 };
 

@@ -150,25 +150,35 @@ __device__ inline void build_masks(unsigned long long *F, unsigned long long *R,
 }
 
 // Next chunk of CH work items of class `cls` for this wavefront (all 64 lanes call it; `shard` is the wavefront's current
-// shard, kept between calls): returns the first item of the chunk, or ~0u when every chunk of the list has been handed
-// out.  The 64 cursors are looked at with ONE load (lane l reads shard l), then one lane claims from the next shard that
-// still has chunks - the atomics of a launch spread over 64 cache lines instead of queueing on one address.
-__device__ inline unsigned fetch_chunk(const Dev &d, int cls, unsigned n_items, unsigned CH, int &shard)
+// shard, `failed` the shards it has found empty - both kept between calls): returns the first item of the chunk, or ~0u
+// when every chunk of the list has been handed out.  Chunk c belongs to shard c % NSHARD; the fast path is ONE returning
+// atomic on the wavefront's own shard (64 cursors, 64 bytes apart: 0.56 ns per atomic chip-wide against 11.4 ns on a
+// single cursor, tools/micro/atomic_spacing.hip).  Whoever claims the last chunk of a shard sets its bit in wdone[cls];
+// a wavefront that finds its shard empty reads that ONE word and moves to a shard that still has chunks.
+__device__ inline unsigned fetch_chunk(const Dev &d, int cls, unsigned n_items, unsigned CH, int &shard, unsigned long long &failed)
 {
     const int lane = threadIdx.x & 63;
     const unsigned chunks_total = (n_items + CH - 1) / CH;
-    const unsigned mine = (unsigned)lane < chunks_total ? (chunks_total - (unsigned)lane + (NSHARD - 1)) / NSHARD : 0u;   // chunks of shard `lane`
+    const unsigned long long exist = chunks_total >= NSHARD ? ~0ULL : ((1ULL << chunks_total) - 1ULL);      // shards that hold any chunk
     for (;;) {
-        const unsigned cur = (unsigned)__hip_atomic_load(&d.c->wcur[cls][lane].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long live = __ballot(cur < mine);
+        if ((exist >> shard) & ~(failed >> shard) & 1ULL) {
+            const unsigned cnt = (chunks_total - (unsigned)shard + (NSHARD - 1)) / NSHARD;                     // chunks of this shard
+            unsigned k = 0;
+            if (lane == 0) k = (unsigned)atomicAdd(&d.c->wcur[cls][shard].v, 1ULL);
+            k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
+            if (k < cnt) {
+                if (k == cnt - 1 && lane == 0) atomicOr(&d.c->wdone[cls], 1ULL << shard);
+                return ((unsigned)shard + NSHARD * k) * CH;
+            }
+            failed |= 1ULL << shard;
+        }
+        unsigned long long done = 0;
+        if (lane == 0) done = __hip_atomic_load(&d.c->wdone[cls], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        done = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(done >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)done);
+        const unsigned long long live = exist & ~(done | failed);
         if (!live) return ~0u;
         const unsigned long long rot = shard ? ((live >> shard) | (live << (64 - shard))) : live;
         shard = (shard + __ffsll((long long)rot) - 1) & (NSHARD - 1);
-        unsigned k = 0;
-        if (lane == 0) k = (unsigned)atomicAdd(&d.c->wcur[cls][shard].v, 1ULL);
-        k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
-        const unsigned chunk = (unsigned)shard + NSHARD * k;
-        if (chunk < chunks_total) return chunk * CH;
     }
 }
 static_assert(NSHARD == 64, "fetch_chunk reads one work cursor per lane");
@@ -199,6 +209,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
 {
     const int cls = cls_arg & 0xFF;
     const bool dry = (cls_arg & 0x100) != 0;      // diagnostic (RAFFT_TWICE=2): everything but the result stores
+    const int skip_lvl = (cls_arg >> 9) & 15;      // diagnostic (RAFFT_TWICE=3..7): a region stops after window_slide (1), ranking (2), lag values (3), FFTs (4), LDS fill (5)
 
     static_assert(WPB == 1 || NT == 64, "only the one-wavefront class packs several wavefronts into a workgroup");
     static_assert(LONGSEQ == 0 || NT > 64, "long sequences never reach the one-wavefront class");
@@ -259,6 +270,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
     const unsigned FETCH = (NT == 64 && n_items > 4u * n_teams) ? 4u : 1u;
     unsigned fetch_base = 0, fetch_left = 0;                 // uniform across the workgroup
     int fshard = (int)(gteam & (NSHARD - 1));                // work-cursor shard this team claims from next (fetch_chunk)
+    unsigned long long ffailed = 0;
     unsigned long long slab_base = 0; unsigned slab_left = 0;   // thread 0 only
 
     for (;;) {
@@ -268,10 +280,11 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (tid == 0) atomicAdd(&d.prof_e[cls * PROF_E + 32], (unsigned long long)(clock64() - t0_));
         }
+        unsigned long long ft0 = eprof ? clock64() : 0;
         if (fetch_left == 0) {
-            if (NT == 64) fetch_base = fetch_chunk(d, cls, n_items, FETCH, fshard);
+            if (NT == 64) fetch_base = fetch_chunk(d, cls, n_items, FETCH, fshard, ffailed);
             else {
-                if (tid < 64) { const unsigned b_ = fetch_chunk(d, cls, n_items, FETCH, fshard); if (tid == 0) misc[8] = (int)b_; }
+                if (tid < 64) { const unsigned b_ = fetch_chunk(d, cls, n_items, FETCH, fshard, ffailed); if (tid == 0) misc[8] = (int)b_; }
                 ESYNC();
                 fetch_base = (unsigned)misc[8];
             }
@@ -284,7 +297,9 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
         const unsigned item = NT == 64 ? (unsigned)__builtin_amdgcn_readfirstlane((int)fetch_base) : fetch_base;
         fetch_base++; fetch_left--;
         if (item >= n_items) { fetch_left = 0; continue; }       // (tail of the list's last chunk; other shards may still hold chunks)
+        if (eprof) { const unsigned long long t_ = clock64(); eacc[8] += t_ - ft0; ft0 = t_; }
         const int nid = NT == 64 ? __builtin_amdgcn_readfirstlane(d.work[cls][item]) : d.work[cls][item];
+        if (eprof) { const unsigned long long t_ = clock64(); eacc[9] += t_ - ft0 + (unsigned long long)(nid & 0); ft0 = t_; }
         const int L = d.nd[nid].L;                 // (the record carries its sequence's length and offset: no look-up keyed on `seq`)
         const int n = d.nd[nid].n, ci = d.nd[nid].ci, cj = d.nd[nid].cj, nbr = d.nd[nid].nbr;
         const int par_dcal = d.nd[nid].pdcal;
@@ -302,6 +317,8 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
         const int Pk = LONGSEQ == 2 ? 0 : P;       // the lag values occupy 8 P bytes of region A - unless they live in HBM
         const int size_bk = n <= 8 ? 0 : n <= 16 ? 1 : n <= 32 ? 2 : n <= 64 ? 3 : n <= 128 ? 4 : 5;      // (diagnostic: regions and cycles by size)
         ESTAMP(0);   // fetch + header
+        if (skip_lvl >= 7) continue;
+        if (skip_lvl >= 6) { if (tid == 0 && n + ci + cj + nbr + L + par_dcal == -12345) d.c->overflow = 1; continue; }     // (header values consumed)
         const unsigned long long t_region0 = eprof ? clock64() : 0;
         const int Kp = d.K < m ? (d.K > 0 ? d.K : 0) : m;
 
@@ -319,6 +336,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
         }
 
         ESTAMP(1);   // LDS fill
+        if (skip_lvl >= 5) continue;
         // ---- correlation: conv(A,U), conv(G,C), conv(G,U).
         // Regions of <= 64 positions (one wavefront holds the whole strand in 64-bit masks) use the exact
         // direct form: popcount(mask & shifted reversed mask) per lag - the analogue of scipy's own
@@ -434,6 +452,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
         }
 
         ESTAMP(2);   // FFTs
+        if (skip_lvl >= 4) continue;
         // ---- lag values (exact integer pair counts, IEEE fp64 divide) and ranking
         // Which lags are searched (rafft/rafft.py:117-118 takes the nb_mode best by (value desc, lag desc)):
         //  - all of them when 2n-1 <= nb_mode: nothing to rank;
@@ -520,6 +539,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
             }
         }
         ESTAMP(3);   // lag values
+        if (skip_lvl >= 3) continue;
         if (selected) {
             int *hist = (int *)(lds + lay.offA + (LONGSEQ == 2 ? lay.szA - 2048 : 10 * P));     // 256 bins in the slack of region A (its end when the masks are already there)
             int *shs = hist + 256;                                   // scan scratch [32]
@@ -631,6 +651,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
         }
 
         ESTAMP(4);   // ranking
+        if (skip_lvl >= 2) continue;
         // ---- window_slide (rafft/rafft.py:36-83).  Small regions: one lane per ranked lag.  Big regions:
         // each diagonal is cut into C chunks handled by different lanes; a lane first walks back to the last
         // zero cell before its chunk and replays the recurrence from there (same fp64 operation order, so
@@ -803,6 +824,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
         ESYNC();
 
         ESTAMP(5);   // window_slide
+        if (skip_lvl >= 1) continue;
         // ---- dE of every candidate stem: only the loops it changes, from the branch list
         const double par_e = dcal_to_energy(par_dcal);
         // prefix sums of the branches' stem terms (region A is free now except, when nothing was ranked, the
@@ -984,6 +1006,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
     }
     if (eprof) {
         for (int k = 0; k < 8; k++) atomicAdd(&d.prof_e[cls * PROF_E + k], eacc[k]);
+        atomicAdd(&d.prof_e[cls * PROF_E + 40], eacc[8]); atomicAdd(&d.prof_e[cls * PROF_E + 41], eacc[9]);
     }
 #undef ESTAMP
     if (tid == 0 && st_items) {
@@ -1075,6 +1098,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
     // the expand kernels of this step are done with their work lists: reset them for dedupe_kernel / the next step
     if (sq == 0 && tid < NCLS) d.c->n_work[tid] = 0;
     if (sq == 0) for (int i = tid; i < NCLS * NSHARD; i += BS_NT) d.c->wcur[i / NSHARD][i % NSHARD].v = 0;
+    if (sq == 0 && tid < NCLS) d.c->wdone[tid] = 0;
     if (d.done[sq]) return;
     const bool prof = d.prof && sq == d.prof_seq && tid == 0;   // diagnostic stamps (RAFFT_TRACE=3)
     unsigned long long tprev = prof ? clock64() : 0;
