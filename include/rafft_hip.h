@@ -116,6 +116,10 @@ int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs,
 
 void rafft_free_result(rafft_result *r);
 
+/* Waits for the batches in flight, stops the library's scheduler thread and joins it.  Registered with atexit() when the
+ * first batch is submitted; call it by hand before dlclose().  Later calls start a fresh scheduler. */
+void rafft_shutdown(void);
+
 /* The same, asynchronously - continuous batching.  rafft_fold_submit() copies the sequences, queues the batch and
  * returns at once; rafft_fold_wait() blocks until that batch is done and hands over its result (then the job
  * handle is gone).  One library thread drives all batches in flight: the last folding steps of a batch - which only

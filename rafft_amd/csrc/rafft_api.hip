@@ -110,6 +110,8 @@ struct Ctx {
     std::deque<std::shared_ptr<struct Batch>> submitted;
     int n_inflight = 0;                // batches submitted and not yet finished
     bool sched_started = false;
+    bool stop = false;                 // under qmu: the process is exiting (rafft_shutdown): the scheduler thread returns
+    std::thread sched_thread;
 };
 // Never destroyed: the scheduler thread sleeps on its condition variable for as long as the process lives, and a
 // condition variable must not be destroyed under a waiter (glibc's pthread_cond_destroy would block process exit).
@@ -142,7 +144,8 @@ rafft_par::ParamSet &param_set()
 }
 
 // Device energy tables for `temp`: the current parameter set rescaled as ViennaRNA does for md.temperature
-// (rafft/utils.py:17-21).  Every C-ABI call is synchronous, so the device is idle when the tables are replaced.
+// (rafft/utils.py:17-21).  Submission is asynchronous: the caller (submit_locked) drains the batches in flight first, so
+// the device is idle when the tables are replaced.
 int ensure_tables(double temp)
 {
     if (!g.T_dirty && g.T_temp == temp) return 0;
@@ -173,7 +176,7 @@ int init_ws(Workspace &w)
     }
     HIPCHK(hipStreamCreateWithFlags(&w.copy_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&w.ev_hot, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&w.ev_hot, hipEventDisableTiming | hipEventBlockingSync));   // (the scheduler sleeps on it when it has spun long enough)
     static_assert(offsetof(Counters, node) <= 512, "hot counters must fit the pinned read-back slot");
     HIPCHK(hipHostMalloc(&w.hot, 512, hipHostMallocDefault));
     w.ready = true;
@@ -516,7 +519,16 @@ struct Wave {
     bool heavy(unsigned below) const { return below != 0x7fffffffu && S >= 256 && !finished && (steps < 3 || last_mat >= below); }
     int setup();
     int issue_step();
-    bool ready() { return hipEventQuery(g.ev_hot) == hipSuccess; }
+    // 1: the step's read-back has landed, 0: not yet, -1: the device reported an error (sticky: the wave is failed, not polled forever)
+    int ready()
+    {
+        const hipError_t e = hipEventQuery(g.ev_hot);
+        if (e == hipSuccess) return 1;
+        if (e == hipErrorNotReady) return 0;
+        fail(RAFFT_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(e));
+        return -1;
+    }
+    std::chrono::steady_clock::time_point t_issued;      // when the running step was issued (the scheduler blocks on the oldest)
     int after_beam();
     int finish();
 };
@@ -525,6 +537,8 @@ int Wave::setup()
 {
     S = seqs.size();
     tw0 = std::chrono::steady_clock::now();
+    // test hook: a wave of exactly this many sequences fails hard (what a structure beyond the kernels' limits does)
+    if (const char *e = getenv("RAFFT_TEST_HARD_FAIL")) if ((int)S == atoi(e)) return fail(RAFFT_ERR_PARAM, "test hook: hard failure of this wave");
     off.resize(S); len.resize(S);
     sumL = 0;
     for (size_t i = 0; i < S; i++) { off[i] = (int)sumL; len[i] = seqs[i].len; sumL += seqs[i].len; }
@@ -740,6 +754,7 @@ int Wave::issue_step()
     steps++;
     HIPCHK(hipMemcpyAsync(g.hot, g.counters.p, hot_len, hipMemcpyDeviceToHost, st));   // pinned: truly asynchronous
     HIPCHK(hipEventRecord(g.ev_hot, st));
+    t_issued = std::chrono::steady_clock::now();
     return 0;
 }
 
@@ -1169,19 +1184,55 @@ static void scheduler_main()
         }
         job.members.clear();
     };
+    // A job some of whose member batches have failed elsewhere keeps folding for the healthy ones: the failed members'
+    // sequences are taken out (their batches are released from this job), the rest stays one job.  False: nothing left.
+    auto strip_failed = [&](Job &job) -> bool {
+        bool any = false;
+        for (auto &m : job.members) any = any || m->rc != 0;
+        if (!any) return true;
+        std::vector<int> remap(job.members.size(), -1);
+        std::vector<std::shared_ptr<Batch>> keep_m;
+        for (size_t i = 0; i < job.members.size(); i++) {
+            auto &m = job.members[i];
+            if (m->rc == 0) { remap[i] = (int)keep_m.size(); keep_m.push_back(m); }
+            else if (--m->pending == 0) { finalize_batch(m); n_active_batches--; }
+        }
+        std::vector<SeqIn> keep_s;
+        for (SeqIn sq : job.seqs) if (remap[sq.bi] >= 0) { sq.bi = remap[sq.bi]; keep_s.push_back(sq); }
+        job.members.swap(keep_m); job.seqs.swap(keep_s);
+        return !job.members.empty() && !job.seqs.empty();
+    };
+    // A hard error of a wave that folds several batches (merged by the scheduler because their parameters were equal)
+    // must not fail batches whose own sequences are fine: every member is folded again on its own; only a job of ONE
+    // batch takes the error.
+    auto fail_or_split = [&](Slot &sl, int rc, const std::string &err, std::deque<Job> *queue_) {
+        if (sl.job.members.size() <= 1 || rc == RAFFT_ERR_NO_DEVICE) { release(sl.job, rc, err); return; }
+        for (size_t i = 0; i < sl.job.members.size(); i++) {
+            Job one;
+            one.est = sl.job.est; one.depth = sl.job.depth; one.no_merge = true;
+            one.members.assign(1, sl.job.members[i]);
+            for (SeqIn sq : sl.job.seqs) if (sq.bi == (int)i) { sq.bi = 0; one.seqs.push_back(sq); }
+            if (one.seqs.empty()) { if (--sl.job.members[i]->pending == 0) { finalize_batch(sl.job.members[i]); n_active_batches--; } continue; }
+            queue_[sl.lane].push_front(std::move(one));        // (the member's pending count moves with it)
+        }
+        sl.job.members.clear();
+    };
+    auto last_progress = std::chrono::steady_clock::now();
     for (;;) {
         {
             if (n_active_batches == 0) free_garbage();            // nothing in flight: the device is idle, hipFree is cheap
             std::unique_lock<std::mutex> lk(g.qmu);
+            if (g.stop && n_active_batches == 0 && g.submitted.empty()) return;
             if (n_active_batches == 0 && g.submitted.empty()) {
                 // idle for a second: give back workspaces that grew huge (re-allocating 80 GB costs seconds, so not between
                 // back-to-back batches)
-                if (!g.qcv_sched.wait_for(lk, std::chrono::seconds(1), [] { return !g.submitted.empty(); })) {
+                if (!g.qcv_sched.wait_for(lk, std::chrono::seconds(1), [] { return !g.submitted.empty() || g.stop; })) {
                     lk.unlock();
                     trim_workspaces();
                     lk.lock();
-                    g.qcv_sched.wait(lk, [] { return !g.submitted.empty(); });
+                    g.qcv_sched.wait(lk, [] { return !g.submitted.empty() || g.stop; });
                 }
+                if (g.stop && g.submitted.empty()) return;
             }
             while (!g.submitted.empty()) {
                 std::shared_ptr<Batch> bp = g.submitted.front();
@@ -1203,8 +1254,17 @@ static void scheduler_main()
         // ---- advance the running waves
         for (int i = 0; i < MAX_PIPES; i++) {
             Slot &sl = slot[i];
-            if (!sl.wave || !sl.wave->ready()) continue;
+            if (!sl.wave) continue;
+            const int rdy = sl.wave->ready();
+            if (rdy == 0) continue;
             progressed = true;
+            if (rdy < 0) {                                   // sticky device error: fail the job, free the slot
+                const std::string err = g_err;
+                { hipError_t e_ = hipDeviceSynchronize(); (void)e_; }
+                release(sl.job, RAFFT_ERR_HIP, err);
+                sl.wave.reset();
+                continue;
+            }
             int rc = sl.wave->after_beam();
             if (sl.wave->finished) {
                 rc = sl.wave->result;
@@ -1217,13 +1277,19 @@ static void scheduler_main()
                         sl.job.depth++;
                         queue[sl.lane].push_front(std::move(sl.job));
                     }
+                } else if (rc) {
+                    const std::string err = g_err;
+                    { hipError_t e_ = hipDeviceSynchronize(); (void)e_; }
+                    sl.wave.reset();
+                    fail_or_split(sl, rc, err, queue);
                 } else
-                    release(sl.job, rc, g_err);
+                    release(sl.job, 0, "");
                 sl.wave.reset();
             } else if (rc) {
+                const std::string err = g_err;
                 { hipError_t e_ = hipDeviceSynchronize(); (void)e_; }
-                release(sl.job, rc, g_err);
                 sl.wave.reset();
+                fail_or_split(sl, rc, err, queue);
             }
         }
         // ---- admit queued jobs: the long-tail lane first (light from the start), then the bulk lane
@@ -1233,9 +1299,9 @@ static void scheduler_main()
         for (int ln = 0; ln < 2; ln++) {
             while (!queue[ln].empty() && n_running < max_waves) {
                 Job &front = queue[ln].front();
-                bool failed = false;                              // a member already failed elsewhere: do not fold for it
-                for (auto &m : front.members) failed = failed || m->rc != 0;
-                if (failed) { Job j = std::move(front); queue[ln].pop_front(); release(j, 0, ""); progressed = true; continue; }
+                if (!strip_failed(front)) {                       // every member already failed elsewhere: nothing to fold
+                    Job j = std::move(front); queue[ln].pop_front(); release(j, 0, ""); progressed = true; continue;
+                }
                 const bool job_heavy = front.seqs.size() >= 256;
                 if (job_heavy && heavy_running) break;
                 int w = -1;                                       // a free workspace, this lane's parity first
@@ -1293,24 +1359,46 @@ static void scheduler_main()
                 }
                 progressed = true;
                 if (rc) {
+                    const std::string err = g_err;
                     { hipError_t e_ = hipDeviceSynchronize(); (void)e_; }
-                    release(sl.job, rc, g_err);
                     sl.wave.reset();
+                    fail_or_split(sl, rc, err, queue);
                     continue;
                 }
                 n_running++;
                 heavy_running = heavy_running || (job_heavy && sl.wave->heavy(admit_below()));
             }
         }
-        if (!progressed) std::this_thread::yield();
+        // Nothing moved.  A step's read-back lands within tens to hundreds of microseconds, so the thread polls for a
+        // short while (a wake-up through the driver costs about as much as a step of the tail); after that it SLEEPS on
+        // the read-back event of the oldest running step (created with hipEventBlockingSync) instead of holding a core.
+        // New submissions wait for that one step at most.
+        const auto now = std::chrono::steady_clock::now();
+        if (progressed) { last_progress = now; continue; }
+        static const long spin_us = getenv("RAFFT_SCHED_SPIN_US") ? atol(getenv("RAFFT_SCHED_SPIN_US")) : 200;
+        if (std::chrono::duration_cast<std::chrono::microseconds>(now - last_progress).count() < spin_us) { std::this_thread::yield(); continue; }
+        Wave *oldest = nullptr;
+        for (int i = 0; i < MAX_PIPES; i++)
+            if (slot[i].wave && (!oldest || slot[i].wave->t_issued < oldest->t_issued)) oldest = slot[i].wave.get();
+        if (oldest) { hipError_t e_ = hipEventSynchronize(oldest->g.ev_hot); (void)e_; }      // (an error shows up in ready())
+        else {
+            // nothing running yet something queued (a job waiting for HBM that running waves hold cannot happen here: no wave runs)
+            std::unique_lock<std::mutex> lk(g.qmu);
+            g.qcv_sched.wait_for(lk, std::chrono::milliseconds(1), [] { return !g.submitted.empty() || g.stop; });
+        }
+        last_progress = std::chrono::steady_clock::now();
     }
 }
 
+extern "C" void rafft_shutdown(void);
 static void start_scheduler()
 {
     if (g.sched_started) return;
     g.sched_started = true;
-    std::thread(scheduler_main).detach();     // lives as long as the process
+    g.sched_thread = std::thread(scheduler_main);
+    // stopped and joined at process exit BEFORE the HIP runtime tears down (atexit handlers run in reverse order of
+    // registration and the runtime registered its own when it was initialised, earlier than this)
+    atexit(rafft_shutdown);
 }
 
 // no batch may be in flight when the device tables change or a seam call borrows workspace 0
@@ -1327,6 +1415,24 @@ void free_out(HostOut *o) { delete o; }      // (its pinned chunks go back to th
 extern "C" {
 
 const char *rafft_last_error(void) { return g_err.c_str(); }
+
+/* Drains the batches in flight, stops the scheduler thread and joins it.  Registered with atexit(); may be called by
+ * hand before unloading the library.  Entry points called afterwards start a fresh scheduler. */
+void rafft_shutdown(void)
+{
+    std::thread t;
+    {
+        std::unique_lock<std::mutex> lk(g.qmu);
+        if (!g.sched_started) return;
+        g.qcv_done.wait(lk, [] { return g.n_inflight == 0; });
+        g.stop = true;
+        t = std::move(g.sched_thread);
+    }
+    g.qcv_sched.notify_all();
+    if (t.joinable()) t.join();
+    std::lock_guard<std::mutex> lk(g.qmu);
+    g.stop = false; g.sched_started = false;
+}
 
 const char *rafft_version(void) { return "raffthip 0.2 (gfx950, HIP; built-in Turner-2004 37C tables or ViennaRNA parameter files)"; }
 
@@ -1372,6 +1478,7 @@ static int submit_locked(const rafft_params *p, int n_seq, const char *const *se
         rafft_seq_result &sr = ho->seq[i];
         memset(&sr, 0, sizeof sr);
         sr.length = L[i];
+        sr.status = RAFFT_ERR_HIP;          // "never folded": only emit_rows sets RAFFT_OK, with the rows in place
         if (L[i] <= 0) { sr.status = RAFFT_ERR_EMPTY; continue; }
         char *dst = b.seqbuf.data() + o;
         memcpy(dst, seqs[i], (size_t)L[i]);
@@ -1751,6 +1858,10 @@ int rafft_kin_rate_matrix(int n_steps, const int *step_size, int L, const char *
     if (!step_size || !rows || !uid || !energy || !rate_device || n_steps < 1 || L < 1 || L > 32767 || n_unique < 1 || !(kt > 0))
         return fail(RAFFT_ERR_PARAM, "bad argument");
     if (int rc = init_ctx(-1)) return rc;
+    // like the other seam calls: no fold in flight (hipMalloc / hipFree below synchronise the device, and the matrix is
+    // written on the library's stream - the caller hands over a buffer its own stream is done with), workspace 0 held
+    drain();
+    std::lock_guard<std::mutex> ws_lk(g.ws_mu);
     if (int rc = init_ws(g.ws[0])) return rc;
     long long n = 0;
     std::vector<int> row0(n_steps);

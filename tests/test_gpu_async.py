@@ -143,3 +143,37 @@ def test_gpu_merged_wave_overflow_regrows_and_stays_exact(bench_rows, monkeypatc
     pend = [rafft_amd.submit_batch(v, **kw) for v in variants]
     for i, pb in enumerate(pend):
         assert key(pb.result(), True) == want[i]
+
+
+def test_gpu_hard_failure_of_one_batch_leaves_the_others_whole(monkeypatch):
+    """(a) a wave that folds several batches - merged by the scheduler because their parameters are equal - and hits a
+    hard error: every member is folded again on its own and none of them pays for it; (b) a batch one of whose jobs
+    failed: its other, still queued job is dropped, the batches queued behind it are folded completely (they used to come
+    back as empty successes)"""
+    rng = np.random.default_rng(29)
+    rnd = lambda lens: ["".join(rng.choice(list("ACGU"), int(n))) for n in lens]
+    A, B = rnd(rng.integers(30, 120, size=300)), rnd(rng.integers(30, 120, size=340))
+    kw = dict(nb_mode=100, max_stack=10, max_branch=200)
+    want_a, want_b = key(rafft_amd.fold_batch(A, **kw), False), key(rafft_amd.fold_batch(B, **kw), False)
+    # (a) one wave at a time: while a blocker folds, A and B queue up and are merged into one wave of 640 sequences
+    monkeypatch.setenv("RAFFT_MAX_WAVES", "1")
+    monkeypatch.setenv("RAFFT_TEST_HARD_FAIL", "640")
+    _native.lib().rafft_shutdown()          # the scheduler thread reads RAFFT_MAX_WAVES when it starts: stop it, the next submit starts a fresh one
+    blocker = rafft_amd.submit_batch(rnd(rng.integers(200, 400, size=400)), nb_mode=100, max_stack=50, max_branch=1000)
+    pa, pb = rafft_amd.submit_batch(A, **kw), rafft_amd.submit_batch(B, **kw)
+    blocker.result()
+    assert key(pa.result(), False) == want_a and key(pb.result(), False) == want_b
+    # (b) A2 = A + two long sequences: cut in a long-tail job (2 sequences: fails by the hook) and a bulk job
+    monkeypatch.setenv("RAFFT_TEST_HARD_FAIL", "2")
+    A2 = A + rnd([1500, 1700])
+    blocker = rafft_amd.submit_batch(rnd(rng.integers(200, 400, size=400)), nb_mode=100, max_stack=50, max_branch=1000)
+    pa, pb = rafft_amd.submit_batch(A2, **kw), rafft_amd.submit_batch(B, **kw)
+    blocker.result()
+    with pytest.raises(Exception) as ei:
+        pa.result()
+    assert "hard failure" in str(ei.value)
+    assert key(pb.result(), False) == want_b
+    monkeypatch.delenv("RAFFT_TEST_HARD_FAIL")
+    monkeypatch.delenv("RAFFT_MAX_WAVES")
+    _native.lib().rafft_shutdown()
+    assert key(rafft_amd.fold_batch(A2, **kw), False)[:300] == want_a
