@@ -3,7 +3,14 @@ bin/rafft (bin/rafft:7-31,34-80), running the fold on the MI355X.
 
 Differences, all additive: `-sf` may hold several FASTA records (they are folded as one
 GPU batch and printed one after the other); `--nono` (the reference's to-be-removed
-test implementation, bin/rafft:29) is not provided."""
+test implementation, bin/rafft:29) is not provided.
+
+Energies: the reference evaluates with ViennaRNA's loaded parameter set (rafft/utils.py:17-21).  Here the set is read ONCE, up
+front: from RAFFT_PARAMS=<ViennaRNA 2.x parameter file>, else through an importable `RNA` module (RNA.params_save),
+else the built-in Turner-2004 37 C tables are used.  The built-in tables reproduce all 11 505 energies the reference
+publishes, but entries no published energy exercises are rule-derived: out of sample about 1 structure in 20 gets
+another energy than ViennaRNA's - supply ViennaRNA's own tables when that matters.  Which set is
+active: `python -c "import rafft_amd; print(rafft_amd.params_info())"`."""
 import argparse
 import sys
 
@@ -23,7 +30,7 @@ _OPTIONS = [
     (("--bp_only",), dict(action="store_true", help="accepted, unused")),
     (("--bench",), dict(action="store_true", help="one line per structure: seq len structure energy #pairs")),
     (("-tr", "--traj"), dict(action="store_true", help="print the whole fast-folding graph")),
-    (("--temp",), dict(type=float, default=37.0, help="temperature; only 37.0 is supported")),
+    (("--temp",), dict(type=float, default=37.0, help="temperature in C (default 37).  Other temperatures need a ViennaRNA parameter file with\nenthalpies (RAFFT_PARAMS=<file>, or an importable RNA module): the built-in tables are 37 C only")),
     (("-gc", "--gc_wei"), dict(type=float, default=3.0, help="GC weight")),
     (("-au", "--au_wei"), dict(type=float, default=2.0, help="AU weight")),
     (("-gu", "--gu_wei"), dict(type=float, default=1.0, help="GU weight")),

@@ -13,6 +13,7 @@
 // Without a loaded file the built-in 37 C tables are used (params/turner2004_tables.h: the published Turner-2004
 // model arbitrated by the reference's 11 505 energy rows; no enthalpies, so only temp == 37).
 #pragma once
+#include <algorithm>
 #include "rafft_device.h"
 #include "../../params/turner2004_tables.h"
 
@@ -82,7 +83,7 @@ inline void builtin(ParamSet &P)
 
 // ---------------------------------------------------------------- reader
 
-struct Section { std::vector<std::string> tok; };
+struct Section { std::vector<std::string> tok; std::vector<int> line; int head_line = 0; };   // tokens with the line each came from; line of the '# name' header
 
 inline bool tokenize(const std::string &text, std::map<std::string, Section> &secs, std::string &err)
 {
@@ -92,7 +93,11 @@ inline bool tokenize(const std::string &text, std::map<std::string, Section> &se
     for (size_t i = 0; i < text.size();) {
         if (text[i] == '/' && i + 1 < text.size() && text[i + 1] == '*') {
             const size_t e = text.find("*/", i + 2);
-            if (e == std::string::npos) { err = "unterminated comment"; return false; }
+            if (e == std::string::npos) {
+                err = "line " + std::to_string(1 + std::count(text.begin(), text.begin() + i, '\n')) + ": unterminated comment";
+                return false;
+            }
+            for (size_t k = i; k < e + 2; k++) if (text[k] == '\n') s.push_back('\n');     // (line numbers survive)
             i = e + 2;
             s.push_back(' ');
         } else s.push_back(text[i++]);
@@ -100,11 +105,13 @@ inline bool tokenize(const std::string &text, std::map<std::string, Section> &se
     bool header = false, ended = false;
     Section *cur = nullptr;
     size_t p = 0;
+    int lineno = 0;
     while (p < s.size() && !ended) {
         size_t e = s.find('\n', p);
         if (e == std::string::npos) e = s.size();
         std::string line = s.substr(p, e - p);
         p = e + 1;
+        lineno++;
         size_t a = line.find_first_not_of(" \t\r");
         if (a == std::string::npos) continue;
         if (line[a] == '#') {
@@ -115,6 +122,7 @@ inline bool tokenize(const std::string &text, std::map<std::string, Section> &se
             std::string name = line.substr(b, c == std::string::npos ? std::string::npos : c - b);
             if (name == "END") { ended = true; break; }
             cur = &secs[name];
+            cur->head_line = lineno;
             continue;
         }
         if (!cur) continue;
@@ -124,6 +132,7 @@ inline bool tokenize(const std::string &text, std::map<std::string, Section> &se
             if (b == std::string::npos) break;
             size_t c = line.find_first_of(" \t\r", b);
             cur->tok.push_back(line.substr(b, c == std::string::npos ? std::string::npos : c - b));
+            cur->line.push_back(lineno);
             if (c == std::string::npos) break;
             q = c;
         }
@@ -154,13 +163,16 @@ inline bool fill(const std::map<std::string, Section> &secs, const char *name, s
     }
     const auto &tk = it->second.tok;
     if (tk.size() != dst.size()) {
-        err = std::string("section '# ") + name + "': " + std::to_string(tk.size()) + " values, expected " + std::to_string(dst.size());
+        // where it goes wrong: the line of the first surplus value, or the last line of a block that is short
+        const int at = tk.size() > dst.size() ? it->second.line[dst.size()] : (tk.empty() ? it->second.head_line : it->second.line.back());
+        err = std::string("section '# ") + name + "' (line " + std::to_string(it->second.head_line) + "): " + std::to_string(tk.size()) + " values, expected " +
+              std::to_string(dst.size()) + (tk.size() > dst.size() ? "; first surplus value on line " : "; block ends on line ") + std::to_string(at);
         return false;
     }
     for (size_t i = 0; i < tk.size(); i++) {
         int v = 0;
         bool keep = false;
-        if (!tok_int(tk[i], v, &keep)) { err = std::string("section '# ") + name + "': bad token '" + tk[i] + "'"; return false; }
+        if (!tok_int(tk[i], v, &keep)) { err = std::string("section '# ") + name + "', line " + std::to_string(it->second.line[i]) + ": bad token '" + tk[i] + "'"; return false; }
         if (!keep) *dst[i] = v;
     }
     return true;
@@ -292,47 +304,57 @@ inline std::string format(const ParamSet &P)
     static const char *pn[8] = {"NP", "CG", "GC", "GU", "UG", "AU", "UA", "NN"};
     static const char *bn = "NACGU";
     o += "## RNAfold parameter file v2.0\n\n/* written by libraffthip (rafft_save_params); source: " + P.source + " */\n";
-    for (int w = 0; w < 2; w++) {
-        if (w && !P.has_dH) break;
-        const std::string sfx = w ? "_enthalpies" : "";
-        o += "\n# stack" + sfx + "\n/*  CG     GC     GU     UG     AU     UA     NN  */\n";
+    // every energy array is followed by its `_enthalpies` twin, in ViennaRNA's order of sections
+    const int nw = P.has_dH ? 2 : 1;
+    auto sfx = [](int w) { return std::string(w ? "_enthalpies" : ""); };
+    for (int w = 0; w < nw; w++) {
+        o += "\n# stack" + sfx(w) + "\n/*  CG     GC     GU     UG     AU     UA     NN  */\n";
         for (int a = 1; a <= NBP; a++) { for (int c = 1; c <= NBP; c++) { num(P.stack[w][a][c]); o += " "; } o += std::string("   /* ") + pn[a] + " */\n"; }
-        struct M3 { const char *n; const int (*arr)[NBP + 1][5][5]; };
-        const M3 m3[] = {{"mismatch_hairpin", P.mmH}, {"mismatch_interior", P.mmI}, {"mismatch_interior_1n", P.mm1n},
-                         {"mismatch_interior_23", P.mm23}, {"mismatch_multi", P.mmM}, {"mismatch_exterior", P.mmE}};
-        for (const M3 &m : m3) {
-            o += std::string("\n# ") + m.n + sfx + "\n";
+    }
+    struct M3 { const char *n; const int (*arr)[NBP + 1][5][5]; };
+    const M3 m3[] = {{"mismatch_hairpin", P.mmH}, {"mismatch_interior", P.mmI}, {"mismatch_interior_1n", P.mm1n},
+                     {"mismatch_interior_23", P.mm23}, {"mismatch_multi", P.mmM}, {"mismatch_exterior", P.mmE}};
+    for (const M3 &m : m3)
+        for (int w = 0; w < nw; w++) {
+            o += std::string("\n# ") + m.n + sfx(w) + "\n";
             for (int t = 1; t <= NBP; t++) for (int a = 0; a < 5; a++) {
                 for (int c = 0; c < 5; c++) { num(m.arr[w][t][a][c]); o += " "; }
                 snprintf(b, sizeof b, "   /* %s,%c */\n", pn[t], bn[a]); o += b;
             }
         }
-        for (int k = 0; k < 2; k++) {
-            o += std::string("\n# ") + (k ? "dangle3" : "dangle5") + sfx + "\n/*   N      A      C      G      U  */\n";
+    for (int k = 0; k < 2; k++)
+        for (int w = 0; w < nw; w++) {
+            o += std::string("\n# ") + (k ? "dangle3" : "dangle5") + sfx(w) + "\n/*   N      A      C      G      U  */\n";
             for (int t = 1; t <= NBP; t++) { for (int a = 0; a < 5; a++) { num((k ? P.d3 : P.d5)[w][t][a]); o += " "; } o += std::string("   /* ") + pn[t] + " */\n"; }
         }
-        o += "\n# int11" + sfx + "\n";
+    for (int w = 0; w < nw; w++) {
+        o += "\n# int11" + sfx(w) + "\n";
         for (int t = 1; t <= NBP; t++) for (int u = 1; u <= NBP; u++) {
             snprintf(b, sizeof b, "/* %s..%s */\n", pn[t], pn[u]); o += b;
             for (int a = 0; a < 5; a++) { for (int c = 0; c < 5; c++) { num(P.int11[w][t][u][a][c]); o += " "; } o += "\n"; }
         }
-        o += "\n# int21" + sfx + "\n";
+    }
+    for (int w = 0; w < nw; w++) {
+        o += "\n# int21" + sfx(w) + "\n";
         for (int t = 1; t <= NBP; t++) for (int u = 1; u <= NBP; u++) for (int a = 0; a < 5; a++) {
             snprintf(b, sizeof b, "/* %s.%c..%s */\n", pn[t], bn[a], pn[u]); o += b;
             for (int c = 0; c < 5; c++) { for (int e = 0; e < 5; e++) { num(P.int21[w][t][u][a][c][e]); o += " "; } o += "\n"; }
         }
-        o += "\n# int22" + sfx + "\n";
+    }
+    for (int w = 0; w < nw; w++) {
+        o += "\n# int22" + sfx(w) + "\n";
         for (int t = 1; t < NBP; t++) for (int u = 1; u < NBP; u++) for (int a = 1; a < 5; a++) for (int c = 1; c < 5; c++) {
             snprintf(b, sizeof b, "/* %s.%c%c..%s */\n", pn[t], bn[a], bn[c], pn[u]); o += b;
             for (int e = 1; e < 5; e++) { for (int f = 1; f < 5; f++) { num(P.int22[w][t][u][a][c][e][f]); o += " "; } o += "\n"; }
         }
-        const int (*lin[3])[31] = {P.hairpin, P.bulge, P.interior};
-        const char *ln[3] = {"hairpin", "bulge", "interior"};
-        for (int k = 0; k < 3; k++) {
-            o += std::string("\n# ") + ln[k] + sfx + "\n";
+    }
+    const int (*lin[3])[31] = {P.hairpin, P.bulge, P.interior};
+    const char *ln[3] = {"hairpin", "bulge", "interior"};
+    for (int k = 0; k < 3; k++)
+        for (int w = 0; w < nw; w++) {
+            o += std::string("\n# ") + ln[k] + sfx(w) + "\n";
             for (int i = 0; i < 31; i++) { num(lin[k][w][i]); o += ((i % 10) == 9 || i == 30) ? "\n" : " "; }
         }
-    }
     o += "\n# NINIO\n/* Ninio = MIN(max, m*|n1-n2| */\n/*       m   m_dH     max  */\n";
     snprintf(b, sizeof b, "%6d %6d %6d\n", P.ninio[0], P.ninio[1], P.max_ninio); o += b;
     o += "\n# ML_params\n/* F = cu*n_unpaired + cc + ci*loop_degree (+TermAU) */\n/*      cu  cu_dH     cc  cc_dH     ci  ci_dH  */\n";

@@ -169,3 +169,79 @@ def test_python_rescale_matches_viennarna_formula(synthetic_par):
     assert T["stack"][1, 1] == int(h - (h - g) * ((25.0 + 273.15) / 310.15))
     assert np.array_equal(PR.tables_at(par, 37.0)["int21"][1:, 1:], par["int21"][:6, :6])
     assert (PR.tables_at(par, 60.0)["dangle5"] <= 0).all() and (PR.tables_at(par, 60.0)["mismatch_multi"] <= 0).all()
+
+
+def test_saved_file_has_the_layout_viennarna_writes(synthetic_par, tmp_path):
+    """The text `rafft_save_params` writes, section by section, against the layout of ViennaRNA 2.x parameter files
+    (`RNA.params_save`, misc/rna_turner2004.par; format "## RNAfold parameter file v2.0", ViennaRNA
+    src/ViennaRNA/params/io.c): header line first; sections in ViennaRNA's order, every energy array followed by its
+    `_enthalpies` twin; one row per innermost-but-one index; the NN / N rows and columns of non-standard pairs and bases -
+    which the fold never reads - present with ViennaRNA's shapes (7 pair rows, 5 base columns; int22 alone has 6 x 6 x 4^4);
+    comments only as /* */; `# END` last.  Read back by a reader that shares no code with the library."""
+    path, par = synthetic_par
+    params.load_params(path)
+    out = tmp_path / "layout.par"
+    params.save_params(out)
+    params.reset_params()
+    lines = open(out).read().split("\n")
+    assert lines[0] == "## RNAfold parameter file v2.0"
+    heads = [(i, l[2:].strip()) for i, l in enumerate(lines) if l.startswith("# ")]
+    names = [n for _, n in heads]
+    arrays = ["stack", "mismatch_hairpin", "mismatch_interior", "mismatch_interior_1n", "mismatch_interior_23", "mismatch_multi",
+              "mismatch_exterior", "dangle5", "dangle3", "int11", "int21", "int22", "hairpin", "bulge", "interior"]
+    want = [x for a in arrays for x in (a, a + "_enthalpies")] + ["NINIO", "ML_params", "Misc", "Hexaloops", "Tetraloops", "Triloops", "END"]
+    assert names == want
+    # rows of every array section: (rows, values per row) with comments stripped
+    strip = lambda l: __import__("re").sub(r"/\*.*?\*/", " ", l).split()
+    rows_of = {}
+    for (i, n), (j, _) in zip(heads, heads[1:]):
+        body = [strip(l) for l in lines[i + 1:j]]
+        rows_of[n] = [r for r in body if r]
+    shape_rows = {"stack": (7, 7), "mismatch_hairpin": (35, 5), "mismatch_interior": (35, 5), "mismatch_interior_1n": (35, 5),
+                  "mismatch_interior_23": (35, 5), "mismatch_multi": (35, 5), "mismatch_exterior": (35, 5), "dangle5": (7, 5), "dangle3": (7, 5),
+                  "int11": (7 * 7 * 5, 5), "int21": (7 * 7 * 5 * 5, 5), "int22": (6 * 6 * 4 * 4 * 4, 4)}
+    for n, (nr, nc) in shape_rows.items():
+        for sfx in ("", "_enthalpies"):
+            assert len(rows_of[n + sfx]) == nr and all(len(r) == nc for r in rows_of[n + sfx]), (n + sfx, len(rows_of[n + sfx]))
+    for n in ("hairpin", "bulge", "interior"):
+        for sfx in ("", "_enthalpies"):
+            toks = [t for r in rows_of[n + sfx] for t in r]
+            assert len(toks) == 31 and toks[0] == "INF"                  # size 0 cannot occur: ViennaRNA writes INF there
+    assert [len(r) for r in rows_of["NINIO"]] == [3] and [len(r) for r in rows_of["ML_params"]] == [6] and [len(r) for r in rows_of["Misc"]] == [6]
+    for n, ln in (("Hexaloops", 8), ("Tetraloops", 6), ("Triloops", 5)):
+        assert rows_of[n] and all(len(r) == 3 and len(r[0]) == ln and set(r[0]) <= set("ACGU") for r in rows_of[n])
+    # every token is an integer, INF or (Misc: lxc) a decimal; nothing but /* */ comments between sections
+    for n, rows in rows_of.items():
+        for r in rows:
+            for t in (r[1:] if n in ("Hexaloops", "Tetraloops", "Triloops") else r):
+                assert t == "INF" or __import__("re").fullmatch(r"-?\d+(\.\d+)?", t), (n, t)
+    # non-standard rows / columns (pair NN = last pair row, base N = first base column): present, and what the independent reader reads back
+    again = PR.read_par(out)
+    for k, v in par.items():
+        if isinstance(v, np.ndarray):
+            assert np.array_equal(again[k], v), k
+    assert again["stack"].shape == (7, 7) and again["mismatch_multi"].shape == (7, 5, 5) and again["int11"].shape == (7, 7, 5, 5)
+
+
+def test_malformed_blocks_are_rejected_with_their_line(synthetic_par):
+    path, par = synthetic_par
+    lines = open(path).read().split("\n")
+    i = lines.index("# int11")
+    first_row = next(k for k in range(i + 1, len(lines)) if lines[k].strip() and not lines[k].strip().startswith("/*"))
+
+    def load(ls, tag):
+        with pytest.raises(_native.RafftError) as ei:
+            params.load_params_text("\n".join(ls), tag)
+        return str(ei.value)
+    bad = list(lines); bad[first_row] = bad[first_row].replace(bad[first_row].split()[0], "x1y", 1)
+    assert f"line {first_row + 1}: bad token 'x1y'" in load(bad, "badtoken")
+    bad = list(lines); del bad[first_row + 2]
+    msg = load(bad, "shortrow")
+    assert "section '# int11' (line %d)" % (i + 1) in msg and "1220 values, expected 1225" in msg and "block ends on line" in msg
+    bad = list(lines); bad.insert(first_row + 1, "  1 2 3")
+    msg = load(bad, "surplus")
+    assert "1228 values, expected 1225" in msg and "first surplus value on line" in msg
+    last = max(k for k, l in enumerate(lines) if "*/" in l)
+    bad = lines[:last + 2] + ["/* never closed"] + [l for l in lines[last + 2:] if "*/" not in l]
+    assert f"line {last + 3}: unterminated comment" in load(bad, "comment")
+    assert params.params_info()["source"].startswith("built-in")         # failed loads changed nothing
