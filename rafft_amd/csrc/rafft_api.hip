@@ -608,6 +608,10 @@ int Wave::setup()
         d.big_keyv = (double *)g.big.p;
     }
     d.cls1_P = cls1_P(); d.cls1_br = cls1_br();
+    // wide classes: regions of up to 1024 positions are correlated by the exact direct form on multi-word bit masks, longer ones
+    // by the LDS FFT (measured on the configs[3] shard: n <= 1024 direct 219.7 ms against 222.8 with the FFT everywhere, 236.4
+    // with the direct form up to 4096 - scipy itself switches at 2381, rafft/utils.py:121).  RAFFT_DIRECT_N moves the limit.
+    d.direct_n = getenv("RAFFT_DIRECT_N") ? atoi(getenv("RAFFT_DIRECT_N")) : 1024;
     // small-region classes (expand_small_kernel): packed positions (no sequence beyond 4096 nt), the bit-mask form of
     // window_slide (non-negative weights, no forced FFT).  RAFFT_SMALL="n4,n5" moves the limits ("0,0": off).
     d.sm_n4 = 16; d.sm_n5 = 32;

@@ -345,7 +345,12 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
         const bool direct = (NT == 64) && n <= 64 && !d.force_fft;
         float2 *z1 = (float2 *)(lds + lay.offA);
         float2 *z2 = z1 + P;
-        if (!direct && LONGSEQ != 2)
+        // The wide classes correlate regions of up to Dev::direct_n positions by the exact direct form on multi-word bit masks -
+        // what the class for regions beyond 4096 positions always does - and longer ones by the FFT (rafft/utils.py:115-122:
+        // scipy's convolve makes the same kind of choice); same integer pair counts either way.
+        const bool mw = NT > 64 && LONGSEQ != 2 && n <= d.direct_n && P >= 128 && d.dbg.lag == nullptr && !d.force_fft &&
+                        d.gc >= 0.0 && d.au >= 0.0 && d.gu >= 0.0;
+        if (!direct && !mw && LONGSEQ != 2)
         for (int rep_ = 0; rep_ < 1 + (d.rep & 1); rep_++) {   // d.rep: profiling-only phase doubling
             for (int t = tid; t < P; t += NT) {
                 int c = t < n ? code[t] : 0;
@@ -466,10 +471,10 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
         const bool inplace = (ranked && !selected) || (dbgrank && !selected);    // keys sorted in place, rk[] in rank order
         double *keyv = LONGSEQ == 2 ? d.big_keyv + (size_t)gteam * d.big_stride : (double *)(lds + lay.offA);
         uint16_t *lagk = LONGSEQ == 2 ? (uint16_t *)(keyv + P) : (uint16_t *)(lds + lay.offA + 8 * P);
-        if (LONGSEQ == 2) {
+        if (LONGSEQ == 2 || mw) {
             // base masks of the region (the same arrays window_slide uses below, built once here) ...
             const int W = (n + 63) >> 6;
-            unsigned long long *F = (unsigned long long *)(lds + lay.offA);
+            unsigned long long *F = (unsigned long long *)(lds + lay.offA + 8 * Pk);
             unsigned long long *R = F + 5 * W;
             build_masks<NT>(F, R, W, n, code, pos, tid);
             __syncthreads();
@@ -675,7 +680,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
             unsigned long long *F = (unsigned long long *)(lds + lay.offA + (inplace ? 0 : 8 * Pk));
             unsigned long long *R = F + 5 * W;
             parts = (WsPart *)(R + 5 * W);
-            if (LONGSEQ != 2)          // (the direct correlation of the biggest regions has built them already)
+            if (LONGSEQ != 2 && !mw)   // (the direct correlation on multi-word masks has built them already)
             for (int rep_ = 0; rep_ < 1 + ((d.rep >> 7) & 1); rep_++) {
                 build_masks<NT>(F, R, W, n, code, pos, tid);
                 ESYNC();

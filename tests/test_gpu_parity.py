@@ -171,6 +171,17 @@ def test_gpu_fft_and_direct_correlation_agree(monkeypatch, node_records):
     monkeypatch.delenv("RAFFT_FORCE_FFT")
     for (f1, t1), (f2, t2) in zip(a, b):
         assert as_lists(t1) == as_lists(t2)
+    # the wide classes: FFT everywhere (limit 0), the default split at 1024 positions, the direct form everywhere (regions of
+    # up to 1500 positions here); the one-wavefront class keeps its own popcount / FFT split
+    longer = ["".join(rng.choice(list("ACGU"), int(n))) for n in (150, 400, 700, 1100, 1500)]
+    runs = {}
+    for lim in ("0", "1024", "4096"):
+        monkeypatch.setenv("RAFFT_DIRECT_N", lim)
+        runs[lim] = [as_lists(t) for _, t in rafft_amd.fold_batch(longer, 100, 6, 1000, traj=True)]
+    monkeypatch.delenv("RAFFT_DIRECT_N")
+    assert runs["0"] == runs["1024"] == runs["4096"]
+    _, o = oracle.fold(longer[2], 100, 6, 1000, traj=True)
+    assert runs["1024"][2] == as_lists(o)
 
 
 def test_gpu_small_region_kernel_is_interchangeable(monkeypatch, node_records):

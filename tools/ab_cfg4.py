@@ -1,6 +1,6 @@
 """A/B on one GPU's LPT shard of BASELINE configs[3] (2048 sequences, L 100..3000, ms=200): library ms per call."""
 import os, sys, time, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')))
 from rafft_amd import _native as N
 if os.environ.get('AB_LIB'):
     N.LIB_PATH = os.path.abspath(os.environ['AB_LIB'])
