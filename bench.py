@@ -249,6 +249,21 @@ def main():
 
     extras = {}
     if not args.no_extras:
+        # steady state (outside `value`): at least two seconds of the same sharded steps, so that a short timed region - whose
+        # start-up and drain are a visible part at N >= 4, where every rank folds one or two merged waves - has a figure beside it
+        # that is neither
+        barrier()
+        t1 = time.perf_counter()
+        n_ss = 0
+        while True:
+            mine.run(2 * DEPTH_RUN, depth=DEPTH_RUN)
+            n_ss += 2 * DEPTH_RUN
+            flag = allmax(1.0 if time.perf_counter() - t1 < 2.0 else 0.0)
+            if flag == 0.0:
+                break
+        barrier()
+        extras["steady_state_value"] = round(n * n_ss / allmax(time.perf_counter() - t1), 2)
+        extras["steady_state_steps"] = n_ss
         # latency of one synchronous call (no second batch in flight)
         mine.run(2, depth=1)
         barrier()
@@ -350,8 +365,8 @@ def main():
     if rank == 0:
         # HBM traffic and SQ counters of the dominant kernel come from rocprofv3 PMC passes (separate runs,
         # gfx950 correction applied by tools/pmc_traffic.py); counters cannot be read in-process.
-        traffic, traffic_src, issue, traffic_batch = None, None, None, None
-        for name in ("r02_traffic.json", "r01_traffic.json"):
+        traffic, traffic_src, issue, traffic_batch, tj = None, None, None, None, None
+        for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
@@ -370,6 +385,31 @@ def main():
         dur_s = agg.get("ms_expand", 0.0) / 1e3 / launches
         bytes_per_launch = agg.get("alg_bytes_expand", 0) / launches
         achieved = bytes_per_launch / dur_s / 1e9 if dur_s > 0 else 0.0
+        # every kernel family of the step beside the dominant one: algorithmic bytes and its time in the untimed
+        # pass that brackets every stage with HIP events; counter bytes and issue fraction from the tracked PMC summary
+        kernels = None
+        if stage_ms and full.agg:
+            fa = full.agg
+
+            def pmc(prefix):
+                if not tj:
+                    return None, None
+                kk = next((v for kn, v in tj["kernels"].items() if kn.replace("void ", "").startswith(prefix)), None)
+                ii = next((v for kn, v in tj.get("issue", {}).items() if kn.replace("void ", "").startswith(prefix)), None)
+                return (kk or {}).get("hbm_bytes_per_batch"), (ii or {}).get("issue_frac")
+            rows = [("expand_kernel<64,true,12>", "expand_kernel<64", fa.get("alg_bytes_expand", 0), fa.get("ms_expand", 0.0)),
+                    ("expand_small_kernel<16|32>", "expand_small_kernel", fa.get("alg_bytes_expand_small", 0), fa.get("ms_expand_c1", 0.0)),
+                    ("expand_kernel<256>", "expand_kernel<256", fa.get("alg_bytes_expand_c2", 0), fa.get("ms_expand_c2", 0.0)),
+                    ("expand_kernel<512>", "expand_kernel<512", fa.get("alg_bytes_expand_c3", 0), fa.get("ms_expand_c3", 0.0)),
+                    ("beam_step_kernel + materialize_kernel + dedupe_kernel (2L+8 per new structure)", "beam_step_kernel<256", fa.get("alg_bytes_beam", 0),
+                     fa.get("ms_beam", 0.0) + fa.get("ms_materialize", 0.0))]
+            kernels = []
+            for label, prefix, ab, ms in rows:
+                cb, fr = pmc(prefix)
+                kernels.append({"kernel": label, "alg_bytes_per_step": int(ab), "ms_per_step_untimed_pass": round(ms, 3),
+                                "achieved_gbs": round(ab / ms / 1e6, 2) if ms > 0 else None,
+                                "frac": round(ab / ms / 1e6 / HBM_PEAK_GBS, 6) if ms > 0 else None,
+                                "counter_bytes_per_batch": cb, "issue_frac": fr})
         out = {
             "metric": "sequences/sec (whole node) on benchmark set, beam N=100; kcal/mol MAE vs CPU",
             "value": round(n * args.steps / el, 2),
@@ -391,7 +431,9 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          "alg_bytes_per_launch": round(bytes_per_launch, 1),
                          "mean_launch_ms": round(dur_s * 1e3, 4), "launches_per_step": launches / args.steps,
-                         "issue_roofline": issue},
+                         "issue_roofline": issue,
+                         "traffic_age": (tj or {}).get("commit"),
+                         "kernels": kernels},
             "kernel_ms_per_step": {"ms_expand": round(agg.get("ms_expand", 0.0) / args.steps, 3),
                                    "batch_latency_ms_mean": round(agg.get("ms_total", 0.0) / args.steps, 3)},
             "stage_ms_untimed_pass": stage_ms,

@@ -80,7 +80,7 @@ typedef struct {
     double ms_total;          /* wall time of the call, host side */
     double ms_expand;         /* sum of expand_kernel<64,false> durations (regions with FFT size P <= 512;
                                  the dominant kernel; HIP events on its own stream) */
-    double ms_expand_c1;      /* experimental tiny-region class (receives no work) */
+    double ms_expand_c1;      /* expand_small_kernel<16|32>: regions of up to 32 positions whose every lag is searched, teams of 16 / 32 lanes */
     double ms_expand_c2;      /* expand_kernel<256,false> (512 < P <= 2048), runs concurrently */
     double ms_expand_c3;      /* expand_kernel<512,false> (P > 2048), runs concurrently */
     double ms_expand_wall;    /* fork->join wall time of the concurrent expand launches of every step */
@@ -102,6 +102,10 @@ typedef struct {
     int64_t alg_bytes_expand; /* the part of the dominant kernel expand_kernel<64> (its regions; 3L per structure pro rata) */
     int64_t alg_bytes_expand_all; /* all three expand size classes */
     int64_t n_regrows;        /* times a wave of the call overflowed its HBM arenas and was re-run with larger ones */
+    int64_t alg_bytes_expand_small; /* algorithmic bytes of the small-region classes (expand_small_kernel; ms_expand_c1 is their time) */
+    int64_t alg_bytes_expand_c2;    /* ... of expand_kernel<256> (ms_expand_c2) */
+    int64_t alg_bytes_expand_c3;    /* ... of expand_kernel<512> (ms_expand_c3) */
+    int64_t alg_bytes_beam;         /* 2L + 8 per new structure: beam_step_kernel + materialize_kernel (ms_beam + ms_materialize) */
 } rafft_stats;
 
 /* Select the GPU (HIP ordinal) and upload the energy tables.  Optional: every other

@@ -922,6 +922,14 @@ int Wave::finish()
         double share = hc.n_expand ? (double)hc.cls_items[1] / (double)hc.n_expand : 0.0;
         bt.stats.alg_bytes_expand += 3 * (int64_t)hc.cls_sum_n[1] + 16 * (int64_t)hc.cls_sum_lags[1] +
                                     (int64_t)(share * 3.0 * (double)(hc.sum_struct_len + sumL));
+        for (int c = 0; c < NCLS; c++) {       // the same figure per size class (2, 3 + regions beyond 4096 positions, small-region classes)
+            const double sh = hc.n_expand ? (double)hc.cls_items[c] / (double)hc.n_expand : 0.0;
+            const int64_t v = 3 * (int64_t)hc.cls_sum_n[c] + 16 * (int64_t)hc.cls_sum_lags[c] + (int64_t)(sh * 3.0 * (double)(hc.sum_struct_len + sumL));
+            if (c == 2) bt.stats.alg_bytes_expand_c2 += v;
+            else if (c == 3 || c == 0) bt.stats.alg_bytes_expand_c3 += v;
+            else if (c >= NGEN) bt.stats.alg_bytes_expand_small += v;
+        }
+        bt.stats.alg_bytes_beam += 2 * (int64_t)hc.sum_struct_len + 8 * (int64_t)(hc.n_struct - S);
         bt.stats.alg_bytes_expand_all += ex;
         bt.stats.alg_bytes += ex + 2 * (int64_t)hc.sum_struct_len + 8 * (int64_t)(hc.n_struct - S);
     }

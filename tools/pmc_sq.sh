@@ -24,6 +24,6 @@ for k in sorted(dur, key=lambda k: -dur[k])[:10]:
     wi = v["SQ_INSTS_VALU"] + v["SQ_INSTS_SALU"] + v["SQ_INSTS_LDS"] + v.get("SQ_INSTS_VMEM_RD", 0) + v.get("SQ_INSTS_VMEM_WR", 0) + v.get("SQ_INSTS_SMEM", 0)
     print(f"{k:36s} {dur[k]/1e6:7.2f} ms {n[k]:4d} launches | Minst: valu {v['SQ_INSTS_VALU']/1e6:7.1f} salu {v['SQ_INSTS_SALU']/1e6:7.1f} lds {v['SQ_INSTS_LDS']/1e6:6.1f} vmem {(v.get('SQ_INSTS_VMEM_RD',0)+v.get('SQ_INSTS_VMEM_WR',0))/1e6:6.1f} smem {v.get('SQ_INSTS_SMEM',0)/1e6:6.1f} branch {v.get('SQ_INSTS_BRANCH',0)/1e6:6.1f}"
           f" | waves {v['SQ_WAVES']/1e3:7.1f}k | wave cycles: active {v['SQ_ACTIVE_INST_ANY']/v['SQ_WAVE_CYCLES']:.2f} parked {v['SQ_WAIT_ANY']/v['SQ_WAVE_CYCLES']:.2f} stalled {v['SQ_WAIT_INST_ANY']/v['SQ_WAVE_CYCLES']:.2f}"
-          f" | lanes/VALU {v.get('SQ_THREAD_CYCLES_VALU',0)/max(v['SQ_INSTS_VALU'],1)/4:.1f} | issue {wi/(1024*2.4e9*dur[k]*1e-9):.3f} | resident waves/SIMD {4*v['SQ_WAVE_CYCLES']/(1024*2.4e9*dur[k]*1e-9):.2f} | LDS conflict cyc {v.get('SQ_LDS_BANK_CONFLICT',0)/1e6:.1f}M")
+          f" | lanes/VALU {v.get('SQ_THREAD_CYCLES_VALU',0)/max(v['SQ_INSTS_VALU'],1):.1f} | issue {wi/(1024*2.4e9*dur[k]*1e-9):.3f} | resident waves/SIMD {4*v['SQ_WAVE_CYCLES']/(1024*2.4e9*dur[k]*1e-9):.2f} | LDS conflict cyc {v.get('SQ_LDS_BANK_CONFLICT',0)/1e6:.1f}M")
 PY
 tail -2 $OUT/err.log | cut -c1-200

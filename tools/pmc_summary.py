@@ -7,7 +7,10 @@ time) - the fraction of SIMD issue slots (one wave-instruction per SIMD per cycl
 VALU-only figure priced at 2 cycles per wave64 VALU instruction on the SIMD-32 (MI355X_MICROARCH.md), and the shares
 of wave cycles spent active / parked (s_waitcnt) / issue-stalled.
 
-usage: python tools/pmc_summary.py gpurun_out/r02_prof profiles r02"""
+Lanes per vector instruction (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU / 4: thread-cycles tick per quad-cycle of a wave64 instruction) and
+LDS bank-conflict cycles come from a fifth pass when present.
+
+usage: python tools/pmc_summary.py gpurun_out/r03_prof profiles r03 [commit]"""
 import collections, csv, json, os, shutil, sys
 
 N_CU, SIMD_PER_CU = 256, 4
@@ -30,7 +33,7 @@ def counters(dirname):
     return tot, {k: len(v) for k, v in disp.items()}, dur
 
 
-def main(src, dst, tag):
+def main(src, dst, tag, *rest):
     shutil.copy(os.path.join(src, "trace", "t_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
     bench = json.load(open(os.path.join(src, "trace_bench.json")))
     json.dump(bench, open(os.path.join(dst, f"{tag}_trace_bench.json"), "w"), indent=1)
@@ -40,6 +43,14 @@ def main(src, dst, tag):
     sq2, ns2, dur2 = ({}, {}, {})
     if os.path.exists(os.path.join(src, "pmc_sq2", "p_counter_collection.csv")):
         sq2, ns2, dur2 = counters(os.path.join(src, "pmc_sq2"))
+    lanes = {}
+    if os.path.exists(os.path.join(src, "pmc_lanes", "p_counter_collection.csv")):
+        ln, _, _ = counters(os.path.join(src, "pmc_lanes"))
+        for k, c in ln.items():
+            if c.get("SQ_INSTS_VALU"):
+                lanes[k] = {"lanes_per_valu_instruction": round(c.get("SQ_THREAD_CYCLES_VALU", 0) / c["SQ_INSTS_VALU"], 2),
+                            "lds_bank_conflict_cycles": int(c.get("SQ_LDS_BANK_CONFLICT", 0)), "lds_idx_active_cycles": int(c.get("SQ_LDS_IDX_ACTIVE", 0)),
+                            "lds_instructions": int(c.get("SQ_INSTS_LDS", 0))}
     clk_mhz = None
     for r in csv.DictReader(open(os.path.join(src, "trace", "t_agent_info.csv"))):
         if r.get("Agent_Type", "").upper() == "GPU" or r.get("Name", "").startswith("gfx"):
@@ -77,10 +88,11 @@ def main(src, dst, tag):
                     # SQ_WAVE_CYCLES (like SQ_BUSY_CYCLES and the SQ_WAIT_* counters) ticks once per 4 cycles
                     "mean_waves_resident_per_simd": round(4.0 * c["SQ_WAVE_CYCLES"] / slots, 3)}
     ex = next((k for k in issue if k.startswith("void expand_kernel<64")), None)
-    out = {"source": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_* | SQ_* second set), each in its own run, "
-                     "bench.py --steps 3 --warmup 1 --no-extras with synchronous calls (BENCH_DEPTH=1); tools/profile_r02.sh",
+    out = {"source": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_* | SQ_* second set | lanes + LDS conflicts), each in its own run, "
+                     "bench.py --steps 3 --warmup 1 --no-extras with synchronous calls (BENCH_DEPTH=1, BENCH_PREWARM_S=0); tools/profile_%s.sh" % tag,
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE halving, MI355X_MICROARCH.md)",
-           "clock_hz_used": clk, "kernels": kernels, "issue": issue,
+           "commit": sys.argv[4] if len(sys.argv) > 4 else None,
+           "clock_hz_used": clk, "kernels": kernels, "issue": issue, "lanes_and_lds": lanes,
            "issue_roofline": dict(kernel=ex, **{k: issue[ex][k] for k in ("issue_frac", "valu_busy_frac_at_2_cycles_per_wave64_op", "pipe_busy_frac_measured",
                                                                              "wave_cycle_shares", "mean_waves_resident_per_simd")}) if ex else None}
     json.dump(out, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
