@@ -487,7 +487,7 @@ struct Wave {
     size_t S = 0, sumL = 0, B = 0, bs_lds[2] = {0, 0}, mat_lds = RAFFT_MAX_LEN;
     double reserve = 1.0;         // buffers are allocated for a wave this many times bigger (merged batches to come)
     bool longseq = false;         // a sequence longer than LDS_SEQ: its loops' bases are read from HBM, regions beyond 4096 positions exist
-    unsigned dedupe_per_cu = 1;
+    unsigned dedupe_per_cu = 1024 / DEDUPE_NT;
     std::vector<int> off, len;
     ClsCfg cf[NGEN];
     Caps c;
