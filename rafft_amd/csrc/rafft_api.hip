@@ -263,8 +263,8 @@ int class_cfg(int K, int maxL, ClsCfg out[NGEN])
         // a size class that no region of this batch can reach need not fit (class 3 needs n > 1024, class 0 n > 4096)
         const bool reachable = c == 0 ? longseq : (c < 3 || maxL > CLS2_P / 2);
         if (l.total > 160 * 1024 && reachable)
-            return fail(RAFFT_ERR_PARAM, "nb_mode too large for the LDS-resident expand kernel: with sequences longer than "
-                                         "1024 nt nb_mode must stay below ~400, otherwise below 2048");
+            return fail(RAFFT_ERR_PARAM, "nb_mode too large for the LDS-resident expand kernel: it must stay below 2048 (below ~400 when a "
+                                         "sequence is longer than 4096 nt)");
         if (l.total > 160 * 1024) out[c].lds = 160 * 1024, out[c].Kmax = 1;    // never launched with work
     }
     return 0;
@@ -601,7 +601,7 @@ int Wave::setup()
     d.rl_cap = RL_CAP;
     longseq = maxL > LDS_SEQ;
     d.pos_packed = longseq ? 0 : 1;          // 12 bits of position leave room for the base code (Dev::pos_packed)
-    d.max_prod = longseq ? MAX_PROD_LONG : MAX_PROD;
+    d.max_prod = maxL > 2048 ? MAX_PROD_LONG : MAX_PROD;     // (a productive region needs a handful of unpaired positions: 256 of them do not fit 2048 nt)
     if (longseq) {       // scratch of the class for regions beyond 4096 positions: lag values (fp64) + lag column, per workgroup
         d.big_stride = (size_t)2 * BIG_N + (size_t)2 * BIG_N / 4;
         if (int rc = ensure(g.big, (size_t)cf[0].grid * d.big_stride * 8)) return rc;

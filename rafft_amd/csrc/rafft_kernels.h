@@ -220,12 +220,21 @@ __host__ __device__ inline ExpandLds expand_lds(int Pmax, int Lmax, int nmax, in
     l.off_code = o; o += al(nmax);
     l.off_S = o; o += al(Lmax + 8);
     l.off_br = o; o += al(4 * brmax);
-    l.off_rk = o; o += al(2 * next_pow2_ge(Kmax));
-    l.off_nb = o; o += al(2 * Kmax);
-    l.off_mi = o; o += al(2 * Kmax);
-    l.off_mj = o; o += al(2 * Kmax);
-    l.off_dd = o; o += al(4 * Kmax);
-    l.off_keep = o; o += al(2 * Kmax);
+    // per-lag arrays (ranked lags, window_slide results, dE, kept list): 14 bytes per searched lag.  In the class with the
+    // 128-KiB FFT buffers (P = 8192) a big nb_mode does not fit beside them - but they are only written once the FFTs are
+    // done, and then the second half of region A is free except for its first 24 KiB (bit masks 5 KiB at 8 P, branch prefix
+    // sums 10 KiB at 8 P, select histogram 1.2 KiB at 10 P; chunked window_slide partials only exist for nb_mode <= 256):
+    // they go there, and nb_mode up to 2047 works for sequences of any length up to 4096 nt.
+    const int lag_bytes = al(2 * next_pow2_ge(Kmax)) + 4 * al(2 * Kmax) + al(4 * Kmax);
+    const bool lag_in_A = Pmax == MAX_P && Kmax > 256 && 8 * Pmax + 24 * 1024 + lag_bytes <= l.szA;
+    int oa = lag_in_A ? 8 * Pmax + 24 * 1024 : 0;
+    int &q = lag_in_A ? oa : o;
+    l.off_rk = q; q += al(2 * next_pow2_ge(Kmax));
+    l.off_nb = q; q += al(2 * Kmax);
+    l.off_mi = q; q += al(2 * Kmax);
+    l.off_mj = q; q += al(2 * Kmax);
+    l.off_dd = q; q += al(4 * Kmax);
+    l.off_keep = q; q += al(2 * Kmax);
     l.off_w = o; o += al(25 * 8);
     l.off_misc = o; o += 128;
     l.per_team = o;

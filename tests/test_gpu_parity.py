@@ -266,3 +266,16 @@ def test_gpu_degenerate_parameters_vs_oracle(nb_mode, mb):
     for s, (fin, traj) in zip(seqs, got):
         _, o = oracle.fold(s, nb_mode, 5, mb, traj=True)
         assert as_lists(traj) == as_lists(o), (len(s), nb_mode, mb)
+
+
+def test_gpu_large_nb_mode_on_long_sequences_vs_oracle():
+    """nb_mode far beyond the default on sequences that reach the class with the 128-KiB FFT buffers (regions of more than
+    1024 positions): the per-lag arrays then live in the free half of the FFT area instead of making the call an error
+    (the reference takes any nb_mode, rafft/rafft.py:219-221)"""
+    rng = np.random.default_rng(1500)
+    seqs = ["".join(rng.choice(list("ACGU"), n)) for n in (1500, 2600, 300)]
+    for nb_mode, ms in ((1000, 2), (2047, 1), (450, 3)):
+        got = rafft_amd.fold_batch(seqs, nb_mode, ms, 1000, traj=True)
+        for s, (fin, traj) in zip(seqs, got):
+            _, o = oracle.fold(s, nb_mode, ms, 1000, traj=True)
+            assert as_lists(traj) == as_lists(o), (len(s), nb_mode, ms)
