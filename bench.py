@@ -425,7 +425,10 @@ def main():
                        "nb_mode": args.nb_mode, "max_stack": args.max_stack, "max_branch": args.max_branch,
                        "sequences_per_step": n, "sequences_on_rank0": mine.n,
                        "parallelism": (f"LPT sequence shards x{world}, no collective" if world > 1 else "1 GPU"),
-                       "batches_in_flight": DEPTH_RUN},
+                       "batches_in_flight": DEPTH_RUN,
+                       "scheduler": "queued batches with equal parameters are folded as ONE wave of up to "
+                                    + os.environ.get("RAFFT_MERGE_SEQS", "9600") + " sequences (4 steps of this workload), two waves at a time; "
+                                    "ms_per_call_sequential is one synchronous call"},
             "roofline": {"bound": "hbm", "kernel": "expand_kernel<64,true,12> (regions with FFT size <= 512; 12 wavefronts per workgroup)", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": traffic, "traffic_source": traffic_src,

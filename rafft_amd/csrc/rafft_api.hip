@@ -723,6 +723,8 @@ int Wave::issue_step()
         // persistent workgroups loop over the work list, so any grid is correct: when few structures were
         // materialized (the tail of a batch) a small grid avoids dispatching thousands of empty workgroups
         unsigned grid = cls >= NGEN ? (unsigned)::g.n_cu * small_wg_per_cu : (unsigned)cf[cls].grid;
+        static const unsigned c1_wgs = getenv("RAFFT_C1_WGS") ? (unsigned)atoi(getenv("RAFFT_C1_WGS")) : 0u;     // A/B: fewer workgroups of the one-wavefront class
+        if (cls == 1 && c1_wgs && cf[1].wpb > 1) grid = std::min(grid, c1_wgs * (unsigned)cf[1].wpb);
         if (steps > 0) {
             const unsigned long long bound = (unsigned long long)last_mat * (cls == 1 ? 8ULL : 4ULL) + 32ULL;
             if (bound < grid) grid = (unsigned)bound;

@@ -2,7 +2,7 @@
 trajectories against the CPU oracle.  Both expand routings (RAFFT_MERGE_*)."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")))
 import oracle, rafft_amd
 
 def as_lists(traj):

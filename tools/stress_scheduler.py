@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0,'.')
+import os; sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')))
 import rafft_amd, oracle
 rng=np.random.default_rng(5)
 def rnd(n): return "".join(rng.choice(list("ACGU"),int(n)))
