@@ -608,6 +608,8 @@ int Wave::setup()
         d.big_keyv = (double *)g.big.p;
     }
     d.cls1_P = cls1_P(); d.cls1_br = cls1_br();
+    d.fetch_bulk = getenv("RAFFT_FETCH") ? std::max(1, atoi(getenv("RAFFT_FETCH"))) : 4;
+    d.taper_pct = getenv("RAFFT_TAPER") ? std::max(0, std::min(100, atoi(getenv("RAFFT_TAPER")))) : 25;
     // wide classes: regions of up to 1024 positions are correlated by the exact direct form on multi-word bit masks, longer ones
     // by the LDS FFT (measured on the configs[3] shard: n <= 1024 direct 219.7 ms against 222.8 with the FFT everywhere, 236.4
     // with the direct form up to 4096 - scipy itself switches at 2381, rafft/utils.py:121).  RAFFT_DIRECT_N moves the limit.

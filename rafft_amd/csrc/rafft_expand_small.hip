@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
     if (gw == 0 && lane == 0) d.c->n_mat = 0;                // the beam step that follows counts its new structures here
     const int shard = gw & (NSHARD - 1);
     unsigned long long st_items = 0, st_n = 0, st_lags = 0, st_nbr = 0;      // statistics (lane 0 of every team)
-    const unsigned FETCH = n_items > 4u * TPW * n_waves ? 4u : 1u;            // groups of TPW regions claimed per atomic
+    const unsigned FETCH = n_items > 4u * TPW * n_waves ? (unsigned)d.fetch_bulk : 1u;            // groups of TPW regions claimed per atomic
     unsigned fetch_base = 0, fetch_left = 0;                                  // uniform across the wavefront
     int fshard = (int)(gw & (NSHARD - 1));
     unsigned long long ffailed = 0;
@@ -96,9 +96,10 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
     for (;;) {
         wave_sync();                                   // the previous regions' LDS use is over
         if (fetch_left == 0) {
-            fetch_base = fetch_chunk(d, cls, n_items, FETCH * TPW, fshard, ffailed);
+            unsigned fcount = TPW;
+            fetch_base = fetch_chunk(d, cls, n_items, FETCH * TPW, TPW, fshard, ffailed, fcount);
             if (fetch_base == ~0u) break;
-            fetch_left = FETCH;
+            fetch_left = fcount / TPW;
         }
         const unsigned item0 = fetch_base;
         fetch_base += TPW; fetch_left--;

@@ -114,6 +114,7 @@ struct Dev {
     int K, B, max_branch, min_hp, traj, memo, force_fft, rl_cap, mat_tile, merge_cls;
     double *big_keyv; size_t big_stride;   // lag values of regions too big for LDS: one slice of `big_stride` doubles per workgroup
     int max_prod;                // productive regions per structure that materialize_kernel's LDS lists hold
+    int fetch_bulk, taper_pct;   // work chunks: regions (rounds of the small-region kernel) per claim in the bulk of a list; percent of the list handed out that way
     int direct_n;                // wide classes: multi-word popcount correlation up to this region size, FFT beyond (RAFFT_DIRECT_N)
     int sm_n4, sm_n5;            // small-region classes: regions of up to sm_n4 positions go to class 4 (teams of 16 lanes), up to
                                  // sm_n5 to class 5 (teams of 32); 0 = class unused (see node_class)

@@ -155,10 +155,14 @@ __device__ inline void build_masks(unsigned long long *F, unsigned long long *R,
 // atomic on the wavefront's own shard (64 cursors, 64 bytes apart: 0.56 ns per atomic chip-wide against 11.4 ns on a
 // single cursor, tools/micro/atomic_spacing.hip).  Whoever claims the last chunk of a shard sets its bit in wdone[cls];
 // a wavefront that finds its shard empty reads that ONE word and moves to a shard that still has chunks.
-__device__ inline unsigned fetch_chunk(const Dev &d, int cls, unsigned n_items, unsigned CH, int &shard, unsigned long long &failed)
+// Chunks taper: the first Dev::taper_pct percent of a list go out CH items at a time, the rest CT at a time (`count` says which) -
+// the wavefronts that finish a launch are then a fraction of a big chunk apart, not a whole one.
+__device__ inline unsigned fetch_chunk(const Dev &d, int cls, unsigned n_items, unsigned CH, unsigned CT, int &shard, unsigned long long &failed, unsigned &count)
 {
     const int lane = threadIdx.x & 63;
-    const unsigned chunks_total = (n_items + CH - 1) / CH;
+    const unsigned cA = CH > CT ? (unsigned)(((unsigned long long)n_items * (unsigned long long)d.taper_pct / 100ULL) / CH) : n_items / CH;      // big chunks
+    const unsigned nA = cA * CH;                                                                               // items in them
+    const unsigned chunks_total = cA + (n_items - nA + CT - 1) / CT;
     const unsigned long long exist = chunks_total >= NSHARD ? ~0ULL : ((1ULL << chunks_total) - 1ULL);      // shards that hold any chunk
     for (;;) {
         if ((exist >> shard) & ~(failed >> shard) & 1ULL) {
@@ -168,7 +172,10 @@ __device__ inline unsigned fetch_chunk(const Dev &d, int cls, unsigned n_items, 
             k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
             if (k < cnt) {
                 if (k == cnt - 1 && lane == 0) atomicOr(&d.c->wdone[cls], 1ULL << shard);
-                return ((unsigned)shard + NSHARD * k) * CH;
+                const unsigned c = (unsigned)shard + NSHARD * k;
+                if (c < cA) { count = CH; return c * CH; }
+                count = CT;
+                return nA + (c - cA) * CT;
             }
             failed |= 1ULL << shard;
         }
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
     const bool eprof = d.prof_e != nullptr && tid == 0;      // diagnostic phase stamps (RAFFT_TRACE=3)
     unsigned long long eacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, et = eprof ? clock64() : 0;
 #define ESTAMP(k) do { if (eprof) { const unsigned long long tn_ = clock64(); eacc[k] += tn_ - et; et = tn_; } } while (0)
-    const unsigned FETCH = (NT == 64 && n_items > 4u * n_teams) ? 4u : 1u;
+    const unsigned FETCH = (NT == 64 && n_items > 4u * n_teams) ? (unsigned)d.fetch_bulk : 1u;
     unsigned fetch_base = 0, fetch_left = 0;                 // uniform across the workgroup
     int fshard = (int)(gteam & (NSHARD - 1));                // work-cursor shard this team claims from next (fetch_chunk)
     unsigned long long ffailed = 0;
@@ -282,14 +289,15 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
         }
         unsigned long long ft0 = eprof ? clock64() : 0;
         if (fetch_left == 0) {
-            if (NT == 64) fetch_base = fetch_chunk(d, cls, n_items, FETCH, fshard, ffailed);
+            unsigned fcount = 1;
+            if (NT == 64) fetch_base = fetch_chunk(d, cls, n_items, FETCH, 1u, fshard, ffailed, fcount);
             else {
-                if (tid < 64) { const unsigned b_ = fetch_chunk(d, cls, n_items, FETCH, fshard, ffailed); if (tid == 0) misc[8] = (int)b_; }
+                if (tid < 64) { const unsigned b_ = fetch_chunk(d, cls, n_items, 1u, 1u, fshard, ffailed, fcount); if (tid == 0) misc[8] = (int)b_; }
                 ESYNC();
                 fetch_base = (unsigned)misc[8];
             }
             if (fetch_base == ~0u) break;
-            fetch_left = FETCH;
+            fetch_left = fcount;
         }
         // (the work item is the same for the whole team: saying so - readfirstlane - turns the header loads below into scalar
         //  loads, off the vector memory queue and out of the vector registers; only for the one-wavefront class, where a
