@@ -1312,8 +1312,14 @@ static void scheduler_main()
         int n_running = 0;
         bool heavy_running = false;
         for (int i = 0; i < MAX_PIPES; i++) if (slot[i].wave) { n_running++; heavy_running = heavy_running || slot[i].wave->heavy(admit_below()); }
+        // The long-tail lane has a wave slot of its own: a long-tail wave (a handful of sequences, two dozen latency-bound steps)
+        // never keeps a second bulk wave from starting (288 -> 294 k sequences/s with eight batches in flight, three interleaved
+        // pairs of runs; RAFFT_TAIL_SLOT=0: the lanes share the `max_waves` slots as in round 2)
+        static const bool tail_slot = getenv("RAFFT_TAIL_SLOT") ? atoi(getenv("RAFFT_TAIL_SLOT")) != 0 : true;
+        int n_lane[2] = {0, 0};
+        for (int i = 0; i < MAX_PIPES; i++) if (slot[i].wave) n_lane[slot[i].lane]++;
         for (int ln = 0; ln < 2; ln++) {
-            while (!queue[ln].empty() && n_running < max_waves) {
+            while (!queue[ln].empty() && (tail_slot ? (ln == 0 ? n_lane[0] < 1 : n_lane[1] < max_waves && n_running < MAX_PIPES) : n_running < max_waves)) {
                 Job &front = queue[ln].front();
                 if (!strip_failed(front)) {                       // every member already failed elsewhere: nothing to fold
                     Job j = std::move(front); queue[ln].pop_front(); release(j, 0, ""); progressed = true; continue;
@@ -1381,28 +1387,31 @@ static void scheduler_main()
                     fail_or_split(sl, rc, err, queue);
                     continue;
                 }
-                n_running++;
+                n_running++; n_lane[ln]++;
                 heavy_running = heavy_running || (job_heavy && sl.wave->heavy(admit_below()));
             }
         }
         // Nothing moved.  A step's read-back lands within tens to hundreds of microseconds, so the thread polls for a
-        // short while (a wake-up through the driver costs about as much as a step of the tail); after that it SLEEPS on
-        // the read-back event of the oldest running step (created with hipEventBlockingSync) instead of holding a core.
-        // New submissions wait for that one step at most.
+        // short while; after that it stops holding a core (below).
         const auto now = std::chrono::steady_clock::now();
         if (progressed) { last_progress = now; continue; }
         static const long spin_us = getenv("RAFFT_SCHED_SPIN_US") ? atol(getenv("RAFFT_SCHED_SPIN_US")) : 200;
         if (std::chrono::duration_cast<std::chrono::microseconds>(now - last_progress).count() < spin_us) { std::this_thread::yield(); continue; }
-        Wave *oldest = nullptr;
-        for (int i = 0; i < MAX_PIPES; i++)
-            if (slot[i].wave && (!oldest || slot[i].wave->t_issued < oldest->t_issued)) oldest = slot[i].wave.get();
-        if (oldest) { hipError_t e_ = hipEventSynchronize(oldest->g.ev_hot); (void)e_; }      // (an error shows up in ready())
-        else {
+        bool any_wave = false;
+        for (int i = 0; i < MAX_PIPES; i++) any_wave = any_wave || (bool)slot[i].wave;
+        if (any_wave) {
+            // Several waves run and ANY of them may finish its step next: sleeping on one wave's event made the others wait for it
+            // (measured: the long-tail wave's steps - 14 sequences, 0.3 ms of kernels - sat 0.5 ms on average, up to 1.6 ms, behind
+            // a bulk wave's step, and while the long-tail wave holds one of the two wave slots the bulk waves do not overlap).  So
+            // the thread naps in short slices and looks at all of them; a nap costs no core to speak of.
+            static const long nap_us = getenv("RAFFT_SCHED_NAP_US") ? atol(getenv("RAFFT_SCHED_NAP_US")) : 50;
+            std::this_thread::sleep_for(std::chrono::microseconds(nap_us));
+            continue;
+        } else {
             // nothing running yet something queued (a job waiting for HBM that running waves hold cannot happen here: no wave runs)
             std::unique_lock<std::mutex> lk(g.qmu);
             g.qcv_sched.wait_for(lk, std::chrono::milliseconds(1), [] { return !g.submitted.empty() || g.stop; });
         }
-        last_progress = std::chrono::steady_clock::now();
     }
 }
 
