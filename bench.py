@@ -13,7 +13,7 @@ N > 1: the set is LPT-sharded over the ranks (rafft_amd/sharding.py - what the r
        outside the timed region.  `weak_replica_value` (every rank folds a full replica) and `cfg4_sharded`
        (BASELINE configs[3]: 16 384 random sequences L 100..3000, ms=200, LPT-sharded) ride along as extra keys.
 
-Steps are issued through the library's asynchronous C-ABI (rafft_fold_submit / rafft_fold_wait) with up to eight batches
+Steps are issued through the library's asynchronous C-ABI (rafft_fold_submit / rafft_fold_wait) with up to ten batches
 in flight - continuous batching: queued batches with identical parameters are folded as ONE wave by the library's
 scheduler (fewer, fuller kernel launches), and the nearly empty last folding steps of step k (only the longest sequences still fold)
 run beside the busy first steps of step k+1.  Every step is waited for, and its result freed, inside the timed
@@ -37,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
-PIPELINE_DEPTH = int(os.environ.get("BENCH_DEPTH", "8"))   # batches in flight (profiling passes use 1)
+PIPELINE_DEPTH = int(os.environ.get("BENCH_DEPTH", "10"))   # batches in flight: two waves of up to five merged batches (profiling passes use 1)
 
 
 def load_bench_sequences():
@@ -233,7 +233,7 @@ def main():
     #  steps, so that the clocks have ramped whatever W is)
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < float(os.environ.get("BENCH_PREWARM_S", "0.5")):
-        mine.run(4, depth=DEPTH_RUN)
+        mine.run(DEPTH_RUN, depth=DEPTH_RUN)
     mine.run(args.warmup, depth=DEPTH_RUN)
     mine.agg = {}
     barrier()
@@ -427,7 +427,7 @@ def main():
                        "parallelism": (f"LPT sequence shards x{world}, no collective" if world > 1 else "1 GPU"),
                        "batches_in_flight": DEPTH_RUN,
                        "scheduler": "queued batches with equal parameters are folded as ONE wave of up to "
-                                    + os.environ.get("RAFFT_MERGE_SEQS", "9600") + " sequences (4 steps of this workload), two waves at a time; "
+                                    + os.environ.get("RAFFT_MERGE_SEQS", "11500") + " sequences (5 steps of this workload), two waves at a time; "
                                     "ms_per_call_sequential is one synchronous call"},
             "roofline": {"bound": "hbm", "kernel": "expand_kernel<64,true,12> (regions with FFT size <= 512; 12 wavefronts per workgroup)", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),

@@ -566,7 +566,7 @@ int Wave::setup()
     Caps cr = c;
     if (S < merge_cap() && !seam) {
         // (a long-tail job has a few sequences per batch: sized once for 64 of them, whatever gets merged later)
-        Sr = S >= 256 ? std::min(merge_cap(), 4 * S) : std::max<size_t>(S, std::min<size_t>(64, 32 * S));
+        Sr = S >= 256 ? std::min(merge_cap(), 5 * S) : std::max<size_t>(S, std::min<size_t>(64, 32 * S));
         Caps big = plan_caps(Sr, (size_t)((double)sumL * (double)Sr / (double)S), p, est);
         if (big.bytes <= (size_t)((double)::g.hbm_total * 0.06)) cr = big; else Sr = S;
     }
@@ -1091,10 +1091,12 @@ static unsigned admit_below()
     return v ? v : 128u * (unsigned)g.n_cu;     // = the step size below which the one-wavefront expand class is merged away
 }
 // sequences one merged wave may hold (a wave of the whole benchmark set four times over folds 25 % faster per sequence
-// than the set alone: fewer, fuller launches; beyond that nothing is gained and the arenas only grow)
+// than the set alone: fewer, fuller launches; five times over - with ten batches in flight, so that two such waves run side by
+// side - another 4 % in round 3: 288 k sequences/s against 277-282 k over 30 steps; beyond that the arenas of a wave pass a tenth
+// of the HBM, where waves run one at a time)
 static size_t merge_cap()
 {
-    static const size_t v = getenv("RAFFT_MERGE_SEQS") ? (size_t)atol(getenv("RAFFT_MERGE_SEQS")) : 9600;
+    static const size_t v = getenv("RAFFT_MERGE_SEQS") ? (size_t)atol(getenv("RAFFT_MERGE_SEQS")) : 11500;
     return v;
 }
 
