@@ -445,7 +445,8 @@ struct PinChunk {
 struct Batch;
 // One wave's worth of work.  `members`: the batches its sequences come from - queued jobs with identical parameters
 // are merged (continuous batching), so one wave may serve several batches; seqs[i].bi indexes this list.
-struct Job { std::vector<SeqIn> seqs; double est; int depth; std::vector<std::shared_ptr<Batch>> members; bool no_merge = false; };
+struct Job { std::vector<SeqIn> seqs; double est; int depth; std::vector<std::shared_ptr<Batch>> members; bool no_merge = false;
+             bool big_prod = false; };    // re-run after a structure had more productive regions than the short lists hold
 
 // One rafft_fold_submit(): its sequences (copied), its result under construction, its jobs (lane 0: the long tail of
 // the batch, lane 1: the bulk - see rafft_fold_submit) and what the scheduler needs to finish it.
@@ -497,6 +498,7 @@ struct Wave {
     int merged_now = 0, merge_target = 0;   // size class that receives every region of the coming expand step (0: by size)
     int steps = 0;
     int depth = 0;                // regrowths of this job so far
+    bool big_prod = false, want_big_prod = false;   // long productive-region lists (1024 per structure) for this run / asked for by it
     bool finished = false;
     long long last_rows_bytes = 0;
     std::vector<OutRec> early_recs, late_recs;
@@ -601,7 +603,11 @@ int Wave::setup()
     d.rl_cap = RL_CAP;
     longseq = maxL > LDS_SEQ;
     d.pos_packed = longseq ? 0 : 1;          // 12 bits of position leave room for the base code (Dev::pos_packed)
-    d.max_prod = maxL > 2048 ? MAX_PROD_LONG : MAX_PROD;     // (a productive region needs a handful of unpaired positions: 256 of them do not fit 2048 nt)
+    // 256 productive regions per structure (never above 64 on any BASELINE workload); the lists live in materialize_kernel's LDS,
+    // and with 1024 entries a CU holds 8 of its workgroups instead of ~24 (measured: 1.5 -> 2.3 ms per benchmark batch) - so the long
+    // lists are for sequences beyond 4096 nt and for a wave that overflowed the short ones and is being folded again
+    d.max_prod = (longseq || big_prod) ? MAX_PROD_LONG : MAX_PROD;
+    if (const char *e = getenv("RAFFT_TEST_MAX_PROD")) if (!big_prod && !longseq) d.max_prod = std::max(1, std::min(atoi(e), MAX_PROD));   // test hook: short lists overflow early
     if (longseq) {       // scratch of the class for regions beyond 4096 positions: lag values (fp64) + lag column, per workgroup
         d.big_stride = (size_t)2 * BIG_N + (size_t)2 * BIG_N / 4;
         if (int rc = ensure(g.big, (size_t)cf[0].grid * d.big_stride * 8)) return rc;
@@ -894,8 +900,12 @@ int Wave::finish()
     if (ovf) {
         HIPCHK(hipStreamSynchronize(st));
         if (harvested) HIPCHK(hipStreamSynchronize(g.copy_stream));
+        if ((ovf & OVF_PROD) && !(ovf & OVF_SORT) && d.max_prod < MAX_PROD_LONG) {
+            want_big_prod = true;          // not a limit yet: the wave is folded again with the long lists (MAX_PROD_LONG)
+            return result = RAFFT_ERR_CAPACITY;
+        }
         if (ovf & (OVF_PROD | OVF_SORT))
-            return result = fail(RAFFT_ERR_PARAM, "structure with more productive regions than the kernels hold (256; 1024 for sequences beyond 4096 nt) or sort capacity exceeded");
+            return result = fail(RAFFT_ERR_PARAM, "structure with more than 1024 productive regions, or sort capacity exceeded");
         return result = RAFFT_ERR_CAPACITY;
     }
     // statistics (SURVEY.md 8d algorithmic bytes; only expansions the kernels really executed)
@@ -1291,7 +1301,8 @@ static void scheduler_main()
                         release(sl.job, RAFFT_ERR_CAPACITY, "HBM arena overflow after 12 regrowths (bits " + std::to_string(sl.wave->ovf) + ")");
                     else {                                   // re-run with larger arenas, ahead of everything queued
                         sl.job.members[0]->stats.n_regrows++;
-                        sl.job.est *= (sl.job.depth >= 2 ? 4.0 : 2.0);
+                        if (sl.wave->want_big_prod) sl.job.big_prod = true;          // (same arenas, longer lists)
+                        else sl.job.est *= (sl.job.depth >= 2 ? 4.0 : 2.0);
                         sl.job.depth++;
                         queue[sl.lane].push_front(std::move(sl.job));
                     }
@@ -1378,6 +1389,7 @@ static void scheduler_main()
                 if (!rc) {
                     sl.wave.reset(new Wave(g.ws[w], sl.job.members, sl.job.seqs, sl.job.est));
                     sl.wave->depth = sl.job.depth;
+                    sl.wave->big_prod = sl.job.big_prod;
                     rc = sl.wave->setup();
                     if (!rc) rc = sl.wave->issue_step();
                 }

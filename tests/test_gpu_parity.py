@@ -279,3 +279,16 @@ def test_gpu_large_nb_mode_on_long_sequences_vs_oracle():
         for s, (fin, traj) in zip(seqs, got):
             _, o = oracle.fold(s, nb_mode, ms, 1000, traj=True)
             assert as_lists(traj) == as_lists(o), (len(s), nb_mode, ms)
+
+
+def test_gpu_more_productive_regions_than_the_short_lists_hold(monkeypatch):
+    """a structure with more productive regions than materialize_kernel's short LDS lists hold (256; here the hook makes it 3)
+    is no error: the wave is folded again with the long lists - same trajectories, one regrowth on record"""
+    rng = np.random.default_rng(256)
+    seqs = ["".join(rng.choice(list("ACGU"), int(n))) for n in (300, 500, 120, 800)]
+    want = [as_lists(t) for _, t in rafft_amd.fold_batch(seqs, 100, 8, 1000, traj=True)]
+    monkeypatch.setenv("RAFFT_TEST_MAX_PROD", "3")
+    got = [as_lists(t) for _, t in rafft_amd.fold_batch(seqs, 100, 8, 1000, traj=True)]
+    assert rafft_amd.last_stats()["n_regrows"] >= 1
+    monkeypatch.delenv("RAFFT_TEST_MAX_PROD")
+    assert got == want
