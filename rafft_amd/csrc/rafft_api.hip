@@ -215,7 +215,7 @@ int init_ctx(int device)
     return init_ws(g.ws[0]);
 }
 
-struct ClsCfg { int nt, Pmax, Lmax, nmax, brmax, Kmax, lds, grid; bool tab; int wpb; };   // grid: teams (wavefronts of the packed one-wavefront class, workgroups otherwise)
+struct ClsCfg { int nt, Pmax, Lmax, nmax, brmax, Kmax, lds, grid; bool tab; int wpb; bool nofft; };   // grid: teams (wavefronts of the packed one-wavefront class, workgroups otherwise)
 
 // limits of the one-wavefront class: its LDS per wavefront (hence its occupancy) follows from them
 // (not below 256: the kernel addresses the staged bases through a pointer shifted back by up to 4095 positions, which must stay
@@ -223,13 +223,18 @@ struct ClsCfg { int nt, Pmax, Lmax, nmax, brmax, Kmax, lds, grid; bool tab; int 
 static int cls1_P() { static const int v = getenv("RAFFT_CLS1_P") ? std::max(256, std::min(next_pow2_ge(atoi(getenv("RAFFT_CLS1_P"))), CLS1_P)) : CLS1_P; return v; }
 static int cls1_br() { return std::min(CLS1_BR, (8 * cls1_P() - 16) / 10 - 1); }
 
-int class_cfg(int K, int maxL, ClsCfg out[NGEN])
+// `nofft1`: the one-wavefront class correlates every region by popcounts (production mode: no seam, no forced FFT, no negative
+// weights, Dev::direct_n >= 256): its FFT buffers and twiddles go, its branch lists shrink to 128 entries, and a workgroup of twelve
+// wavefronts leaves ~32 KiB of a CU's LDS - room for a workgroup of the small-region kernel beside it.
+// `nofft2`: the same for the 256-thread class when Dev::direct_n covers all of its regions (<= 1024 positions): 46 -> 39 KiB, four
+// workgroups per CU instead of three.
+int class_cfg(int K, int maxL, ClsCfg out[NGEN], bool nofft1 = false, bool nofft2 = false)
 {
     // sequences longer than LDS_SEQ: classes 2 and 3 read the bases of a loop from HBM/L2 (no LDS copy), class 0 takes the
     // regions whose FFT would not fit
     const bool longseq = maxL > LDS_SEQ;
     const int P[NGEN] = {CLS0_P, cls1_P(), CLS2_P, MAX_P}, LM[NGEN] = {0, CLS01_L, longseq ? 0 : LDS_SEQ, longseq ? 0 : LDS_SEQ};
-    const int NT[NGEN] = {512, 64, getenv("RAFFT_NT2") ? atoi(getenv("RAFFT_NT2")) : 256, 512}, BR[NGEN] = {BIG_BR + 1, cls1_br(), MAX_BR, MAX_BR};
+    const int NT[NGEN] = {512, 64, getenv("RAFFT_NT2") ? atoi(getenv("RAFFT_NT2")) : 256, 512}, BR[NGEN] = {BIG_BR + 1, nofft1 ? 128 : cls1_br(), MAX_BR, MAX_BR};
     // class 0 (tiny regions in their own kernel) is kept compiled for experiments but receives no work (see node_class)
     const int tabm = getenv("RAFFT_TAB") ? atoi(getenv("RAFFT_TAB")) : 0;      // bit c: energy tables of class c in LDS
     // The one-wavefront class packs 12 wavefronts - what a CU holds of them anyway - into one workgroup that shares ONE LDS
@@ -237,18 +242,20 @@ int class_cfg(int K, int maxL, ClsCfg out[NGEN])
     // (measured: 5.9 -> 5.4 ms per benchmark batch in this kernel; with 4 or 8 per workgroup a CU holds fewer wavefronts
     // and loses more than it gains).  Falls back to one wavefront per workgroup, tables in L2, when nb_mode makes the
     // per-wavefront arrays too big for 12 to fit.  RAFFT_WPB=1/4/12 overrides.
-    int wpb1 = getenv("RAFFT_WPB") ? atoi(getenv("RAFFT_WPB")) : 12;
-    if (!(wpb1 == 4 || wpb1 == 12)) wpb1 = 1;
+    int wpb1 = getenv("RAFFT_WPB") ? atoi(getenv("RAFFT_WPB")) : (nofft1 ? 16 : 12);
+    if (!(wpb1 == 4 || wpb1 == 12 || (wpb1 == 16 && nofft1))) wpb1 = 1;
     if (wpb1 > 1) {
         const int Kmax1 = std::max(1, std::min(K, cls1_P() - 1));
-        if (expand_lds(cls1_P(), CLS01_L, cls1_P() / 2, cls1_br(), Kmax1, true, wpb1).total > 160 * 1024) wpb1 = 1;
+        if (wpb1 == 16 && expand_lds(cls1_P(), CLS01_L, cls1_P() / 2, BR[1], Kmax1, true, wpb1, nofft1).total > 160 * 1024) wpb1 = 12;
+        if (expand_lds(cls1_P(), CLS01_L, cls1_P() / 2, BR[1], Kmax1, true, wpb1, nofft1).total > 160 * 1024) wpb1 = 1;
     }
     const int WPB[NGEN] = {1, wpb1, 1, 1};
     const bool TAB[NGEN] = {false, (tabm & 2) != 0 || WPB[1] > 1, (tabm & 4) != 0, false};    // (LDS tables come with LDS twiddles: FFT sizes <= CLS2_P only)
     for (int c = 0; c < NGEN; c++) {
         int nmax = c == 0 ? BIG_N : P[c] / 2;
         int Kmax = std::max(1, std::min(K, c == 0 ? 2 * BIG_N - 1 : P[c] - 1));
-        ExpandLds l = expand_lds(P[c], LM[c], nmax, BR[c], Kmax, TAB[c], WPB[c]);
+        const bool nf = (c == 1 && nofft1 && WPB[1] > 1) || (c == 2 && nofft2);
+        ExpandLds l = expand_lds(P[c], LM[c], nmax, BR[c], Kmax, TAB[c], WPB[c], nf);
         // region A is time-shared: behind the fp64 lag values (8 P bytes) it must still hold the branch prefix sums
         // (10 bytes per branch), the select histogram and the window_slide scratch of this class
         if (c == 0 && longseq && (80 * (BIG_N / 64) + 24 * 8 * std::max(Kmax, 1) + 4096 > 16 * P[c] || 10 * (BR[c] + 1) + 16 + 24 * Kmax + 2048 > 16 * P[c]))
@@ -259,7 +266,7 @@ int class_cfg(int K, int maxL, ClsCfg out[NGEN])
             return fail(RAFFT_ERR_PARAM, "internal: the LDS copy of the bases sits too low for its shifted pointer");
         int per_cu = std::max(1, std::min(32 / (NT[c] / 64), WPB[c] * ((160 * 1024) / l.total)));      // teams per CU
         if (c == 1 && getenv("RAFFT_C1_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(getenv("RAFFT_C1_PER_CU"))));
-        out[c] = {NT[c], P[c], LM[c], nmax, BR[c], Kmax, l.total, g.n_cu * per_cu, TAB[c], WPB[c]};
+        out[c] = {NT[c], P[c], LM[c], nmax, BR[c], Kmax, l.total, g.n_cu * per_cu, TAB[c], WPB[c], nf};
         // a size class that no region of this batch can reach need not fit (class 3 needs n > 1024, class 0 n > 4096)
         const bool reachable = c == 0 ? longseq : (c < 3 || maxL > CLS2_P / 2);
         if (l.total > 160 * 1024 && reachable)
@@ -295,16 +302,18 @@ int launch_expand_cls(const Dev &d, int cls, const ClsCfg cf[NGEN], unsigned n_b
     }
     const bool longseq = cf[2].Lmax == 0;          // (class_cfg: no LDS copy of the bases)
     if (cls == 0) return launch_expand<512, false, 1, 2>(d, 0, cf[0], n_blocks, st);
-    if (longseq && cls == 2 && cf[2].nt == 256) return launch_expand<256, false, 1, 1>(d, 2, cf[2], n_blocks, st);
-    if (longseq && cls >= 2) return launch_expand<512, false, 1, 1>(d, cls, cf[cls], n_blocks, st);
+    const int nf = cls < NGEN && cf[cls].nofft ? 0x2000 : 0;
+    if (longseq && cls == 2 && cf[2].nt == 256) return launch_expand<256, false, 1, 1>(d, 2 | nf, cf[2], n_blocks, st);
+    if (longseq && cls >= 2) return launch_expand<512, false, 1, 1>(d, cls | nf, cf[cls], n_blocks, st);
     if (cls == 1) {
         if (cf[1].wpb == 4) return launch_expand<64, true, 4>(d, 1, cf[1], n_blocks, st);
-        if (cf[1].wpb == 12) return launch_expand<64, true, 12>(d, dry ? (0x101 | (std::max(0, atoi(getenv("RAFFT_TWICE")) - 2) << 9)) : 1, cf[1], n_blocks, st);
+        if (cf[1].wpb == 16) return launch_expand<64, true, 16>(d, 1 | (cf[1].nofft ? 0x2000 : 0), cf[1], n_blocks, st);
+        if (cf[1].wpb == 12) return launch_expand<64, true, 12>(d, (dry ? (0x101 | (std::max(0, atoi(getenv("RAFFT_TWICE")) - 2) << 9)) : 1) | (cf[1].nofft ? 0x2000 : 0), cf[1], n_blocks, st);
         return cf[1].tab ? launch_expand<64, true>(d, 1, cf[1], n_blocks, st) : launch_expand<64, false>(d, 1, cf[1], n_blocks, st);
     }
     if (cls == 2) {
-        if (cf[2].nt == 512) return cf[2].tab ? launch_expand<512, true>(d, 2, cf[2], n_blocks, st) : launch_expand<512, false>(d, 2, cf[2], n_blocks, st);
-        return cf[2].tab ? launch_expand<256, true>(d, 2, cf[2], n_blocks, st) : launch_expand<256, false>(d, 2, cf[2], n_blocks, st);
+        if (cf[2].nt == 512) return cf[2].tab ? launch_expand<512, true>(d, 2 | nf, cf[2], n_blocks, st) : launch_expand<512, false>(d, 2 | nf, cf[2], n_blocks, st);
+        return cf[2].tab ? launch_expand<256, true>(d, 2 | nf, cf[2], n_blocks, st) : launch_expand<256, false>(d, 2 | nf, cf[2], n_blocks, st);
     }
     return cf[3].tab ? launch_expand<512, true>(d, 3, cf[3], n_blocks, st) : launch_expand<512, false>(d, 3, cf[3], n_blocks, st);
 }
@@ -553,7 +562,16 @@ int Wave::setup()
     const double ms_enc = since(tw0);
     int maxL = 0;
     for (size_t i = 0; i < S; i++) maxL = std::max(maxL, len[i]);
-    if (int rc = class_cfg(p.nb_mode, maxL, cf)) return rc;
+    const int direct_n_ = getenv("RAFFT_DIRECT_N") ? atoi(getenv("RAFFT_DIRECT_N")) : 1024;
+    const bool force_fft_ = getenv("RAFFT_FORCE_FFT") && atoi(getenv("RAFFT_FORCE_FFT"));
+    const bool nofft1 = !seam && !force_fft_ && direct_n_ >= cls1_P() / 2 && p.gc_wei >= 0.0 && p.au_wei >= 0.0 && p.gu_wei >= 0.0 &&
+                        !(getenv("RAFFT_C1_FFT") && atoi(getenv("RAFFT_C1_FFT")));
+    const bool nofft2 = nofft1 && direct_n_ >= CLS2_P / 2 && !(getenv("RAFFT_C2_FFT") && atoi(getenv("RAFFT_C2_FFT")));
+    if (int rc = class_cfg(p.nb_mode, maxL, cf, nofft1, nofft2)) return rc;
+    if (getenv("RAFFT_TRACE"))
+        for (int c = 0; c < NGEN; c++)
+            fprintf(stderr, "[rafft] expand class %d: %d threads x %d regions per workgroup, P <= %d, branches <= %d, lags <= %d, LDS %d B%s\n", c, cf[c].nt, cf[c].wpb,
+                    cf[c].Pmax, cf[c].brmax, cf[c].Kmax, cf[c].lds, cf[c].nofft ? " (no FFT buffers)" : "");
     merge_target = maxL > CLS2_P / 2 ? 3 : 2;
     c = plan_caps(S, sumL, p, est);
     if (std::max((size_t)c.sort_cap * 8, (size_t)24 * 1024) + RL_CAP * 12 + (size_t)(p.max_stack + 4) * (sizeof(ParentInfo) + 12) + 1024 > 150 * 1024)
@@ -613,7 +631,7 @@ int Wave::setup()
         if (int rc = ensure(g.big, (size_t)cf[0].grid * d.big_stride * 8)) return rc;
         d.big_keyv = (double *)g.big.p;
     }
-    d.cls1_P = cls1_P(); d.cls1_br = cls1_br();
+    d.cls1_P = cls1_P(); d.cls1_br = cf[1].brmax;
     d.fetch_bulk = getenv("RAFFT_FETCH") ? std::max(1, atoi(getenv("RAFFT_FETCH"))) : 4;
     d.taper_pct = getenv("RAFFT_TAPER") ? std::max(0, std::min(100, atoi(getenv("RAFFT_TAPER")))) : 25;
     // wide classes: regions of up to 1024 positions are correlated by the exact direct form on multi-word bit masks, longer ones

@@ -210,12 +210,18 @@ struct ExpandLds {
         off_tab, off_tw,      // ... followed by ONE shared area: energy tables, twiddles (offsets inside that area)
         total;
 };
-__host__ __device__ inline ExpandLds expand_lds(int Pmax, int Lmax, int nmax, int brmax, int Kmax, bool tab_lds, int wpb = 1)
+// `nofft`: the class never runs the FFT (every region is correlated by popcounts on bit masks): region A only holds the lag
+// values (8 P bytes) and what follows them in turn - bit masks, select histogram (at 9 P), branch prefix sums, sort keys.
+__host__ __device__ inline ExpandLds expand_lds(int Pmax, int Lmax, int nmax, int brmax, int Kmax, bool tab_lds, int wpb = 1, bool nofft = false)
 {
     ExpandLds l;
     auto al = [](int x) { return (x + 15) & ~15; };
     l.offA = 0;
     l.szA = al(16 * Pmax);
+    if (nofft) {
+        const int need1 = 8 * Pmax + 80 * ((nmax + 63) / 64) + (nmax > 256 ? 24 * 512 : 1152) /* partial results of chunked diagonals (wide classes) */, need2 = 8 * Pmax + 10 * (brmax + 1) + 16, need3 = 8 * Pmax + 8 * Kmax + 64;
+        l.szA = al(need1 > need2 ? (need1 > need3 ? need1 : need3) : (need2 > need3 ? need2 : need3));
+    }
     int o = l.szA;
     l.off_pos = o; o += al(2 * nmax + 2);
     l.off_code = o; o += al(nmax);
@@ -224,7 +230,7 @@ __host__ __device__ inline ExpandLds expand_lds(int Pmax, int Lmax, int nmax, in
     // per-lag arrays (ranked lags, window_slide results, dE, kept list): 14 bytes per searched lag.  In the class with the
     // 128-KiB FFT buffers (P = 8192) a big nb_mode does not fit beside them - but they are only written once the FFTs are
     // done, and then the second half of region A is free except for its first 24 KiB (bit masks 5 KiB at 8 P, branch prefix
-    // sums 10 KiB at 8 P, select histogram 1.2 KiB at 10 P; chunked window_slide partials only exist for nb_mode <= 256):
+    // sums 10 KiB at 8 P, select histogram 1.2 KiB at 9 P; chunked window_slide partials only exist for nb_mode <= 256):
     // they go there, and nb_mode up to 2047 works for sequences of any length up to 4096 nt.
     const int lag_bytes = al(2 * next_pow2_ge(Kmax)) + 4 * al(2 * Kmax) + al(4 * Kmax);
     const bool lag_in_A = Pmax == MAX_P && Kmax > 256 && 8 * Pmax + 24 * 1024 + lag_bytes <= l.szA;
@@ -241,7 +247,7 @@ __host__ __device__ inline ExpandLds expand_lds(int Pmax, int Lmax, int nmax, in
     l.per_team = o;
     int sh = 0;
     l.off_tab = sh; if (tab_lds) sh += al((int)sizeof(SmallT));
-    l.off_tw = sh; if (tab_lds && Pmax <= CLS2_P) sh += al(8 * (Pmax / 2));    // (the twiddles of the largest class stay in L2)
+    l.off_tw = sh; if (tab_lds && Pmax <= CLS2_P && !nofft) sh += al(8 * (Pmax / 2));    // (the twiddles of the largest class stay in L2)
     l.total = wpb * l.per_team + sh;
     return l;
 }

@@ -212,7 +212,7 @@ __device__ __forceinline__ void wave_sync()
 //              mask), the analogue of scipy's own direct branch (rafft/utils.py:121) - and the lag values live in a
 //              per-workgroup scratch in HBM instead of LDS.  Same integer pair counts, same fp64 values, same ranking.
 template <int NT, bool TAB_LDS, int WPB, int LONGSEQ = 0>
-__global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 256 ? 3 : 2)) void expand_kernel(Dev d, int cls_arg, int Pmax, int Lmax, int nmax, int brmax, int Kmax)
+__global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND64_WAVES) : NT == 256 ? 3 : 2)) void expand_kernel(Dev d, int cls_arg, int Pmax, int Lmax, int nmax, int brmax, int Kmax)
 {
     const int cls = cls_arg & 0xFF;
     const bool dry = (cls_arg & 0x100) != 0;      // diagnostic (RAFFT_TWICE=2): everything but the result stores
@@ -221,7 +221,8 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
     static_assert(WPB == 1 || NT == 64, "only the one-wavefront class packs several wavefronts into a workgroup");
     static_assert(LONGSEQ == 0 || NT > 64, "long sequences never reach the one-wavefront class");
     extern __shared__ __align__(16) unsigned char lds_all[];
-    const ExpandLds lay = expand_lds(Pmax, Lmax, nmax, brmax, Kmax, TAB_LDS, WPB);
+    const bool nofft = (cls_arg & 0x2000) != 0;   // the host promises: no seam, no forced FFT, no negative weights, every region within Dev::direct_n
+    const ExpandLds lay = expand_lds(Pmax, Lmax, nmax, brmax, Kmax, TAB_LDS, WPB, nofft);
     const int tid = threadIdx.x % NT;                 // position inside this region's team (a wavefront / the workgroup)
     const int team = threadIdx.x / NT;                // wavefront of the workgroup (0 when the workgroup is the team)
     const unsigned gteam = blockIdx.x * WPB + team, n_teams = gridDim.x * WPB;
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
         {   // (always, so that the compiler knows `tw` for an LDS pointer: a pointer that may be either makes every twiddle
             //  read a FLAT load, and a flat load waits for every global load in flight; the host keeps Pmax <= CLS2_P here)
             float2 *twl = (float2 *)(shared + lay.off_tw);
-            for (int m = threadIdx.x; m < Pmax / 2; m += NT * WPB) twl[m] = d.tw[m * (MAX_P / Pmax)];
+            if (!nofft) for (int m = threadIdx.x; m < Pmax / 2; m += NT * WPB) twl[m] = d.tw[m * (MAX_P / Pmax)];
             tw = twl;
             twN = Pmax;
         }
@@ -356,8 +357,8 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
         // The wide classes correlate regions of up to Dev::direct_n positions by the exact direct form on multi-word bit masks -
         // what the class for regions beyond 4096 positions always does - and longer ones by the FFT (rafft/utils.py:115-122:
         // scipy's convolve makes the same kind of choice); same integer pair counts either way.
-        const bool mw = NT > 64 && LONGSEQ != 2 && n <= d.direct_n && P >= 128 && d.dbg.lag == nullptr && !d.force_fft &&
-                        d.gc >= 0.0 && d.au >= 0.0 && d.gu >= 0.0;
+        const bool mw = !direct && LONGSEQ != 2 && (nofft || (n <= d.direct_n && P >= 128 && d.dbg.lag == nullptr && !d.force_fft &&
+                        d.gc >= 0.0 && d.au >= 0.0 && d.gu >= 0.0));
         if (!direct && !mw && LONGSEQ != 2)
         for (int rep_ = 0; rep_ < 1 + (d.rep & 1); rep_++) {   // d.rep: profiling-only phase doubling
             for (int t = tid; t < P; t += NT) {
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
             unsigned long long *F = (unsigned long long *)(lds + lay.offA + 8 * Pk);
             unsigned long long *R = F + 5 * W;
             build_masks<NT>(F, R, W, n, code, pos, tid);
-            __syncthreads();
+            ESYNC();
             // ... and the three pair counts of every lag: bit ip of window(R_x, sft + 64 w) = base x at position k - ip
             for (int k = tid; k < P; k += NT) {
                 double v = -INFINITY;
@@ -503,7 +504,11 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
                 }
                 keyv[k] = v;
             }
-            __syncthreads();
+            ESYNC();
+            if (inplace) {                                  // lag column of the in-place sort (tiny regions in a class without FFT buffers;
+                for (int k = tid; k < P; k += NT) lagk[k] = (uint16_t)k;      //  it takes the place of the masks, rebuilt for window_slide)
+                ESYNC();
+            }
         } else if (direct) {
             const int c = tid < n ? code[tid] : 0;
             const unsigned long long mA = __ballot(c == 1), mC = __ballot(c == 2), mG = __ballot(c == 3), mU = __ballot(c == 4);
@@ -554,7 +559,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
         ESTAMP(3);   // lag values
         if (skip_lvl >= 3) continue;
         if (selected) {
-            int *hist = (int *)(lds + lay.offA + (LONGSEQ == 2 ? lay.szA - 2048 : 10 * P));     // 256 bins in the slack of region A (its end when the masks are already there)
+            int *hist = (int *)(lds + lay.offA + (LONGSEQ == 2 ? lay.szA - 2048 : nofft ? 8 * P + 80 * ((nmax + 63) >> 6) : 9 * P));      // 256 bins behind the lag values and the bit masks (8 P + 0.625 P at most); at region A's end when the masks of the biggest regions are already there
             int *shs = hist + 256;                                   // scan scratch [32]
             for (int rep_ = 0; rep_ < 1 + ((d.rep >> 1) & 1); rep_++) {
             auto ukey = [&](int i) -> unsigned long long {
@@ -688,7 +693,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? RAFFT_EXPAND64_WAVES : NT == 
             unsigned long long *F = (unsigned long long *)(lds + lay.offA + (inplace ? 0 : 8 * Pk));
             unsigned long long *R = F + 5 * W;
             parts = (WsPart *)(R + 5 * W);
-            if (LONGSEQ != 2 && !mw)   // (the direct correlation on multi-word masks has built them already)
+            if (LONGSEQ != 2 && (!mw || inplace))   // (the direct correlation on multi-word masks has built them already - behind the lag values)
             for (int rep_ = 0; rep_ < 1 + ((d.rep >> 7) & 1); rep_++) {
                 build_masks<NT>(F, R, W, n, code, pos, tid);
                 ESYNC();
