@@ -124,6 +124,14 @@ void rafft_free_result(rafft_result *r);
  * first batch is submitted; call it by hand before dlclose().  Later calls start a fresh scheduler. */
 void rafft_shutdown(void);
 
+/* Allocation counters of the library, process-wide and monotonic: out[0] device buffers allocated so far (hipMalloc calls),
+ * out[1] their bytes, out[2] the slowest of those calls in microseconds, out[3] pinned host chunks allocated, out[4] their
+ * bytes.  Workspaces are sized once for the biggest wave the scheduler may merge and are kept, so a steady stream of equal
+ * batches allocates nothing after its first waves; a caller that times a region (bench.py) takes the difference around
+ * it and reports it - a hipMalloc of gigabytes takes seconds now and then (tools/micro/malloc_busy.hip).
+ * No counterpart in the reference (Python objects; benchmark_results/bench_fft.py:10-22 starts a process per sequence). */
+void rafft_alloc_counters(unsigned long long out[5]);
+
 /* The same, asynchronously - continuous batching.  rafft_fold_submit() copies the sequences, queues the batch and
  * returns at once; rafft_fold_wait() blocks until that batch is done and hands over its result (then the job
  * handle is gone).  One library thread drives all batches in flight: the last folding steps of a batch - which only

@@ -44,7 +44,7 @@ class Stats(C.Structure):
 EXPORTS = ["rafft_init", "rafft_fold_batch", "rafft_fold_submit", "rafft_fold_wait", "rafft_free_result", "rafft_last_error", "rafft_eval_structure",
            "rafft_eval_structures", "rafft_eval_structures_at", "rafft_expand_node", "rafft_get_stats", "rafft_version",
            "rafft_load_params", "rafft_load_params_text", "rafft_reset_params", "rafft_save_params", "rafft_params_info",
-           "rafft_param_value", "rafft_kin_rate_matrix", "rafft_shutdown"]
+           "rafft_param_value", "rafft_kin_rate_matrix", "rafft_shutdown", "rafft_alloc_counters"]
 
 _lib = None
 
@@ -98,6 +98,8 @@ def lib():
     L.rafft_free_result.restype = None
     L.rafft_shutdown.restype = None
     L.rafft_shutdown.argtypes = []
+    L.rafft_alloc_counters.restype = None
+    L.rafft_alloc_counters.argtypes = [C.POINTER(C.c_ulonglong * 5)]
     L.rafft_last_error.restype = C.c_char_p
     L.rafft_version.restype = C.c_char_p
     L.rafft_eval_structure.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int)]

@@ -10,6 +10,7 @@
 #include "rafft_params.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -117,6 +118,9 @@ struct Ctx {
 // condition variable must not be destroyed under a waiter (glibc's pthread_cond_destroy would block process exit).
 Ctx &g = *new Ctx();
 
+// allocations made so far: device buffers (calls, bytes, slowest call in ms) and pinned chunks (calls, bytes) - rafft_alloc_counters()
+std::atomic<unsigned long long> g_dev_allocs{0}, g_dev_bytes{0}, g_dev_worst_us{0}, g_pin_allocs{0}, g_pin_bytes{0};
+
 int ensure(Buf &b, size_t bytes)
 {
     if (bytes <= b.cap) return 0;
@@ -127,6 +131,12 @@ int ensure(Buf &b, size_t bytes)
     size_t want = bytes + std::min<size_t>(bytes / (old_cap ? 2 : 8), (size_t)256 << 20) + 256;
     want = (want + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);      // whole 2 MiB fragments
     hipError_t e = hipMalloc(&b.p, want);
+    {
+        const unsigned long long us = (unsigned long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0_).count();
+        g_dev_allocs++; g_dev_bytes += want;
+        unsigned long long w = g_dev_worst_us.load();
+        while (us > w && !g_dev_worst_us.compare_exchange_weak(w, us)) { }
+    }
     if (getenv("RAFFT_TRACE_ALLOC")) fprintf(stderr, "[rafft] ptr %p (mod 2MiB %zu KiB) ", b.p, ((size_t)(uintptr_t)b.p & (((size_t)2 << 20) - 1)) >> 10);
     if (getenv("RAFFT_TRACE_ALLOC")) fprintf(stderr, "[rafft] t=%.3f device buffer -> %.1f MB in %.3f ms\n", std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(), (double)want / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count());
     if (e != hipSuccess) {
@@ -246,8 +256,8 @@ int class_cfg(int K, int maxL, ClsCfg out[NGEN], bool nofft1 = false, bool nofft
     if (!(wpb1 == 4 || wpb1 == 12 || (wpb1 == 16 && nofft1))) wpb1 = 1;
     if (wpb1 > 1) {
         const int Kmax1 = std::max(1, std::min(K, cls1_P() - 1));
-        if (wpb1 == 16 && expand_lds(cls1_P(), CLS01_L, cls1_P() / 2, BR[1], Kmax1, true, wpb1, nofft1).total > 160 * 1024) wpb1 = 12;
-        if (expand_lds(cls1_P(), CLS01_L, cls1_P() / 2, BR[1], Kmax1, true, wpb1, nofft1).total > 160 * 1024) wpb1 = 1;
+        if (wpb1 == 16 && expand_lds(cls1_P(), CLS01_L, cls1_P() / 2, BR[1], Kmax1, true, wpb1, nofft1, 64).total > 160 * 1024) wpb1 = 12;
+        if (expand_lds(cls1_P(), CLS01_L, cls1_P() / 2, BR[1], Kmax1, true, wpb1, nofft1, 64).total > 160 * 1024) wpb1 = 1;
     }
     const int WPB[NGEN] = {1, wpb1, 1, 1};
     const bool TAB[NGEN] = {false, (tabm & 2) != 0 || WPB[1] > 1, (tabm & 4) != 0, false};    // (LDS tables come with LDS twiddles: FFT sizes <= CLS2_P only)
@@ -255,7 +265,7 @@ int class_cfg(int K, int maxL, ClsCfg out[NGEN], bool nofft1 = false, bool nofft
         int nmax = c == 0 ? BIG_N : P[c] / 2;
         int Kmax = std::max(1, std::min(K, c == 0 ? 2 * BIG_N - 1 : P[c] - 1));
         const bool nf = (c == 1 && nofft1 && WPB[1] > 1) || (c == 2 && nofft2);
-        ExpandLds l = expand_lds(P[c], LM[c], nmax, BR[c], Kmax, TAB[c], WPB[c], nf);
+        ExpandLds l = expand_lds(P[c], LM[c], nmax, BR[c], Kmax, TAB[c], WPB[c], nf, NT[c]);
         // region A is time-shared: behind the fp64 lag values (8 P bytes) it must still hold the branch prefix sums
         // (10 bytes per branch), the select histogram and the window_slide scratch of this class
         if (c == 0 && longseq && (80 * (BIG_N / 64) + 24 * 8 * std::max(Kmax, 1) + 4096 > 16 * P[c] || 10 * (BR[c] + 1) + 16 + 24 * Kmax + 2048 > 16 * P[c]))
@@ -424,6 +434,7 @@ PinBuf pin_acquire(size_t bytes)
     PinBuf b;
     const auto t0_ = std::chrono::steady_clock::now();
     if (hipHostMalloc(&b.p, want, hipHostMallocDefault) != hipSuccess) { b.p = nullptr; return b; }
+    g_pin_allocs++; g_pin_bytes += want;
     if (getenv("RAFFT_TRACE_ALLOC")) fprintf(stderr, "[rafft] t=%.3f pinned chunk %.1f MB in %.3f ms (pool %zu)\n", std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(), (double)want / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count(), g.pin_free.size());
     b.cap = want;
     return b;
@@ -580,15 +591,18 @@ int Wave::setup()
 
     // Buffers are allocated for the wave that queued batches could be merged into (the scheduler folds up to merge_cap()
     // sequences of equal-parameter batches as one wave), not just for this one: a hipFree + hipMalloc of a multi-GB arena
-    // in the middle of a stream of batches stalls every queue for tens of ms (now and then seconds).  Only when that
-    // reserve is small against the HBM (the benchmark set: 2.5 GB -> 10 GB).
+    // in the middle of a stream of batches stalls every queue for tens of ms - and now and then for SECONDS (measured: one
+    // hipMalloc of 7 GB took 2.2 s while another wave's kernels were running; a bench run that met it fell from 290 k to 10 k
+    // sequences/s).  Only when that reserve is small against the HBM (the benchmark set: 4.4 GB -> 21.6 GB per workspace, two
+    // workspaces for bulk waves: 15 % of the card).
     size_t Sr = S;
     Caps cr = c;
     if (S < merge_cap() && !seam) {
         // (a long-tail job has a few sequences per batch: sized once for 64 of them, whatever gets merged later)
         Sr = S >= 256 ? std::min(merge_cap(), 5 * S) : std::max<size_t>(S, std::min<size_t>(64, 32 * S));
         Caps big = plan_caps(Sr, (size_t)((double)sumL * (double)Sr / (double)S), p, est);
-        if (big.bytes <= (size_t)((double)::g.hbm_total * 0.06)) cr = big; else Sr = S;
+        static const double reserve_frac = getenv("RAFFT_RESERVE_FRAC") ? atof(getenv("RAFFT_RESERVE_FRAC")) : 0.10;
+        if (big.bytes <= (size_t)((double)::g.hbm_total * reserve_frac)) cr = big; else Sr = S;
     }
     reserve = (double)Sr / (double)S;
     const size_t sumLr = Sr == S ? sumL : (size_t)((double)sumL * (double)Sr / (double)S);
@@ -1489,6 +1503,14 @@ void rafft_shutdown(void)
     if (t.joinable()) t.join();
     std::lock_guard<std::mutex> lk(g.qmu);
     g.stop = false; g.sched_started = false;
+}
+
+/* out[0..4] = device buffers allocated so far (calls), their bytes, the slowest such call in microseconds, pinned host chunks
+ * allocated (calls), their bytes.  Process-wide, monotonic: a caller that takes the difference around a region of its own
+ * sees whether the library had to allocate inside it (a hipMalloc of gigabytes now and then takes seconds). */
+void rafft_alloc_counters(unsigned long long out[5])
+{
+    out[0] = g_dev_allocs; out[1] = g_dev_bytes; out[2] = g_dev_worst_us; out[3] = g_pin_allocs; out[4] = g_pin_bytes;
 }
 
 const char *rafft_version(void) { return "raffthip 0.2 (gfx950, HIP; built-in Turner-2004 37C tables or ViennaRNA parameter files)"; }

@@ -212,14 +212,14 @@ struct ExpandLds {
 };
 // `nofft`: the class never runs the FFT (every region is correlated by popcounts on bit masks): region A only holds the lag
 // values (8 P bytes) and what follows them in turn - bit masks, select histogram (at 9 P), branch prefix sums, sort keys.
-__host__ __device__ inline ExpandLds expand_lds(int Pmax, int Lmax, int nmax, int brmax, int Kmax, bool tab_lds, int wpb = 1, bool nofft = false)
+__host__ __device__ inline ExpandLds expand_lds(int Pmax, int Lmax, int nmax, int brmax, int Kmax, bool tab_lds, int wpb = 1, bool nofft = false, int nt = 512)
 {
     ExpandLds l;
     auto al = [](int x) { return (x + 15) & ~15; };
     l.offA = 0;
     l.szA = al(16 * Pmax);
     if (nofft) {
-        const int need1 = 8 * Pmax + 80 * ((nmax + 63) / 64) + (nmax > 256 ? 24 * 512 : 1152) /* partial results of chunked diagonals (wide classes) */, need2 = 8 * Pmax + 10 * (brmax + 1) + 16, need3 = 8 * Pmax + 8 * Kmax + 64;
+        const int need1 = 8 * Pmax + 80 * ((nmax + 63) / 64) + (nt > 64 && 24 * nt > 1152 ? 24 * nt : 1152) /* select histogram, later the partial results of chunked diagonals (wide classes) */, need2 = 8 * Pmax + 10 * (brmax + 1) + 16, need3 = 8 * Pmax + 8 * Kmax + 64;
         l.szA = al(need1 > need2 ? (need1 > need3 ? need1 : need3) : (need2 > need3 ? need2 : need3));
     }
     int o = l.szA;

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
     static_assert(LONGSEQ == 0 || NT > 64, "long sequences never reach the one-wavefront class");
     extern __shared__ __align__(16) unsigned char lds_all[];
     const bool nofft = (cls_arg & 0x2000) != 0;   // the host promises: no seam, no forced FFT, no negative weights, every region within Dev::direct_n
-    const ExpandLds lay = expand_lds(Pmax, Lmax, nmax, brmax, Kmax, TAB_LDS, WPB, nofft);
+    const ExpandLds lay = expand_lds(Pmax, Lmax, nmax, brmax, Kmax, TAB_LDS, WPB, nofft, NT);
     const int tid = threadIdx.x % NT;                 // position inside this region's team (a wavefront / the workgroup)
     const int team = threadIdx.x / NT;                // wavefront of the workgroup (0 when the workgroup is the team)
     const unsigned gteam = blockIdx.x * WPB + team, n_teams = gridDim.x * WPB;
