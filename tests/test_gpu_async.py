@@ -123,6 +123,42 @@ def test_gpu_queued_batches_with_equal_parameters_are_merged_and_split_back(benc
         assert total == sum(single_structs)          # every wave's work is attributed to exactly one of its batches
 
 
+def test_gpu_steady_stream_of_equal_batches_allocates_nothing_after_its_first_waves(bench_rows):
+    """Workspaces are sized at first use for the biggest wave the scheduler may merge from such batches (five of them, up to the
+    merge cap) and are kept: whatever way the later rounds are merged, the library allocates no device buffer (a hipMalloc of
+    gigabytes takes seconds now and then - tools/micro/malloc_busy.hip).  rafft_alloc_counters() is what bench.py reports."""
+    import ctypes as C
+    lib = _native.lib()
+
+    def counters():
+        a = (C.c_ulonglong * 5)()
+        lib.rafft_alloc_counters(C.byref(a))
+        return list(a)
+
+    seqs = [r["seq"] for r in bench_rows if len(r["seq"]) <= 400][:600]
+    kw = dict(nb_mode=100, max_stack=20, max_branch=1000, traj=False)
+    want = key(rafft_amd.fold_batch(seqs, **kw), False)
+
+    def round_(n, depth):
+        pend = []
+        for _ in range(n):
+            pend.append(rafft_amd.submit_batch(seqs, **kw))
+            if len(pend) >= depth:
+                assert key(pend.pop(0).result(), False) == want
+        for pb in pend:
+            assert key(pb.result(), False) == want
+
+    for _ in range(3):             # first waves: both workspaces for bulk waves meet a merged wave
+        round_(8, 8)
+    before = counters()
+    assert before[0] > 0 and before[1] > 0 and before[3] > 0
+    for n, depth in ((8, 8), (5, 2), (7, 4), (1, 1), (6, 6)):
+        round_(n, depth)
+    after = counters()
+    assert after[0] == before[0] and after[1] == before[1], (before, after)
+    assert after[2] >= before[2]
+
+
 def test_gpu_merged_wave_overflow_regrows_and_stays_exact(bench_rows, monkeypatch):
     """a wave that serves several batches and overflows its (starved) HBM arenas is re-run with larger ones - for all of
     its batches - and every batch still gets exactly its result"""
