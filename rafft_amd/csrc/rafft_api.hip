@@ -287,16 +287,16 @@ int class_cfg(int K, int maxL, ClsCfg out[NGEN], bool nofft1 = false, bool nofft
     return 0;
 }
 
-template <int NT, bool TAB, int WPB = 1, int LONGSEQ = 0>
+template <int NT, bool TAB, int WPB = 1, int LONGSEQ = 0, bool PROD = false>
 int launch_expand(const Dev &d, int cls, const ClsCfg &cf, unsigned n_teams, hipStream_t st)
 {
     static int lds_set = 0;
     if (cf.lds > lds_set) {
-        HIPCHK(hipFuncSetAttribute((const void *)expand_kernel<NT, TAB, WPB, LONGSEQ>, hipFuncAttributeMaxDynamicSharedMemorySize, cf.lds));
+        HIPCHK(hipFuncSetAttribute((const void *)expand_kernel<NT, TAB, WPB, LONGSEQ, PROD>, hipFuncAttributeMaxDynamicSharedMemorySize, cf.lds));
         lds_set = cf.lds;
     }
     const unsigned n_blocks = (n_teams + WPB - 1) / WPB;
-    hipLaunchKernelGGL((expand_kernel<NT, TAB, WPB, LONGSEQ>), dim3(n_blocks), dim3(NT * WPB), cf.lds, st, d, cls, cf.Pmax, cf.Lmax, cf.nmax, cf.brmax, cf.Kmax);
+    hipLaunchKernelGGL((expand_kernel<NT, TAB, WPB, LONGSEQ, PROD>), dim3(n_blocks), dim3(NT * WPB), cf.lds, st, d, cls, cf.Pmax, cf.Lmax, cf.nmax, cf.brmax, cf.Kmax);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -305,24 +305,33 @@ int launch_expand_cls(const Dev &d, int cls, const ClsCfg cf[NGEN], unsigned n_b
 {
     if (cls >= NGEN) {        // small regions: teams of 16 / 32 lanes, four wavefronts per workgroup (n_blocks = workgroups)
         const int arg = cls | ((getenv("RAFFT_SMALL_DIAG") ? atoi(getenv("RAFFT_SMALL_DIAG")) : 0) << 8);
-        if (cls == 4) hipLaunchKernelGGL(expand_small_kernel<16>, dim3(n_blocks), dim3(64 * SM_WG_WAVES), small_lds_bytes<16>(), st, d, arg);
-        else hipLaunchKernelGGL(expand_small_kernel<32>, dim3(n_blocks), dim3(64 * SM_WG_WAVES), small_lds_bytes<32>(), st, d, arg);
+        static const bool prod_ok = !(getenv("RAFFT_PROD") && atoi(getenv("RAFFT_PROD")) == 0);
+        const bool prod = prod_ok && arg == cls && d.prof_e == nullptr && d.dbg.lag == nullptr;      // no diagnostics asked for: the production build
+        if (cls == 4 && prod) hipLaunchKernelGGL((expand_small_kernel<16, true>), dim3(n_blocks), dim3(64 * SM_WG_WAVES), small_lds_bytes<16>(), st, d, arg);
+        else if (cls == 4) hipLaunchKernelGGL((expand_small_kernel<16, false>), dim3(n_blocks), dim3(64 * SM_WG_WAVES), small_lds_bytes<16>(), st, d, arg);
+        else if (prod) hipLaunchKernelGGL((expand_small_kernel<32, true>), dim3(n_blocks), dim3(64 * SM_WG_WAVES), small_lds_bytes<32>(), st, d, arg);
+        else hipLaunchKernelGGL((expand_small_kernel<32, false>), dim3(n_blocks), dim3(64 * SM_WG_WAVES), small_lds_bytes<32>(), st, d, arg);
         HIPCHK(hipGetLastError());
         return 0;
     }
     const bool longseq = cf[2].Lmax == 0;          // (class_cfg: no LDS copy of the bases)
     if (cls == 0) return launch_expand<512, false, 1, 2>(d, 0, cf[0], n_blocks, st);
     const int nf = cls < NGEN && cf[cls].nofft ? 0x2000 : 0;
+    // the production build of the classes without FFT buffers: no diagnostics of any kind asked for (RAFFT_PROD=0: the general build)
+    static const bool prod_ok = !(getenv("RAFFT_PROD") && atoi(getenv("RAFFT_PROD")) == 0);
+    const bool prod = prod_ok && nf && !dry && d.prof_e == nullptr && d.rep == 0 && d.dbg.lag == nullptr && !d.force_fft;
     if (longseq && cls == 2 && cf[2].nt == 256) return launch_expand<256, false, 1, 1>(d, 2 | nf, cf[2], n_blocks, st);
     if (longseq && cls >= 2) return launch_expand<512, false, 1, 1>(d, cls | nf, cf[cls], n_blocks, st);
     if (cls == 1) {
         if (cf[1].wpb == 4) return launch_expand<64, true, 4>(d, 1, cf[1], n_blocks, st);
+        if (cf[1].wpb == 16 && prod) return launch_expand<64, true, 16, 0, true>(d, 1 | nf, cf[1], n_blocks, st);
         if (cf[1].wpb == 16) return launch_expand<64, true, 16>(d, 1 | (cf[1].nofft ? 0x2000 : 0), cf[1], n_blocks, st);
         if (cf[1].wpb == 12) return launch_expand<64, true, 12>(d, (dry ? (0x101 | (std::max(0, atoi(getenv("RAFFT_TWICE")) - 2) << 9)) : 1) | (cf[1].nofft ? 0x2000 : 0), cf[1], n_blocks, st);
         return cf[1].tab ? launch_expand<64, true>(d, 1, cf[1], n_blocks, st) : launch_expand<64, false>(d, 1, cf[1], n_blocks, st);
     }
     if (cls == 2) {
         if (cf[2].nt == 512) return cf[2].tab ? launch_expand<512, true>(d, 2 | nf, cf[2], n_blocks, st) : launch_expand<512, false>(d, 2 | nf, cf[2], n_blocks, st);
+        if (prod && !cf[2].tab) return launch_expand<256, false, 1, 0, true>(d, 2 | nf, cf[2], n_blocks, st);
         return cf[2].tab ? launch_expand<256, true>(d, 2 | nf, cf[2], n_blocks, st) : launch_expand<256, false>(d, 2 | nf, cf[2], n_blocks, st);
     }
     return cf[3].tab ? launch_expand<512, true>(d, 3, cf[3], n_blocks, st) : launch_expand<512, false>(d, 3, cf[3], n_blocks, st);
@@ -646,6 +655,7 @@ int Wave::setup()
         d.big_keyv = (double *)g.big.p;
     }
     d.cls1_P = cls1_P(); d.cls1_br = cf[1].brmax;
+    d.cand_slab = getenv("RAFFT_SLAB") ? std::max(16, atoi(getenv("RAFFT_SLAB"))) : 64;
     d.fetch_bulk = getenv("RAFFT_FETCH") ? std::max(1, atoi(getenv("RAFFT_FETCH"))) : 4;
     d.taper_pct = getenv("RAFFT_TAPER") ? std::max(0, std::min(100, atoi(getenv("RAFFT_TAPER")))) : 25;
     // wide classes: regions of up to 1024 positions are correlated by the exact direct form on multi-word bit masks, longer ones
@@ -1025,6 +1035,8 @@ int Wave::finish()
                         pe[c * PROF_E + 8 + k] ? (double)pe[c * PROF_E + 16 + k] / (double)pe[c * PROF_E + 8 + k] / 1e3 : 0.0);
             fprintf(stderr, "\n");
             fprintf(stderr, "[rafft]   class %d: inside fetch+header: claiming items %llu Mcycles, work-list entry %llu Mcycles (of %llu)\n", c, pe[c * PROF_E + 40] / 1000000, pe[c * PROF_E + 41] / 1000000, pe[c * PROF_E] / 1000000);
+            fprintf(stderr, "[rafft]   class %d: inside dE: branch prefix sums %llu, candidates %llu Mcycles; inside emit: compaction %llu, candidate slots %llu, keys+rank %llu, hashes+cuts+stores %llu Mcycles\n", c,
+                    pe[c * PROF_E + 42] / 1000000, pe[c * PROF_E + 43] / 1000000, pe[c * PROF_E + 44] / 1000000, pe[c * PROF_E + 45] / 1000000, pe[c * PROF_E + 46] / 1000000, pe[c * PROF_E + 47] / 1000000);
             if (pe[c * PROF_E + 32]) fprintf(stderr, "[rafft]   class %d: draining the previous region's stores (RAFFT_REP=256): %llu Mcycles\n", c, pe[c * PROF_E + 32] / 1000000);
             if (c == 1) {
                 fprintf(stderr, "[rafft]   class 1, regions without any stem / without a kept candidate (share of the size class):");
@@ -1400,7 +1412,8 @@ static void scheduler_main()
                 bool fits_now = std::max(cc.bytes, g.ws[w].bytes()) + others <= (size_t)((double)g.hbm_total * 0.85);
                 // waves whose arenas take more than a tenth of the HBM run one at a time (the halves of a split job would
                 // otherwise fill two workspaces of that size)
-                const size_t big_wave = g.hbm_total / 10;
+                static const double big_wave_frac = getenv("RAFFT_BIG_WAVE_FRAC") ? atof(getenv("RAFFT_BIG_WAVE_FRAC")) : 0.10;
+                const size_t big_wave = (size_t)((double)g.hbm_total * big_wave_frac);
                 if (cc.bytes > big_wave)
                     for (int k = 0; k < MAX_PIPES; k++) if (slot[k].wave && slot[k].wave->c.bytes > big_wave) fits_now = false;
                 if ((cc.bytes > budget || (!fits_now && n_running == 0)) && job.seqs.size() > 1) {

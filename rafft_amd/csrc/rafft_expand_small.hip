@@ -44,10 +44,11 @@ __device__ __forceinline__ uint32_t sm_shift(uint32_t x, int s)          // x >>
     return s >= 0 ? (s < 32 ? x >> s : 0u) : (s > -32 ? x << -s : 0u);
 }
 
-template <int TL>
+// PROD: the production build (no seam, no phase stamps, no diagnostic exits compiled in): fewer live registers, fewer spills
+template <int TL, bool PROD = false>
 __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_small_kernel(Dev d, int cls_arg)
 {
-    const int cls = cls_arg & 0xFF, diag = cls_arg >> 8;       // diag: diagnostic early exits (RAFFT_SMALL_DIAG)
+    const int cls = cls_arg & 0xFF, diag = PROD ? 0 : cls_arg >> 8;       // diag: diagnostic early exits (RAFFT_SMALL_DIAG)
     if (diag == 1) return;
     using LY = SmLds<TL>;
     constexpr int TPW = 64 / TL;                  // teams per wavefront
@@ -86,11 +87,11 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
     int fshard = (int)(gw & (NSHARD - 1));
     unsigned long long ffailed = 0;
     unsigned long long slab_base = 0; unsigned slab_left = 0;                 // lane 0 only: reserved candidate slots
-    const bool dbg = d.dbg.lag != nullptr;                                    // kernel-level seam (one region, team 0)
+    const bool dbg = !PROD && d.dbg.lag != nullptr;                                    // kernel-level seam (one region, team 0)
     const double par_none = 0.0; (void)par_none;
 
     if (diag == 4) return;
-    const bool eprof = d.prof_e != nullptr && lane == 0;      // diagnostic phase stamps (RAFFT_TRACE=3)
+    const bool eprof = !PROD && d.prof_e != nullptr && lane == 0;      // diagnostic phase stamps (RAFFT_TRACE=3)
     unsigned long long eacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, et = eprof ? clock64() : 0, n_rounds = 0;
 #define SSTAMP(k) do { if (eprof) { const unsigned long long tn_ = clock64(); eacc[k] += tn_ - et; et = tn_; } } while (0)
     for (;;) {
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
         int ovf = 0;
         if (lane == 0 && tot) {
             if ((unsigned)tot > slab_left) {        // a new slab of candidate slots (the rest of the old one is dropped)
-                const unsigned slab = d.cand_shard_cap >= 4096 ? 64u : 16u;
+                const unsigned slab = d.cand_shard_cap >= 64u * (unsigned)d.cand_slab ? (unsigned)d.cand_slab : 16u;
                 const unsigned want = (unsigned)tot > slab ? (unsigned)tot : slab;
                 const unsigned long long b0 = atomicAdd(&d.c->cand[shard].v, (unsigned long long)want);
                 if (b0 + want > d.cand_shard_cap) { atomicOr(&d.c->overflow, OVF_CAND); ovf = 1; slab_left = 0; }

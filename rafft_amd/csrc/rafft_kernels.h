@@ -117,6 +117,7 @@ struct Dev {
     int fetch_bulk, taper_pct;   // work chunks: regions (rounds of the small-region kernel) per claim in the bulk of a list; percent of the list handed out that way
     int direct_n;                // wide classes: multi-word popcount correlation up to this region size, FFT beyond (RAFFT_DIRECT_N)
     int sm_n4, sm_n5;            // small-region classes: regions of up to sm_n4 positions go to class 4 (teams of 16 lanes), up to
+    int cand_slab;                           // candidate slots an expand wavefront reserves at a time (one returning atomic each)
                                  // sm_n5 to class 5 (teams of 32); 0 = class unused (see node_class)
     int cls1_P, cls1_br;         // limits of the one-wavefront expand class (FFT size, branches): they set its LDS per wavefront
     double min_nrj, gc, au, gu;

@@ -211,17 +211,22 @@ __device__ __forceinline__ void wave_sync()
 //              correlation is the exact direct form on multi-word bit masks - popcount(base mask AND shifted reversed base
 //              mask), the analogue of scipy's own direct branch (rafft/utils.py:121) - and the lag values live in a
 //              per-workgroup scratch in HBM instead of LDS.  Same integer pair counts, same fp64 values, same ranking.
-template <int NT, bool TAB_LDS, int WPB, int LONGSEQ = 0>
+// PROD: the production build of a class without FFT buffers (no seam, no forced FFT, no negative weights, no diagnostics): the
+// debug-seam stores, the phase stamps, the FFT and the cell-by-cell window_slide are compiled out - fewer live registers, fewer spills.
+template <int NT, bool TAB_LDS, int WPB, int LONGSEQ = 0, bool PROD = false>
 __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND64_WAVES) : NT == 256 ? 3 : 2)) void expand_kernel(Dev d, int cls_arg, int Pmax, int Lmax, int nmax, int brmax, int Kmax)
 {
     const int cls = cls_arg & 0xFF;
-    const bool dry = (cls_arg & 0x100) != 0;      // diagnostic (RAFFT_TWICE=2): everything but the result stores
-    const int skip_lvl = (cls_arg >> 9) & 15;      // diagnostic (RAFFT_TWICE=3..7): a region stops after window_slide (1), ranking (2), lag values (3), FFTs (4), LDS fill (5)
+    const DebugOut dbg = PROD ? DebugOut{} : d.dbg;
+    const int rep = PROD ? 0 : d.rep, force_fft = PROD ? 0 : d.force_fft;
+    unsigned long long *const prof_e = PROD ? nullptr : d.prof_e;
+    const bool dry = !PROD && (cls_arg & 0x100) != 0;      // diagnostic (RAFFT_TWICE=2): everything but the result stores
+    const int skip_lvl = PROD ? 0 : (cls_arg >> 9) & 15;      // diagnostic (RAFFT_TWICE=3..7): a region stops after window_slide (1), ranking (2), lag values (3), FFTs (4), LDS fill (5)
 
     static_assert(WPB == 1 || NT == 64, "only the one-wavefront class packs several wavefronts into a workgroup");
     static_assert(LONGSEQ == 0 || NT > 64, "long sequences never reach the one-wavefront class");
     extern __shared__ __align__(16) unsigned char lds_all[];
-    const bool nofft = (cls_arg & 0x2000) != 0;   // the host promises: no seam, no forced FFT, no negative weights, every region within Dev::direct_n
+    const bool nofft = PROD || (cls_arg & 0x2000) != 0;   // the host promises: no seam, no forced FFT, no negative weights, every region within Dev::direct_n
     const ExpandLds lay = expand_lds(Pmax, Lmax, nmax, brmax, Kmax, TAB_LDS, WPB, nofft, NT);
     const int tid = threadIdx.x % NT;                 // position inside this region's team (a wavefront / the workgroup)
     const int team = threadIdx.x / NT;                // wavefront of the workgroup (0 when the workgroup is the team)
@@ -272,9 +277,10 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
     // Work items are fetched FETCH at a time and candidate slots are reserved in slabs, so that the
     // two atomics with a returned value (a full L2 round trip each) are paid once per several regions.
     // (only when there is plenty of work: with fewer regions than workgroups every region gets its own)
-    const bool eprof = d.prof_e != nullptr && tid == 0;      // diagnostic phase stamps (RAFFT_TRACE=3)
-    unsigned long long eacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, et = eprof ? clock64() : 0;
-#define ESTAMP(k) do { if (eprof) { const unsigned long long tn_ = clock64(); eacc[k] += tn_ - et; et = tn_; } } while (0)
+    const bool eprof = prof_e != nullptr && tid == 0;      // diagnostic phase stamps (RAFFT_TRACE=3)
+    unsigned long long eacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, et = eprof ? clock64() : 0, ft1 = 0;
+#define ESTAMP(k) do { if (eprof) { const unsigned long long tn_ = clock64(); eacc[k] += tn_ - et; et = tn_; ft1 = tn_; } } while (0)
+#define FSTAMP(k) do { if (eprof) { const unsigned long long tn_ = clock64(); eacc[k] += tn_ - ft1; ft1 = tn_; } } while (0)   // inside dE (10, 11) and emit (12-15)
     const unsigned FETCH = (NT == 64 && n_items > 4u * n_teams) ? (unsigned)d.fetch_bulk : 1u;
     unsigned fetch_base = 0, fetch_left = 0;                 // uniform across the workgroup
     int fshard = (int)(gteam & (NSHARD - 1));                // work-cursor shard this team claims from next (fetch_chunk)
@@ -283,10 +289,10 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
 
     for (;;) {
         ESYNC();                       // previous region's LDS use is over
-        if (d.prof_e != nullptr && (d.rep & 256)) {      // diagnostic: how long the previous region's stores take to drain
+        if (prof_e != nullptr && (rep & 256)) {      // diagnostic: how long the previous region's stores take to drain
             const unsigned long long t0_ = clock64();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (tid == 0) atomicAdd(&d.prof_e[cls * PROF_E + 32], (unsigned long long)(clock64() - t0_));
+            if (tid == 0) atomicAdd(&prof_e[cls * PROF_E + 32], (unsigned long long)(clock64() - t0_));
         }
         unsigned long long ft0 = eprof ? clock64() : 0;
         if (fetch_left == 0) {
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
         const unsigned long long t_region0 = eprof ? clock64() : 0;
         const int Kp = d.K < m ? (d.K > 0 ? d.K : 0) : m;
 
-        for (int rep_ = 0; rep_ < 1 + ((d.rep >> 4) & 1); rep_++) {
+        for (int rep_ = 0; rep_ < 1 + ((rep >> 4) & 1); rep_++) {
         for (int t = tid; t < n; t += NT) {
             const int p = posg[t];
             if (LONGSEQ == 0 && d.pos_packed) { pos[t] = (uint16_t)(p & 0x0FFF); code[t] = (uint8_t)(p >> 12); }   // (Dev::pos_packed)
@@ -351,16 +357,16 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
         // direct form: popcount(mask & shifted reversed mask) per lag - the analogue of scipy's own
         // method="auto" picking direct convolution for short inputs (rafft/utils.py:121).  Longer regions
         // go through two packed complex FFTs in LDS.  Both give the same exact integer pair counts.
-        const bool direct = (NT == 64) && n <= 64 && !d.force_fft;
+        const bool direct = (NT == 64) && n <= 64 && !force_fft;
         float2 *z1 = (float2 *)(lds + lay.offA);
         float2 *z2 = z1 + P;
         // The wide classes correlate regions of up to Dev::direct_n positions by the exact direct form on multi-word bit masks -
         // what the class for regions beyond 4096 positions always does - and longer ones by the FFT (rafft/utils.py:115-122:
         // scipy's convolve makes the same kind of choice); same integer pair counts either way.
-        const bool mw = !direct && LONGSEQ != 2 && (nofft || (n <= d.direct_n && P >= 128 && d.dbg.lag == nullptr && !d.force_fft &&
+        const bool mw = !direct && LONGSEQ != 2 && (nofft || (n <= d.direct_n && P >= 128 && dbg.lag == nullptr && !force_fft &&
                         d.gc >= 0.0 && d.au >= 0.0 && d.gu >= 0.0));
         if (!direct && !mw && LONGSEQ != 2)
-        for (int rep_ = 0; rep_ < 1 + (d.rep & 1); rep_++) {   // d.rep: profiling-only phase doubling
+        for (int rep_ = 0; rep_ < 1 + (rep & 1); rep_++) {   // rep: profiling-only phase doubling
             for (int t = tid; t < P; t += NT) {
                 int c = t < n ? code[t] : 0;
                 z1[t] = make_float2(c == 1 ? 1.f : 0.f, c == 3 ? 1.f : 0.f); // A + iG
@@ -474,7 +480,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
         //    pattern of the fp64 value, ties: larger lag first) - their order is not needed, because the only
         //    place it shows is the stable dE sort of the candidates, and that breaks ties from (value, lag) itself;
         //  - tiny FFT sizes (P <= 128) and the debug seam, which reports the ranking, sort all keys in place.
-        const bool dbgrank = d.dbg.lag != nullptr;
+        const bool dbgrank = dbg.lag != nullptr;
         const bool ranked = m > Kp;
         const bool selected = ranked && P >= 128;
         const bool inplace = (ranked && !selected) || (dbgrank && !selected);    // keys sorted in place, rk[] in rank order
@@ -513,7 +519,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
             const int c = tid < n ? code[tid] : 0;
             const unsigned long long mA = __ballot(c == 1), mC = __ballot(c == 2), mG = __ballot(c == 3), mU = __ballot(c == 4);
             const unsigned long long rU = __brevll(mU) >> (64 - n), rC = __brevll(mC) >> (64 - n);   // strand reversed
-            for (int rep_ = 0; rep_ < 1 + (d.rep & 1) + ((d.rep >> 5) & 1); rep_++)
+            for (int rep_ = 0; rep_ < 1 + (rep & 1) + ((rep >> 5) & 1); rep_++)
             for (int k = tid; k < P; k += NT) {
                 double v = -INFINITY;
                 if (k < m) {
@@ -561,7 +567,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
         if (selected) {
             int *hist = (int *)(lds + lay.offA + (LONGSEQ == 2 ? lay.szA - 2048 : nofft ? 8 * P + 80 * ((nmax + 63) >> 6) : 9 * P));      // 256 bins behind the lag values and the bit masks (8 P + 0.625 P at most); at region A's end when the masks of the biggest regions are already there
             int *shs = hist + 256;                                   // scan scratch [32]
-            for (int rep_ = 0; rep_ < 1 + ((d.rep >> 1) & 1); rep_++) {
+            for (int rep_ = 0; rep_ < 1 + ((rep >> 1) & 1); rep_++) {
             auto ukey = [&](int i) -> unsigned long long {
                 unsigned long long u = (unsigned long long)__double_as_longlong(keyv[i]);
                 return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
@@ -636,12 +642,12 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
             }
             }
             for (int r = tid; r < Kp; r += NT)
-                if (d.dbg.lag) { d.dbg.lag[r] = rk[r]; d.dbg.corval[r] = keyv[rk[r]]; }
-            if (tid == 0 && d.dbg.n_ranked) *d.dbg.n_ranked = Kp;
+                if (dbg.lag) { dbg.lag[r] = rk[r]; dbg.corval[r] = keyv[rk[r]]; }
+            if (tid == 0 && dbg.n_ranked) *dbg.n_ranked = Kp;
             ESYNC();
         } else {
         if (inplace)
-        for (int rep_ = 0; rep_ < 1 + ((d.rep >> 1) & 1); rep_++)
+        for (int rep_ = 0; rep_ < 1 + ((rep >> 1) & 1); rep_++)
             for (int k2 = 2; k2 <= P; k2 <<= 1) {
                 for (int j = k2 >> 1; j > 0; j >>= 1) {
                     for (int i = tid; i < P; i += NT) {
@@ -662,9 +668,9 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
             }
         for (int r = tid; r < Kp; r += NT) {
             rk[r] = inplace ? lagk[r] : (uint16_t)r;
-            if (d.dbg.lag) { d.dbg.lag[r] = lagk[r]; d.dbg.corval[r] = keyv[r]; }   // (debug seam always sorts)
+            if (dbg.lag) { dbg.lag[r] = lagk[r]; dbg.corval[r] = keyv[r]; }   // (debug seam always sorts)
         }
-        if (tid == 0 && d.dbg.n_ranked) *d.dbg.n_ranked = Kp;
+        if (tid == 0 && dbg.n_ranked) *dbg.n_ranked = Kp;
         ESYNC();
         }
 
@@ -684,7 +690,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
         // same order, same `>=` rule.  A chunk first walks back over the run of pairing cells that ends just
         // before it and replays the recurrence over that run (zero cells reset it, so nothing older matters).
         // (negative weights or the forced-FFT test mode take the cell-by-cell form below)
-        const bool ws_masks = d.gc >= 0.0 && d.au >= 0.0 && d.gu >= 0.0 && !d.force_fft;
+        const bool ws_masks = PROD || (d.gc >= 0.0 && d.au >= 0.0 && d.gu >= 0.0 && !force_fft);
         if (ws_masks) {
             // forward masks F[0..3] = A,C,G,U, F[4] = contiguity with the previous position; R[] = reversed strings.
             // Region A: behind the lag values (8 P bytes) unless those were sorted in place and are dead; the
@@ -694,12 +700,12 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
             unsigned long long *R = F + 5 * W;
             parts = (WsPart *)(R + 5 * W);
             if (LONGSEQ != 2 && (!mw || inplace))   // (the direct correlation on multi-word masks has built them already - behind the lag values)
-            for (int rep_ = 0; rep_ < 1 + ((d.rep >> 7) & 1); rep_++) {
+            for (int rep_ = 0; rep_ < 1 + ((rep >> 7) & 1); rep_++) {
                 build_masks<NT>(F, R, W, n, code, pos, tid);
                 ESYNC();
             }
             auto window = [&](const unsigned long long *X, int start) -> unsigned long long { return mask_window(X, W, start); };
-            for (int rep_ = 0; rep_ < 1 + ((d.rep >> 2) & 1); rep_++) {
+            for (int rep_ = 0; rep_ < 1 + ((rep >> 2) & 1); rep_++) {
             for (int q = tid; q < Kp * C; q += NT) {
                 const int r = q / C, c = q - r * C;
                 const int lagp = rk[r];
@@ -773,7 +779,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                 }
                 if (C == 1) {
                     wnb[r] = (uint16_t)mx_nb; wmi[r] = (uint16_t)mx_i; wmj[r] = (uint16_t)mx_j;
-                    if (d.dbg.nb) { d.dbg.nb[r] = mx_nb; d.dbg.mi[r] = mx_i; d.dbg.mj[r] = mx_j; d.dbg.score[r] = mx_s; }
+                    if (dbg.nb) { dbg.nb[r] = mx_nb; dbg.mi[r] = mx_i; dbg.mj[r] = mx_j; dbg.score[r] = mx_s; }
                 } else {
                     WsPart wp; wp.score = mx_s; wp.nb = mx_nb; wp.mi = mx_i; wp.mj = mx_j; wp.any = ipe > ipa ? 1 : 0;
                     parts[q] = wp;
@@ -789,12 +795,12 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                         if (wp.any && wp.score >= mx_s) { mx_s = wp.score; mx_nb = wp.nb; mx_i = wp.mi; mx_j = wp.mj; }
                     }
                     wnb[r] = (uint16_t)mx_nb; wmi[r] = (uint16_t)mx_i; wmj[r] = (uint16_t)mx_j;
-                    if (d.dbg.nb) { d.dbg.nb[r] = mx_nb; d.dbg.mi[r] = mx_i; d.dbg.mj[r] = mx_j; d.dbg.score[r] = mx_s; }
+                    if (dbg.nb) { dbg.nb[r] = mx_nb; dbg.mi[r] = mx_i; dbg.mj[r] = mx_j; dbg.score[r] = mx_s; }
                 }
             }
             }
         } else
-        for (int rep_ = 0; rep_ < 1 + ((d.rep >> 2) & 1); rep_++) {
+        for (int rep_ = 0; rep_ < 1 + ((rep >> 2) & 1); rep_++) {
             for (int q = tid; q < Kp * C; q += NT) {
                 const int r = q / C, c = q - r * C;
                 const int lagp = rk[r];
@@ -819,7 +825,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                 }
                 if (C == 1) {
                     wnb[r] = (uint16_t)mx_nb; wmi[r] = (uint16_t)mx_i; wmj[r] = (uint16_t)mx_j;
-                    if (d.dbg.nb) { d.dbg.nb[r] = mx_nb; d.dbg.mi[r] = mx_i; d.dbg.mj[r] = mx_j; d.dbg.score[r] = mx_s; }
+                    if (dbg.nb) { dbg.nb[r] = mx_nb; dbg.mi[r] = mx_i; dbg.mj[r] = mx_j; dbg.score[r] = mx_s; }
                 } else {
                     WsPart w; w.score = mx_s; w.nb = mx_nb; w.mi = mx_i; w.mj = mx_j; w.any = any;
                     parts[q] = w;
@@ -835,7 +841,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                         if (w.any && w.score >= mx_s) { mx_s = w.score; mx_nb = w.nb; mx_i = w.mi; mx_j = w.mj; }
                     }
                     wnb[r] = (uint16_t)mx_nb; wmi[r] = (uint16_t)mx_i; wmj[r] = (uint16_t)mx_j;
-                    if (d.dbg.nb) { d.dbg.nb[r] = mx_nb; d.dbg.mi[r] = mx_i; d.dbg.mj[r] = mx_j; d.dbg.score[r] = mx_s; }
+                    if (dbg.nb) { dbg.nb[r] = mx_nb; dbg.mi[r] = mx_i; dbg.mj[r] = mx_j; dbg.score[r] = mx_s; }
                 }
             }
         }
@@ -874,10 +880,11 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
             if (tid == 0) { pe_ext[nbr] = c_e; pe_ml[nbr] = c_m; psp[nbr] = (uint16_t)c_s; }
         }
         ESYNC();
+        FSTAMP(10);  // (dE: branch prefix sums)
         const BrPrefix pf{pe_ext, pe_ml, psp};
         const BrList all_br{brl, 0, nbr, 0, 0, 0, 0, 0};
         const int e_old = loop_energy_pre(T, B, Sl, L, ci, cj, all_br, pf);      // the loop as it is (same for every stem)
-        for (int rep_ = 0; rep_ < 1 + ((d.rep >> 3) & 1); rep_++)
+        for (int rep_ = 0; rep_ < 1 + ((rep >> 3) & 1); rep_++)
             for (int r = tid; r < Kp; r += NT) {
                 const int nb = wnb[r];
                 keep[r] = 0;
@@ -909,12 +916,13 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                     dd[r] = ddc;
                     const double dE = dcal_to_energy(par_dcal + ddc) - par_e;
                     keep[r] = (dE < d.min_nrj) ? 1 : 0;
-                    if (d.dbg.ddcal) d.dbg.ddcal[r] = ddc;
-                } else if (d.dbg.ddcal)
-                    d.dbg.ddcal[r] = INT_MIN;
+                    if (dbg.ddcal) dbg.ddcal[r] = ddc;
+                } else if (dbg.ddcal)
+                    dbg.ddcal[r] = INT_MIN;
             }
         ESYNC();
 
+        FSTAMP(11);  // (dE: the loop as it is + every candidate)
         ESTAMP(6);   // dE
         // ---- stable sort of the kept candidates by dE (ties keep lag-rank order), emit
         // compact the kept lags (keep[] becomes the list of their indices)
@@ -943,12 +951,13 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
             }
             ESYNC();
         }
+        FSTAMP(12);  // (emit: compaction)
         if (tid == 0) {
             unsigned long long base = 0;
             misc[2] = 0;
             if (nkept) {
                 if ((unsigned)nkept > slab_left) {      // reserve a new slab of candidate slots (the rest of the old one is dropped)
-                    const unsigned slab = d.cand_shard_cap >= 4096 ? 64u : 16u;
+                    const unsigned slab = d.cand_shard_cap >= 64u * (unsigned)d.cand_slab ? (unsigned)d.cand_slab : 16u;
                     const unsigned want = (unsigned)nkept > slab ? (unsigned)nkept : slab;
                     unsigned long long b0 = atomicAdd(&d.c->cand[shard].v, (unsigned long long)want);
                     if (b0 + want > d.cand_shard_cap) { atomicOr(&d.c->overflow, OVF_CAND); misc[2] = 1; slab_left = 0; }
@@ -960,10 +969,11 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
             st_items++; st_n += n; st_lags += Kp; st_nbr += nbr;
         }
         ESYNC();
+        FSTAMP(13);  // (emit: candidate slots)
         const unsigned long long cbase = *(unsigned long long *)&misc[4];
         const bool ovf = misc[2] != 0;
         if (!ovf)
-        for (int rep_ = 0; rep_ < 1 + ((d.rep >> 6) & 1); rep_++) {
+        for (int rep_ = 0; rep_ < 1 + ((rep >> 6) & 1); rep_++) {
             // packed sort key of every kept candidate: (dE biased to unsigned) << 32 | lag rank.  (They take the place of
             // the branch prefix sums in region A, which dE is done with: 8 * Kp bytes behind the lag values.)
             unsigned long long *ck = (unsigned long long *)(lds + lay.offA + (inplace ? 0 : 8 * Pk));
@@ -992,6 +1002,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                             rank += ky < kx ? 1 : 0;
                     }
                 }
+                FSTAMP(14);  // (emit: sort keys, rank)
                 int mi = wmi[r], mj = wmj[r], nb = wnb[r];
                 uint64_t h1 = 0, h2 = 0;
                 for (int t = 0; t < nb; t++) {
@@ -1004,29 +1015,32 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                 cd.set_cuts(br_lower(brl, nbr, pos[mi]), br_lower(brl, nbr, pos[mj]), br_lower(brl, nbr, pos[mi - nb + 1]), br_lower(brl, nbr, pos[mj + nb - 1]));
                 cd.h1 = h1; cd.h2 = h2;
                 if (!dry) d.cand[cbase + rank] = cd;
-                if (d.dbg.kept) d.dbg.kept[rank] = r;
+                if (dbg.kept) dbg.kept[rank] = r;
             }
         }
         if (tid == 0 && !dry) {
             d.nd[nid].cand = cbase;
             d.nd[nid].ncand = ovf ? 0 : nkept;
-            if (d.dbg.n_ranked) d.dbg.n_ranked[1] = nkept;
+            if (dbg.n_ranked) dbg.n_ranked[1] = nkept;
         }
+        FSTAMP(15);  // (emit: pair hashes, cuts, stores)
         ESTAMP(7);   // emit
-        if (NT == 64 && d.prof_e != nullptr) {         // diagnostic: regions without any candidate stem / without a kept one, by size
+        if (NT == 64 && prof_e != nullptr) {         // diagnostic: regions without any candidate stem / without a kept one, by size
             int has = 0;
             for (int r = tid; r < Kp; r += NT) has |= wnb[r] > 0 ? 1 : 0;
             const bool anystem = __ballot(has) != 0ULL;
-            if (tid == 0 && !anystem) atomicAdd(&d.prof_e[cls * PROF_E + 80 + size_bk], 1ULL);
-            if (tid == 0 && nkept == 0) atomicAdd(&d.prof_e[cls * PROF_E + 88 + size_bk], 1ULL);
+            if (tid == 0 && !anystem) atomicAdd(&prof_e[cls * PROF_E + 80 + size_bk], 1ULL);
+            if (tid == 0 && nkept == 0) atomicAdd(&prof_e[cls * PROF_E + 88 + size_bk], 1ULL);
         }
-        if (eprof) { atomicAdd(&d.prof_e[cls * PROF_E + 8 + size_bk], 1ULL); atomicAdd(&d.prof_e[cls * PROF_E + 16 + size_bk], (unsigned long long)(clock64() - t_region0)); }
+        if (eprof) { atomicAdd(&prof_e[cls * PROF_E + 8 + size_bk], 1ULL); atomicAdd(&prof_e[cls * PROF_E + 16 + size_bk], (unsigned long long)(clock64() - t_region0)); }
     }
     if (eprof) {
-        for (int k = 0; k < 8; k++) atomicAdd(&d.prof_e[cls * PROF_E + k], eacc[k]);
-        atomicAdd(&d.prof_e[cls * PROF_E + 40], eacc[8]); atomicAdd(&d.prof_e[cls * PROF_E + 41], eacc[9]);
+        for (int k = 0; k < 8; k++) atomicAdd(&prof_e[cls * PROF_E + k], eacc[k]);
+        atomicAdd(&prof_e[cls * PROF_E + 40], eacc[8]); atomicAdd(&prof_e[cls * PROF_E + 41], eacc[9]);
+        for (int k = 10; k < 16; k++) atomicAdd(&prof_e[cls * PROF_E + 32 + k], eacc[k]);
     }
 #undef ESTAMP
+#undef FSTAMP
     if (tid == 0 && st_items) {
         Counters::StatLine *sl = &d.c->xstat[cls][gteam & (NSHARD - 1)];
         atomicAdd(&sl->items, st_items);
