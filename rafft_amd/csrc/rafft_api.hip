@@ -287,7 +287,7 @@ int class_cfg(int K, int maxL, ClsCfg out[NGEN], bool nofft1 = false, bool nofft
     return 0;
 }
 
-template <int NT, bool TAB, int WPB = 1, int LONGSEQ = 0, bool PROD = false>
+template <int NT, bool TAB, int WPB = 1, int LONGSEQ = 0, int PROD = 0>
 int launch_expand(const Dev &d, int cls, const ClsCfg &cf, unsigned n_teams, hipStream_t st)
 {
     static int lds_set = 0;
@@ -305,7 +305,7 @@ int launch_expand_cls(const Dev &d, int cls, const ClsCfg cf[NGEN], unsigned n_b
 {
     if (cls >= NGEN) {        // small regions: teams of 16 / 32 lanes, four wavefronts per workgroup (n_blocks = workgroups)
         const int arg = cls | ((getenv("RAFFT_SMALL_DIAG") ? atoi(getenv("RAFFT_SMALL_DIAG")) : 0) << 8);
-        static const bool prod_ok = !(getenv("RAFFT_PROD") && atoi(getenv("RAFFT_PROD")) == 0);
+        const bool prod_ok = !(getenv("RAFFT_PROD") && atoi(getenv("RAFFT_PROD")) == 0);      // (read at every launch: tests switch it)
         const bool prod = prod_ok && arg == cls && d.prof_e == nullptr && d.dbg.lag == nullptr;      // no diagnostics asked for: the production build
         if (cls == 4 && prod) hipLaunchKernelGGL((expand_small_kernel<16, true>), dim3(n_blocks), dim3(64 * SM_WG_WAVES), small_lds_bytes<16>(), st, d, arg);
         else if (cls == 4) hipLaunchKernelGGL((expand_small_kernel<16, false>), dim3(n_blocks), dim3(64 * SM_WG_WAVES), small_lds_bytes<16>(), st, d, arg);
@@ -315,25 +315,27 @@ int launch_expand_cls(const Dev &d, int cls, const ClsCfg cf[NGEN], unsigned n_b
         return 0;
     }
     const bool longseq = cf[2].Lmax == 0;          // (class_cfg: no LDS copy of the bases)
-    if (cls == 0) return launch_expand<512, false, 1, 2>(d, 0, cf[0], n_blocks, st);
     const int nf = cls < NGEN && cf[cls].nofft ? 0x2000 : 0;
     // the production build of the classes without FFT buffers: no diagnostics of any kind asked for (RAFFT_PROD=0: the general build)
-    static const bool prod_ok = !(getenv("RAFFT_PROD") && atoi(getenv("RAFFT_PROD")) == 0);
-    const bool prod = prod_ok && nf && !dry && d.prof_e == nullptr && d.rep == 0 && d.dbg.lag == nullptr && !d.force_fft;
-    if (longseq && cls == 2 && cf[2].nt == 256) return launch_expand<256, false, 1, 1>(d, 2 | nf, cf[2], n_blocks, st);
-    if (longseq && cls >= 2) return launch_expand<512, false, 1, 1>(d, cls | nf, cf[cls], n_blocks, st);
+    const bool prod_ok = !(getenv("RAFFT_PROD") && atoi(getenv("RAFFT_PROD")) == 0);      // (read at every launch: tests switch it)
+    const bool nodiag = prod_ok && !dry && d.prof_e == nullptr && d.rep == 0 && d.dbg.lag == nullptr && !d.force_fft && d.gc >= 0.0 && d.au >= 0.0 && d.gu >= 0.0;
+    const bool prod = nodiag && nf;
+    if (cls == 0) return nodiag ? launch_expand<512, false, 1, 2, 2>(d, 0, cf[0], n_blocks, st) : launch_expand<512, false, 1, 2>(d, 0, cf[0], n_blocks, st);
+    if (longseq && cls == 2 && cf[2].nt == 256) return prod ? launch_expand<256, false, 1, 1, 1>(d, 2 | nf, cf[2], n_blocks, st) : launch_expand<256, false, 1, 1>(d, 2 | nf, cf[2], n_blocks, st);
+    if (longseq && cls >= 2) return nodiag && !nf ? launch_expand<512, false, 1, 1, 2>(d, cls, cf[cls], n_blocks, st) : launch_expand<512, false, 1, 1>(d, cls | nf, cf[cls], n_blocks, st);
     if (cls == 1) {
         if (cf[1].wpb == 4) return launch_expand<64, true, 4>(d, 1, cf[1], n_blocks, st);
-        if (cf[1].wpb == 16 && prod) return launch_expand<64, true, 16, 0, true>(d, 1 | nf, cf[1], n_blocks, st);
+        if (cf[1].wpb == 16 && prod) return launch_expand<64, true, 16, 0, 1>(d, 1 | nf, cf[1], n_blocks, st);
         if (cf[1].wpb == 16) return launch_expand<64, true, 16>(d, 1 | (cf[1].nofft ? 0x2000 : 0), cf[1], n_blocks, st);
         if (cf[1].wpb == 12) return launch_expand<64, true, 12>(d, (dry ? (0x101 | (std::max(0, atoi(getenv("RAFFT_TWICE")) - 2) << 9)) : 1) | (cf[1].nofft ? 0x2000 : 0), cf[1], n_blocks, st);
         return cf[1].tab ? launch_expand<64, true>(d, 1, cf[1], n_blocks, st) : launch_expand<64, false>(d, 1, cf[1], n_blocks, st);
     }
     if (cls == 2) {
         if (cf[2].nt == 512) return cf[2].tab ? launch_expand<512, true>(d, 2 | nf, cf[2], n_blocks, st) : launch_expand<512, false>(d, 2 | nf, cf[2], n_blocks, st);
-        if (prod && !cf[2].tab) return launch_expand<256, false, 1, 0, true>(d, 2 | nf, cf[2], n_blocks, st);
+        if (prod && !cf[2].tab) return launch_expand<256, false, 1, 0, 1>(d, 2 | nf, cf[2], n_blocks, st);
         return cf[2].tab ? launch_expand<256, true>(d, 2 | nf, cf[2], n_blocks, st) : launch_expand<256, false>(d, 2 | nf, cf[2], n_blocks, st);
     }
+    if (nodiag && !cf[3].tab) return launch_expand<512, false, 1, 0, 2>(d, 3, cf[3], n_blocks, st);
     return cf[3].tab ? launch_expand<512, true>(d, 3, cf[3], n_blocks, st) : launch_expand<512, false>(d, 3, cf[3], n_blocks, st);
 }
 

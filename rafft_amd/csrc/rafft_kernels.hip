@@ -190,6 +190,9 @@ __device__ inline unsigned fetch_chunk(const Dev &d, int cls, unsigned n_items, 
 }
 static_assert(NSHARD == 64, "fetch_chunk reads one work cursor per lane");
 
+#ifndef RAFFT_EXPAND256_PROD_WAVES
+#define RAFFT_EXPAND256_PROD_WAVES 4
+#endif
 #ifndef RAFFT_EXPAND64_WAVES
 #define RAFFT_EXPAND64_WAVES 3        // <= 168 VGPRs (12 B/lane of scratch): its LDS allows three wavefronts per SIMD anyway; a cap of 128 spilled 152 B/lane
 #endif
@@ -213,8 +216,9 @@ __device__ __forceinline__ void wave_sync()
 //              per-workgroup scratch in HBM instead of LDS.  Same integer pair counts, same fp64 values, same ranking.
 // PROD: the production build of a class without FFT buffers (no seam, no forced FFT, no negative weights, no diagnostics): the
 // debug-seam stores, the phase stamps, the FFT and the cell-by-cell window_slide are compiled out - fewer live registers, fewer spills.
-template <int NT, bool TAB_LDS, int WPB, int LONGSEQ = 0, bool PROD = false>
-__global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND64_WAVES) : NT == 256 ? 3 : 2)) void expand_kernel(Dev d, int cls_arg, int Pmax, int Lmax, int nmax, int brmax, int Kmax)
+// PROD 2: the same for a class that keeps its FFT (regions beyond Dev::direct_n positions): only the diagnostics go.
+template <int NT, bool TAB_LDS, int WPB, int LONGSEQ = 0, int PROD = 0>
+__global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND64_WAVES) : NT == 256 ? (PROD == 1 ? RAFFT_EXPAND256_PROD_WAVES : 3) : 2)) void expand_kernel(Dev d, int cls_arg, int Pmax, int Lmax, int nmax, int brmax, int Kmax)
 {
     const int cls = cls_arg & 0xFF;
     const DebugOut dbg = PROD ? DebugOut{} : d.dbg;
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
     static_assert(WPB == 1 || NT == 64, "only the one-wavefront class packs several wavefronts into a workgroup");
     static_assert(LONGSEQ == 0 || NT > 64, "long sequences never reach the one-wavefront class");
     extern __shared__ __align__(16) unsigned char lds_all[];
-    const bool nofft = PROD || (cls_arg & 0x2000) != 0;   // the host promises: no seam, no forced FFT, no negative weights, every region within Dev::direct_n
+    const bool nofft = PROD == 1 || (cls_arg & 0x2000) != 0;   // the host promises: no seam, no forced FFT, no negative weights, every region within Dev::direct_n
     const ExpandLds lay = expand_lds(Pmax, Lmax, nmax, brmax, Kmax, TAB_LDS, WPB, nofft, NT);
     const int tid = threadIdx.x % NT;                 // position inside this region's team (a wavefront / the workgroup)
     const int team = threadIdx.x / NT;                // wavefront of the workgroup (0 when the workgroup is the team)

@@ -19,14 +19,17 @@ def as_lists(traj):
     return [[[s.str_struct, s.dcal] for s in st] for st in traj]
 
 
-@pytest.fixture(autouse=True, params=["classes_by_size", "classes_merged"])
+@pytest.fixture(autouse=True, params=["classes_by_size", "classes_merged", "general_builds"])
 def expand_class_routing(request, monkeypatch):
     """Steps with few new structures send all their regions to one wide expand kernel (the tail of a big batch;
     every step of the small batches in this file).  Each test runs both ways, so that the one-wavefront kernel
-    (popcount correlation, bit-mask window_slide) and the wide kernels see the same cases."""
-    if request.param == "classes_by_size":
+    (popcount correlation, bit-mask window_slide) and the wide kernels see the same cases - and a third time with the
+    general builds of the expand kernels (diagnostics, seam and FFT paths compiled in) instead of the production builds."""
+    if request.param in ("classes_by_size", "general_builds"):
         monkeypatch.setenv("RAFFT_MERGE_BELOW", "0")
         monkeypatch.setenv("RAFFT_MERGE2_BELOW", "0")
+    if request.param == "general_builds":
+        monkeypatch.setenv("RAFFT_PROD", "0")
     yield
 
 
