@@ -803,8 +803,14 @@ int Wave::issue_step()
         SPAN_REC(sp.a, st, sp.kind);
         // few sequences left (the long ones): a 1024-thread workgroup per sequence shortens the serial
         // chains (16 wavefronts for the prepass, 1024 combos per chunk); many sequences: 256 threads
-        if (n_active < wide_below) hipLaunchKernelGGL(beam_step_kernel<1024>, dim3((unsigned)S), dim3(1024), bs_lds[1], st, d, c.sort_cap);
-        else hipLaunchKernelGGL(beam_step_kernel<256>, dim3((unsigned)S), dim3(256), bs_lds[0], st, d, c.sort_cap);
+        const bool bs_prod = d.prof == nullptr && d.prof_ws == nullptr;          // no diagnostic stamps asked for: the production builds
+        if (n_active < wide_below) {
+            if (bs_prod) hipLaunchKernelGGL((beam_step_kernel<1024, true>), dim3((unsigned)S), dim3(1024), bs_lds[1], st, d, c.sort_cap);
+            else hipLaunchKernelGGL((beam_step_kernel<1024, false>), dim3((unsigned)S), dim3(1024), bs_lds[1], st, d, c.sort_cap);
+        } else {
+            if (bs_prod) hipLaunchKernelGGL((beam_step_kernel<256, true>), dim3((unsigned)S), dim3(256), bs_lds[0], st, d, c.sort_cap);
+            else hipLaunchKernelGGL((beam_step_kernel<256, false>), dim3((unsigned)S), dim3(256), bs_lds[0], st, d, c.sort_cap);
+        }
         HIPCHK(hipGetLastError());
         SPAN_REC(sp.b, st, sp.kind);
         spans.push_back(sp);
@@ -839,7 +845,8 @@ int Wave::after_beam()
     {
         Span sp{next_event(), next_event(), 2};
         SPAN_REC(sp.a, st, sp.kind);
-        hipLaunchKernelGGL(materialize_kernel, dim3(hc.n_mat), dim3(MAT_NT), mat_lds, st, d);
+        if (d.prof_e == nullptr) hipLaunchKernelGGL(materialize_kernel<true>, dim3(hc.n_mat), dim3(MAT_NT), mat_lds, st, d);
+        else hipLaunchKernelGGL(materialize_kernel<false>, dim3(hc.n_mat), dim3(MAT_NT), mat_lds, st, d);
         HIPCHK(hipGetLastError());
         // tail of the batch: so few new structures that their regions fit one wave of workgroups of the widest class
         // (measured on the benchmark batch: 18.8 -> 17.3 ms; thresholds in new structures per step, per CU)

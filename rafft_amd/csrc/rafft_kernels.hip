@@ -1111,7 +1111,7 @@ __device__ __forceinline__ unsigned long long sat_mul(unsigned long long a, unsi
 }
 
 // LDS: sort keys (dynamic) + product description + per-parent prepass records
-template <int BS_NT>
+template <int BS_NT, bool PROD = false>      // (PROD: the diagnostic stamps compiled out - see expand_kernel)
 __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
 {
     extern __shared__ __align__(16) unsigned char lds[];
@@ -1136,12 +1136,13 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
     if (sq == 0) for (int i = tid; i < NCLS * NSHARD; i += BS_NT) d.c->wcur[i / NSHARD][i % NSHARD].v = 0;
     if (sq == 0 && tid < NCLS) d.c->wdone[tid] = 0;
     if (d.done[sq]) return;
-    const bool prof = d.prof && sq == d.prof_seq && tid == 0;   // diagnostic stamps (RAFFT_TRACE=3)
+    const bool prof = !PROD && d.prof && sq == d.prof_seq && tid == 0;   // diagnostic stamps (RAFFT_TRACE=3)
     unsigned long long tprev = prof ? clock64() : 0;
-    const unsigned long long t_begin = d.prof_ws ? clock64() : 0;
+    unsigned long long *const prof_ws = PROD ? nullptr : d.prof_ws;
+    const unsigned long long t_begin = prof_ws ? clock64() : 0;
     unsigned long long n_chunks = 0, n_par = 0, n_combos = 0;
-#define WS_END() do { if (d.prof_ws && tid == 0) { unsigned long long dt_ = clock64() - t_begin; d.prof_ws[3 * sq] += dt_; d.prof_ws[3 * sq + 1] += n_chunks | (n_combos << 24); \
-        d.prof_ws[3 * sq + 2] += n_par; } } while (0)
+#define WS_END() do { if (prof_ws && tid == 0) { unsigned long long dt_ = clock64() - t_begin; prof_ws[3 * sq] += dt_; prof_ws[3 * sq + 1] += n_chunks | (n_combos << 24); \
+        prof_ws[3 * sq + 2] += n_par; } } while (0)
 #define STAMP(k) do { if (prof) { unsigned long long tn_ = clock64(); d.prof[k] += tn_ - tprev; tprev = tn_; } } while (0)
     const int nbeam = d.beam_n[sq];
     int *beam = d.beam + (size_t)sq * d.B;
@@ -1676,6 +1677,7 @@ __device__ inline MatDesc mat_describe(const Dev &d, int pn, int selk)
 #endif
 // (dynamic LDS: the dot-bracket staging row, sized for the longest sequence of the wave - a latency-bound kernel of
 //  one-wavefront workgroups lives on the number of them a CU holds)
+template <bool PROD>      // (PROD: the phase stamps of RAFFT_TRACE=3 compiled out - see expand_kernel)
 __global__ __launch_bounds__(MAT_NT, RAFFT_MAT_WAVES) void materialize_kernel(Dev d)
 {
     extern __shared__ __align__(16) uint8_t mat_dyn[];
@@ -1692,7 +1694,7 @@ __global__ __launch_bounds__(MAT_NT, RAFFT_MAT_WAVES) void materialize_kernel(De
     __shared__ int shi[8];
     const int tid = threadIdx.x;
     // diagnostic phase stamps (RAFFT_TRACE=3) of every 64th workgroup, kept in the slots of class 0
-    const bool mprof = d.prof_e != nullptr && tid == 0 && (blockIdx.x & 63) == 0;
+    const bool mprof = !PROD && d.prof_e != nullptr && tid == 0 && (blockIdx.x & 63) == 0;
     unsigned long long mt = mprof ? clock64() : 0, macc[7] = {0, 0, 0, 0, 0, 0, 0};
 #define MSTAMP(k) do { if (mprof) { const unsigned long long tn_ = clock64(); macc[k] += tn_ - mt; mt = tn_; } } while (0)
     const MatRec rec = d.mat[blockIdx.x];              // written by the beam step: no chain of look-ups to get started
