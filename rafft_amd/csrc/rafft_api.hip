@@ -59,7 +59,7 @@ struct Workspace {
     hipStream_t stream = nullptr;
     hipStream_t cls_stream[NCLS] = {};
     hipStream_t copy_stream = nullptr;   // result rows of sequences that finish early leave while the others still fold
-    hipEvent_t ev_fork = nullptr, ev_join[NCLS] = {}, ev_hot = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join[NCLS] = {}, ev_hot = nullptr, ev_copy = nullptr;
     void *hot = nullptr;                 // pinned, 512 B
     // named device buffers (grow-only)
     Buf codes, seq_off, seq_len, beam, beam_n, done, nsteps, ch_parent, ch_combo, ch_dcal, ch_h, seen, seen_off,
@@ -186,6 +186,7 @@ int init_ws(Workspace &w)
     }
     HIPCHK(hipStreamCreateWithFlags(&w.copy_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&w.ev_copy, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&w.ev_hot, hipEventDisableTiming | hipEventBlockingSync));   // (the scheduler sleeps on it when it has spun long enough)
     static_assert(offsetof(Counters, node) <= 512, "hot counters must fit the pinned read-back slot");
     HIPCHK(hipHostMalloc(&w.hot, 512, hipHostMallocDefault));
@@ -418,7 +419,7 @@ Caps plan_caps(size_t S, size_t sumL, const rafft_params &p, double est)
 }
 
 static size_t merge_cap();
-struct SeqIn { const char *s; int len; int idx; int bi; };   // bi: which member batch of the job the sequence belongs to
+struct SeqIn { const char *s; int len; int idx; int bi; const uint8_t *c = nullptr; };   // bi: which member batch of the job the sequence belongs to; c: the bases as codes (encoded at submit, on the caller's thread), or null
 
 struct HostOut {   // owner of a rafft_result
     std::vector<rafft_seq_result> seq;
@@ -485,6 +486,7 @@ struct Batch {
     rafft_params p;
     int n_seq = 0;
     std::vector<char> seqbuf;                 // the caller's sequences, copied at submit
+    std::vector<uint8_t> codebuf;             // ... and as base codes, same offsets
     HostOut *ho = nullptr;
     std::deque<Job> lane[2];                  // as submitted; the scheduler moves them to its own queues
     int pending = 0;                          // jobs (queued or running) that still hold sequences of this batch
@@ -533,6 +535,11 @@ struct Wave {
     bool finished = false;
     long long last_rows_bytes = 0;
     std::vector<OutRec> early_recs, late_recs;
+    PinBuf stage{};               // pinned staging of the wave's inputs (setup)
+    bool draining = false;        // every step is done, the last rows are on their way to the host (finish): ready() tells when they have landed
+    double tl_stats_ = 0, tl_gather_ = 0, ms_loop_ = 0;
+    std::chrono::steady_clock::time_point tw2_;
+    ~Wave() { pin_release(stage); }
     size_t harvested = 0;         // trajectory records whose rows already left through the copy stream (early harvest)
     int emit_rows(size_t first, size_t count, bool early, double *t_gather);
     int result = 0;               // valid when finished: 0, RAFFT_ERR_CAPACITY (regrow) or a hard error
@@ -564,6 +571,7 @@ struct Wave {
     std::chrono::steady_clock::time_point t_issued;      // when the running step was issued (the scheduler blocks on the oldest)
     int after_beam();
     int finish();
+    int finish_done();
 };
 
 int Wave::setup()
@@ -575,12 +583,25 @@ int Wave::setup()
     off.resize(S); len.resize(S);
     sumL = 0;
     for (size_t i = 0; i < S; i++) { off[i] = (int)sumL; len[i] = seqs[i].len; sumL += seqs[i].len; }
-    std::vector<uint8_t> codes(sumL + 16, 0);
+    // the wave's inputs are staged in a pinned chunk (codes | offsets | lengths | counters image): the uploads below are truly
+    // asynchronous and the scheduler thread goes on to the other waves' steps at once (it used to wait here, 0.6-0.7 ms per
+    // wave of five batches); the chunk goes back to the pool with the wave
+    const size_t st_codes = 0, st_off = (sumL + 16 + 63) & ~(size_t)63, st_len = st_off + ((S * 4 + 63) & ~(size_t)63),
+                 st_ctr = st_len + ((S * 4 + 63) & ~(size_t)63), st_bytes = st_ctr + sizeof(Counters);
+    stage = pin_acquire(st_bytes);
+    if (!stage.p) return fail(RAFFT_ERR_HIP, "hipHostMalloc failed for the input staging buffer");
+    uint8_t *codes = (uint8_t *)stage.p + st_codes;
     for (size_t i = 0; i < S; i++) {
-        const unsigned char *src = (const unsigned char *)seqs[i].s;
-        uint8_t *dst = codes.data() + off[i];
-        for (int x = 0; x < seqs[i].len; x++) dst[x] = kBaseCode[src[x]] & 7;
+        uint8_t *dst = codes + off[i];
+        if (seqs[i].c) memcpy(dst, seqs[i].c, (size_t)seqs[i].len);          // (encoded at submit, on the caller's thread)
+        else {
+            const unsigned char *src = (const unsigned char *)seqs[i].s;
+            for (int x = 0; x < seqs[i].len; x++) dst[x] = kBaseCode[src[x]] & 7;
+        }
     }
+    memset(codes + sumL, 0, 16);
+    memcpy((char *)stage.p + st_off, off.data(), S * 4);
+    memcpy((char *)stage.p + st_len, len.data(), S * 4);
     const double ms_enc = since(tw0);
     int maxL = 0;
     for (size_t i = 0; i < S; i++) maxL = std::max(maxL, len[i]);
@@ -719,17 +740,18 @@ int Wave::setup()
 
     const double ms_plan = since(tw0);
     hipStream_t st = g.stream;
-    HIPCHK(hipMemcpyAsync(g.codes.p, codes.data(), sumL + 16, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(g.seq_off.p, off.data(), S * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(g.seq_len.p, len.data(), S * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(g.codes.p, codes, sumL + 16, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(g.seq_off.p, (char *)stage.p + st_off, S * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(g.seq_len.p, (char *)stage.p + st_len, S * 4, hipMemcpyHostToDevice, st));
     memset(&hc, 0, sizeof hc);
     hc.n_struct = S; hc.seen_top = S * (size_t)SEEN0;
-    HIPCHK(hipMemcpyAsync(g.counters.p, &hc, sizeof hc, hipMemcpyHostToDevice, st));
+    memcpy((char *)stage.p + st_ctr, &hc, sizeof hc);
+    HIPCHK(hipMemcpyAsync(g.counters.p, (char *)stage.p + st_ctr, sizeof hc, hipMemcpyHostToDevice, st));
     if (d.memo) HIPCHK(hipMemsetAsync(g.looptab.p, 0, c.looptab * 8, st));
     HIPCHK(hipMemsetAsync(g.seen.p, 0, S * (size_t)SEEN0 * 16, st));   // first region of every sequence; later regions are zeroed on allocation
     hipLaunchKernelGGL(init_roots_kernel, dim3((unsigned)S), dim3(64), 0, st, d);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));      // `codes` (host vector) must outlive the copy
+    if (seam) HIPCHK(hipStreamSynchronize(st));      // (the seam overwrites the root region with synchronous copies right after)
     // beam_step_kernel LDS: time-shared region 0 (walk scratch 24 B/thread, then sort keys), region list, per-member records
     for (int v = 0; v < 2; v++) {
         const size_t nt = v ? 1024 : 256;
@@ -828,6 +850,7 @@ int Wave::after_beam()
     const auto t_in = std::chrono::steady_clock::now();
     struct Acc { double &a; std::chrono::steady_clock::time_point t; ~Acc() { a += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); } } acc_{ms_after, t_in};
     hipStream_t st = g.stream;
+    if (draining) return finish_done();            // the last rows have landed
     const size_t hot_len = offsetof(Counters, node);
     memcpy(&hc, g.hot, hot_len);
     if (hc.overflow) { ovf = hc.overflow; return finish(); }
@@ -917,8 +940,8 @@ int Wave::emit_rows(size_t first, size_t count, bool early, double *t_gather)
     spans.push_back(sp);
     HIPCHK(hipMemcpyAsync(all_db, b_db.p, (size_t)tot_bytes, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(all_dcal, b_dc.p, nrows * 4, hipMemcpyDeviceToHost, st));
-    // `recs` was handed to an asynchronous copy from pageable memory: HIP stages such copies before returning
-    if (!early) HIPCHK(hipStreamSynchronize(st));
+    // `recs` was handed to an asynchronous copy from pageable memory: HIP stages such copies before returning.  Nobody waits
+    // here: the early rows are waited for at the end of the wave, the late ones by the scheduler's poll of Workspace::ev_hot (finish)
     // per-sequence views into the chunk (the pointers are only read by the caller after the call has returned)
     for (size_t r0 = 0; r0 < recs.size();) {
         const int i = trec[r0].x;
@@ -940,12 +963,16 @@ int Wave::emit_rows(size_t first, size_t count, bool early, double *t_gather)
     return 0;
 }
 
+// Every step is done.  The statistics are read back, the rows that have not left yet are formatted and sent to the host - and
+// the scheduler thread goes back to the other waves: it used to sit in a stream synchronize here for the 1-3 ms the rows of a
+// wave of five batches take (32 MB D2H), during which no other wave's step was read back or issued.  ready() / after_beam()
+// see the end of that copy through Workspace::ev_hot (finish_done).
 int Wave::finish()
 {
     hipStream_t st = g.stream;
     finished = true;
-    const double ms_loop = since(tw1);
-    auto tw2 = std::chrono::steady_clock::now();
+    const double ms_loop = ms_loop_ = since(tw1);
+    auto tw2 = tw2_ = std::chrono::steady_clock::now();
     bt.stats.n_steps = std::max<int64_t>(bt.stats.n_steps, steps);
     if (ovf && getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] wave S=%zu est %.1f overflowed (bits %u) after %d steps, %.1f ms\n", S, est, ovf, steps, since(tw0));
     if (ovf) {
@@ -1005,7 +1032,22 @@ int Wave::finish()
     double tl_gather = 0;
     if (int rc = emit_rows(harvested, (size_t)hc.trec_n - harvested, false, &tl_gather)) return rc;
     tl_gather += tl_stats;
-    if (harvested) HIPCHK(hipStreamSynchronize(g.copy_stream));
+    tl_stats_ = tl_stats; tl_gather_ = tl_gather;
+    if (harvested) {                                  // the early rows went through the copy stream: one event covers both
+        HIPCHK(hipEventRecord(g.ev_copy, g.copy_stream));
+        HIPCHK(hipStreamWaitEvent(st, g.ev_copy, 0));
+    }
+    HIPCHK(hipEventRecord(g.ev_hot, st));
+    finished = false; draining = true;
+    (void)ms_loop;
+    return 0;
+}
+
+int Wave::finish_done()
+{
+    finished = true;
+    const auto tw2 = tw2_;
+    const double ms_loop = ms_loop_, tl_stats = tl_stats_, tl_gather = tl_gather_;
     const double tl_copy = since(tw2);
     const long long tot_bytes = last_rows_bytes;
     if (d.prof_e) {
@@ -1573,6 +1615,7 @@ static int submit_locked(const rafft_params *p, int n_seq, const char *const *se
     size_t tot = 0;
     for (int i = 0; i < n_seq; i++) { L[i] = lens ? lens[i] : (int)strlen(seqs[i]); tot += (size_t)std::max(L[i], 0); }
     b.seqbuf.resize(tot + 1);
+    b.codebuf.resize(tot + 1);
     std::vector<SeqIn> good;
     size_t o = 0;
     for (int i = 0; i < n_seq; i++) {
@@ -1585,10 +1628,11 @@ static int submit_locked(const rafft_params *p, int n_seq, const char *const *se
         memcpy(dst, seqs[i], (size_t)L[i]);
         o += (size_t)L[i];
         unsigned bad = 0;
-        for (int x = 0; x < L[i]; x++) bad |= kBaseCode[(unsigned char)dst[x]];
+        uint8_t *cdst = b.codebuf.data() + (dst - b.seqbuf.data());
+        for (int x = 0; x < L[i]; x++) { const unsigned k = kBaseCode[(unsigned char)dst[x]]; bad |= k; cdst[x] = (uint8_t)(k & 7); }
         if (bad & 8) { sr.status = RAFFT_ERR_BAD_CHAR; continue; }
         if (L[i] > RAFFT_MAX_LEN) { sr.status = RAFFT_ERR_TOO_LONG; continue; }
-        good.push_back({dst, L[i], i, 0});
+        good.push_back({dst, L[i], i, 0, cdst});
     }
     // ---- lanes.  Folds are independent, so how the batch is cut cannot change any result.  The number of
     // folding steps of a wave is set by its longest sequence, and the steps that only the long ones still need
