@@ -631,10 +631,16 @@ int Wave::setup()
     Caps cr = c;
     if (S < merge_cap() && !seam) {
         // (a long-tail job has a few sequences per batch: sized once for 64 of them, whatever gets merged later)
-        Sr = S >= 256 ? std::min(merge_cap(), 5 * S) : std::max<size_t>(S, std::min<size_t>(64, 32 * S));
-        Caps big = plan_caps(Sr, (size_t)((double)sumL * (double)Sr / (double)S), p, est);
+        // bulk batches: for the merge cap itself (a stream of small batches is merged up to it whatever their size), or for five of
+        // them when that is too much
         static const double reserve_frac = getenv("RAFFT_RESERVE_FRAC") ? atof(getenv("RAFFT_RESERVE_FRAC")) : 0.10;
-        if (big.bytes <= (size_t)((double)::g.hbm_total * reserve_frac)) cr = big; else Sr = S;
+        const size_t tries[2] = {S >= 256 ? merge_cap() : std::max<size_t>(S, std::min<size_t>(64, 32 * S)), S >= 256 ? std::min(merge_cap(), 5 * S) : S};
+        Sr = S;
+        for (size_t want : tries) {
+            if (want <= S) continue;
+            Caps big = plan_caps(want, (size_t)((double)sumL * (double)want / (double)S), p, est);
+            if (big.bytes <= (size_t)((double)::g.hbm_total * reserve_frac)) { cr = big; Sr = want; break; }
+        }
     }
     reserve = (double)Sr / (double)S;
     const size_t sumLr = Sr == S ? sumL : (size_t)((double)sumL * (double)Sr / (double)S);
