@@ -131,6 +131,16 @@ int ensure(Buf &b, size_t bytes)
     size_t want = bytes + std::min<size_t>(bytes / (old_cap ? 2 : 8), (size_t)256 << 20) + 256;
     want = (want + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);      // whole 2 MiB fragments
     hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        // out of memory with replaced buffers still waiting for an idle moment to be freed: free them now (hipFree waits for the
+        // device - a stall, not a failure) and ask again, for what is needed without the head-room
+        (void)hipGetLastError();
+        std::vector<void *> junk;
+        { std::lock_guard<std::mutex> lk(g.gc_mu); junk.swap(g.garbage); }
+        for (void *q : junk) { hipError_t e2 = hipFree(q); (void)e2; }
+        want = (bytes + 256 + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+        e = hipMalloc(&b.p, want);
+    }
     {
         const unsigned long long us = (unsigned long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0_).count();
         g_dev_allocs++; g_dev_bytes += want;
