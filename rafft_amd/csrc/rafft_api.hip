@@ -110,6 +110,7 @@ struct Ctx {
     std::condition_variable qcv_sched, qcv_done;
     std::deque<std::shared_ptr<struct Batch>> submitted;
     int n_inflight = 0;                // batches submitted and not yet finished
+    std::chrono::steady_clock::time_point t_last_submit{};   // under qmu: when the last batch was queued (the scheduler lingers on a stream of them)
     bool sched_started = false;
     bool stop = false;                 // under qmu: the process is exiting (rafft_shutdown): the scheduler thread returns
     std::thread sched_thread;
@@ -1442,7 +1443,22 @@ static void scheduler_main()
         static const bool tail_slot = getenv("RAFFT_TAIL_SLOT") ? atoi(getenv("RAFFT_TAIL_SLOT")) != 0 : true;
         int n_lane[2] = {0, 0};
         for (int i = 0; i < MAX_PIPES; i++) if (slot[i].wave) n_lane[slot[i].lane]++;
+        // A caller that streams batches (two or more in flight) queues them microseconds apart: a bulk wave admitted the moment the
+        // first one arrives would fold that one alone and the second wave whatever came in the meantime - three waves one after the
+        // other (heavy phases do not overlap) where one merged wave would do.  So while submissions keep coming (the last one less
+        // than RAFFT_LINGER_US = 150 us ago) and the queue is below the merge cap, the bulk lane waits for them.  A lone synchronous
+        // call never lingers.
+        static const long linger_us = getenv("RAFFT_LINGER_US") ? atol(getenv("RAFFT_LINGER_US")) : 150;
+        bool linger = false;
+        if (linger_us > 0 && !queue[1].empty()) {
+            size_t queued = 0;
+            for (auto &j : queue[1]) queued += j.seqs.size();
+            std::lock_guard<std::mutex> lk(g.qmu);
+            linger = g.n_inflight >= 2 && queued < merge_cap() &&
+                     std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - g.t_last_submit).count() < linger_us;
+        }
         for (int ln = 0; ln < 2; ln++) {
+            if (ln == 1 && linger) break;
             while (!queue[ln].empty() && (tail_slot ? (ln == 0 ? n_lane[0] < 1 : n_lane[1] < max_waves && n_running < MAX_PIPES) : n_running < max_waves)) {
                 Job &front = queue[ln].front();
                 if (!strip_failed(front)) {                       // every member already failed elsewhere: nothing to fold
@@ -1521,6 +1537,7 @@ static void scheduler_main()
         // short while; after that it stops holding a core (below).
         const auto now = std::chrono::steady_clock::now();
         if (progressed) { last_progress = now; continue; }
+        if (linger) { std::this_thread::yield(); continue; }          // (at most linger_us: keep looking)
         static const long spin_us = getenv("RAFFT_SCHED_SPIN_US") ? atol(getenv("RAFFT_SCHED_SPIN_US")) : 200;
         if (std::chrono::duration_cast<std::chrono::microseconds>(now - last_progress).count() < spin_us) { std::this_thread::yield(); continue; }
         bool any_wave = false;
@@ -1696,6 +1713,7 @@ static int submit_locked(const rafft_params *p, int n_seq, const char *const *se
         std::lock_guard<std::mutex> lk(g.qmu);
         g.submitted.push_back(bp);
         g.n_inflight++;
+        g.t_last_submit = std::chrono::steady_clock::now();
     }
     g.qcv_sched.notify_one();
     *job_ = new rafft_job{bp};
