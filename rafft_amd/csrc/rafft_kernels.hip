@@ -60,6 +60,32 @@ __device__ inline int block_exscan(int v, int *scratch, int *tot)
     return base + x - v;
 }
 
+// The same for a 0/1 flag: a ballot and two bit counts instead of six shuffle steps per wavefront.
+template <int NT>
+__device__ inline int block_exscan_flag(int f, int *scratch, int *tot)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long bal = __ballot(f != 0);
+    const int pre = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));   // set bits below my lane
+    const int wtot = __popcll(bal);
+    (void)lane;
+    if (NT == 64) {
+        *tot = wtot;
+        return pre;
+    }
+    __syncthreads();
+    if (lane == 0) scratch[wv] = wtot;
+    __syncthreads();
+    int base = 0, t = 0;
+    for (int i = 0; i < NT / 64; i++) {
+        int s = scratch[i];
+        if (i < wv) base += s;
+        t += s;
+    }
+    *tot = t;
+    return base + pre;
+}
+
 // Exact top-K selection for a workgroup: moves the K smallest of the N DISTINCT 64-bit keys in LDS to
 // keys[0..K) (unordered).  Byte-wise radix select from the most significant byte: 8 passes over the
 // keys with a 256-bin LDS histogram instead of sorting all N.  `hist` needs 256 ints, `sh` 32 ints.
@@ -100,7 +126,7 @@ __device__ inline void select_smallest_inplace(unsigned long long *keys, int N, 
         unsigned long long key = 0;
         int f = 0;
         if (i < N) { key = keys[i]; f = key <= prefix ? 1 : 0; }
-        int tot, ex = block_exscan<NT>(f, sh, &tot);     // (barriers inside: all reads of this slab are done)
+        int tot, ex = block_exscan_flag<NT>(f, sh, &tot);     // (barriers inside: all reads of this slab are done)
         if (f) keys[outn + ex] = key;                     // outn + ex <= i: never clobbers an unread key
         outn += tot;
         __syncthreads();
@@ -615,9 +641,10 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                 unsigned long long u = 0;
                 int tie = 0;
                 if (i >= 0 && i < m) { u = ukey(i); tie = (u == prefix) ? 1 : 0; }
-                int ttot, tex = block_exscan<NT>(tie, shs, &ttot);
+                int ttot = 0, tex = 0;
+                if (!take_ge) tex = block_exscan_flag<NT>(tie, shs, &ttot);     // (the order among ties only matters when the cut falls inside them)
                 const int g = (i >= 0 && i < m) && (take_ge ? u >= prefix : (u > prefix || (tie && tie_run + tex < kk))) ? 1 : 0;
-                int gtot, gex = block_exscan<NT>(g, shs, &gtot);
+                int gtot, gex = block_exscan_flag<NT>(g, shs, &gtot);
                 if (g) rk[outn + gex] = (uint16_t)i;
                 outn += gtot; tie_run += ttot;
                 ESYNC();
@@ -1500,7 +1527,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
                         if (g1 == h1 && g2 == h2) isnew = 0;
                     }
             }
-            int tot, ex = block_exscan<BS_NT>(isnew, sh, &tot);
+            int tot, ex = block_exscan_flag<BS_NT>(isnew, sh, &tot);
             if (isnew) {
                 const int ci2 = nchild + ex;
                 if (ci2 < d.ch_cap) {
@@ -1558,7 +1585,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
     for (int base = 0; base < nnew; base += BS_NT) {
         int i = base + tid, f = 0;
         if (i < nnew) f = ((uint32_t)skey[i] < (uint32_t)nchild) ? 1 : 0;
-        int tot, ex = block_exscan<BS_NT>(f, sh, &tot);
+        int tot, ex = block_exscan_flag<BS_NT>(f, sh, &tot);
         (void)ex;
         nsurv_child += tot;
         __syncthreads();
@@ -1596,7 +1623,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
         int i = base + tid, f = 0;
         uint32_t ord = 0;
         if (i < nnew) { ord = (uint32_t)skey[i]; f = (ord < (uint32_t)nchild) ? 1 : 0; }
-        int tot, ex = block_exscan<BS_NT>(f, sh, &tot);
+        int tot, ex = block_exscan_flag<BS_NT>(f, sh, &tot);
         if (i < nnew) {
             if (f) {
                 int sid = sbase + run + ex;
