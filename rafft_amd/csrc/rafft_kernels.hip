@@ -1163,14 +1163,14 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
     if (sq == 0) for (int i = tid; i < NCLS * NSHARD; i += BS_NT) d.c->wcur[i / NSHARD][i % NSHARD].v = 0;
     if (sq == 0 && tid < NCLS) d.c->wdone[tid] = 0;
     if (d.done[sq]) return;
-    const bool prof = !PROD && d.prof && sq == d.prof_seq && tid == 0;   // diagnostic stamps (RAFFT_TRACE=3)
+    const bool prof = !PROD && d.prof && (d.prof_seq < 0 || sq == d.prof_seq) && tid == 0;   // diagnostic stamps (RAFFT_TRACE=3; RAFFT_PROF_SEQ=-1: summed over all sequences)
     unsigned long long tprev = prof ? clock64() : 0;
     unsigned long long *const prof_ws = PROD ? nullptr : d.prof_ws;
     const unsigned long long t_begin = prof_ws ? clock64() : 0;
     unsigned long long n_chunks = 0, n_par = 0, n_combos = 0;
 #define WS_END() do { if (prof_ws && tid == 0) { unsigned long long dt_ = clock64() - t_begin; prof_ws[3 * sq] += dt_; prof_ws[3 * sq + 1] += n_chunks | (n_combos << 24); \
         prof_ws[3 * sq + 2] += n_par; } } while (0)
-#define STAMP(k) do { if (prof) { unsigned long long tn_ = clock64(); d.prof[k] += tn_ - tprev; tprev = tn_; } } while (0)
+#define STAMP(k) do { if (prof) { unsigned long long tn_ = clock64(); atomicAdd(&d.prof[k], tn_ - tprev); tprev = tn_; } } while (0)
     const int nbeam = d.beam_n[sq];
     int *beam = d.beam + (size_t)sq * d.B;
     for (int i = tid; i < nbeam; i += BS_NT) oldbeam[i] = beam[i];
@@ -1653,7 +1653,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
     }
     if (tid == 0) d.beam_n[sq] = nnew;
     STAMP(4);
-    if (prof) d.prof[5] += 1;
+    if (prof) atomicAdd(&d.prof[5], 1ULL);
     WS_END();
 #undef WS_END
 #undef STAMP
