@@ -684,8 +684,9 @@ int Wave::setup()
     d.rl_cap = RL_CAP;
     longseq = maxL > LDS_SEQ;
     d.pos_packed = longseq ? 0 : 1;          // 12 bits of position leave room for the base code (Dev::pos_packed)
-    // 256 productive regions per structure (never above 64 on any BASELINE workload); the lists live in materialize_kernel's LDS,
-    // and with 1024 entries a CU holds 8 of its workgroups instead of ~24 (measured: 1.5 -> 2.3 ms per benchmark batch) - so the long
+    // 64 productive regions per structure (no BASELINE workload has more: the configs[3] shard - 3000 nt, ms=200 - folds without a
+    // regrowth); the lists live in materialize_kernel's LDS: with 256 entries a CU holds 19 of its workgroups instead of 20 at
+    // 86 VGPRs (measured: 68.4 -> 62.2 ms per 36 benchmark batches), with 1024 entries 8 (1.5 -> 2.3 ms per batch) - so the long
     // lists are for sequences beyond 4096 nt and for a wave that overflowed the short ones and is being folded again
     d.max_prod = (longseq || big_prod) ? MAX_PROD_LONG : MAX_PROD;
     if (const char *e = getenv("RAFFT_TEST_MAX_PROD")) if (!big_prod && !longseq) d.max_prod = std::max(1, std::min(atoi(e), MAX_PROD));   // test hook: short lists overflow early

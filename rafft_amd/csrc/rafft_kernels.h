@@ -172,7 +172,7 @@ struct Dev {
 #define BIG_BR 4095        // ... of the class for the biggest regions (the 12-bit cut points of a candidate)
 #define BIG_N 16384        // positions of a region of that class = RAFFT_MAX_LEN
 #define LDS_SEQ 4096       // sequences up to this length have the bases of a loop staged in LDS by classes 2 and 3
-#define MAX_PROD 256       // productive regions per structure (sequences up to LDS_SEQ)
+#define MAX_PROD 64        // productive regions per structure (sequences up to LDS_SEQ); a wave that meets more is folded again with the long lists
 #define MAX_PROD_LONG 1024 // ... for longer sequences
 #define RL_CAP 1024        // beam_step_kernel: regions with >= 2 candidates of all beam members, kept in LDS
 
