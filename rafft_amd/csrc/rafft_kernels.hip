@@ -8,6 +8,11 @@
 //                       (rafft/rafft.py:36-83), local Turner dE of every candidate stem from
 //                       prefix sums over the loop's branch list + filter/sort
 //                       (rafft/rafft.py:86-109)
+//                       Template switch PROD: production builds with the debug seam, the phase
+//                       stamps and - for the classes whose regions all take the popcount
+//                       correlation - the FFT compiled out (no register spills).
+//   expand_small_kernel  (rafft_expand_small.hip) the same for regions of up to 16 / 32 positions:
+//                       teams of 16 / 32 lanes, four or two regions per wavefront
 //   beam_step_kernel    one workgroup per sequence: helix combination in product order, flat
 //                       over all parents of the beam, with `seen` dedupe and the max_branch
 //                       rule, stable energy sort and beam cut (rafft/rafft.py:176-214)
