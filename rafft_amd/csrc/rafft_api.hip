@@ -891,7 +891,9 @@ int Wave::after_beam()
         HIPCHK(hipGetLastError());
         // tail of the batch: so few new structures that their regions fit one wave of workgroups of the widest class
         // (measured on the benchmark batch: 18.8 -> 17.3 ms; thresholds in new structures per step, per CU)
-        const unsigned merge_below = getenv("RAFFT_MERGE_BELOW") ? (unsigned)atoi(getenv("RAFFT_MERGE_BELOW")) : 16u * (unsigned)::g.n_cu;
+        // (round 3, after the 256-thread class got its production build and four workgroups per CU: everything goes to the widest
+        //  class only below 2 structures per CU - 16 per CU before; a burst of 20 shard batches 18.5 -> 17.8 ms, the rest unchanged)
+        const unsigned merge_below = getenv("RAFFT_MERGE_BELOW") ? (unsigned)atoi(getenv("RAFFT_MERGE_BELOW")) : 2u * (unsigned)::g.n_cu;
         const unsigned merge2_below = getenv("RAFFT_MERGE2_BELOW") ? (unsigned)atoi(getenv("RAFFT_MERGE2_BELOW")) : 128u * (unsigned)::g.n_cu;
         d.merge_cls = seam ? 0 : hc.n_mat < merge_below ? merge_target : hc.n_mat < merge2_below ? 2 : 0;
         merged_now = d.merge_cls;
