@@ -116,6 +116,18 @@ class Folder:
         """`steps` passes, `depth` in flight; every pass waited for and freed before this returns"""
         if self.n == 0:
             return
+        if depth == 1:          # one call at a time: the synchronous entry point (rafft_fold_batch), as a blocking caller would use it
+            for _ in range(steps):
+                res = C.POINTER(self.N.Result)()
+                self.N.check(self.lib.rafft_fold_batch(C.byref(self.p), self.n, self.arr, self.lens, self.device, C.byref(res)))
+                st = self.N.Stats()
+                self.lib.rafft_get_stats(C.byref(st))
+                for k, v in st.as_dict().items():
+                    self.agg[k] = self.agg.get(k, 0) + v
+                ok = res.contents.n_failed == 0
+                self.lib.rafft_free_result(res)
+                assert ok
+            return
         q = []
         for _ in range(steps):
             q.append(self.submit())

@@ -110,6 +110,7 @@ struct Ctx {
     std::condition_variable qcv_sched, qcv_done;
     std::deque<std::shared_ptr<struct Batch>> submitted;
     int n_inflight = 0;                // batches submitted and not yet finished
+    bool last_submit_async = false;    // under qmu: the last batch came through rafft_fold_submit (its caller may be about to queue more)
     std::chrono::steady_clock::time_point t_last_submit{};   // under qmu: when the last batch was queued (the scheduler lingers on a stream of them)
     bool sched_started = false;
     bool stop = false;                 // under qmu: the process is exiting (rafft_shutdown): the scheduler thread returns
@@ -1449,19 +1450,23 @@ static void scheduler_main()
         // A caller that streams batches (two or more in flight) queues them microseconds apart: a bulk wave admitted the moment the
         // first one arrives would fold that one alone and the second wave whatever came in the meantime - three waves one after the
         // other (heavy phases do not overlap) where one merged wave would do.  So while submissions keep coming (the last one less
-        // than RAFFT_LINGER_US = 150 us ago) and the queue is below the merge cap, the bulk lane waits for them.  A lone synchronous
+        // than RAFFT_LINGER_US = 150 us ago) and the queues are below the merge cap, both lanes wait for them.  A lone synchronous
         // call never lingers.
         static const long linger_us = getenv("RAFFT_LINGER_US") ? atol(getenv("RAFFT_LINGER_US")) : 150;
         bool linger = false;
-        if (linger_us > 0 && !queue[1].empty()) {
+        if (linger_us > 0 && (!queue[1].empty() || !queue[0].empty())) {
             size_t queued = 0;
-            for (auto &j : queue[1]) queued += j.seqs.size();
+            for (int ln = 0; ln < 2; ln++) for (auto &j : queue[ln]) queued = std::max(queued, j.seqs.size() * queue[ln].size());   // (a bound is enough)
             std::lock_guard<std::mutex> lk(g.qmu);
-            linger = g.n_inflight >= 2 && queued < merge_cap() &&
-                     std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - g.t_last_submit).count() < linger_us;
+            // (the FIRST batch of a burst lingers too when it came through rafft_fold_submit - otherwise it is folded alone, in both
+            //  lanes, and the long-tail lane, one wave at a time, needs two rounds: 20 shard batches 17.8 -> 13.4 ms.  rafft_fold_batch,
+            //  whose caller is blocked and cannot be streaming, never lingers.)
+            const long lim = (g.n_inflight >= 2 || g.last_submit_async) ? linger_us : 0;
+            linger = queued < merge_cap() &&
+                     std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - g.t_last_submit).count() < lim;
         }
         for (int ln = 0; ln < 2; ln++) {
-            if (ln == 1 && linger) break;
+            if (linger) break;          // (both lanes: the long-tail jobs of a burst are merged into one wave too - the lane runs one at a time)
             while (!queue[ln].empty() && (tail_slot ? (ln == 0 ? n_lane[0] < 1 : n_lane[1] < max_waves && n_running < MAX_PIPES) : n_running < max_waves)) {
                 Job &front = queue[ln].front();
                 if (!strip_failed(front)) {                       // every member already failed elsewhere: nothing to fold
@@ -1624,7 +1629,7 @@ int rafft_init(int device)
 struct rafft_job { std::shared_ptr<Batch> b; };
 
 // (holds g.mu)
-static int submit_locked(const rafft_params *p, int n_seq, const char *const *seqs, const int *lens, int device, rafft_job **job_)
+static int submit_locked(const rafft_params *p, int n_seq, const char *const *seqs, const int *lens, int device, rafft_job **job_, bool async_call = true)
 {
     if (!p || !job_ || n_seq < 0 || (n_seq > 0 && !seqs)) return fail(RAFFT_ERR_PARAM, "null argument");
     *job_ = nullptr;
@@ -1717,6 +1722,7 @@ static int submit_locked(const rafft_params *p, int n_seq, const char *const *se
         g.submitted.push_back(bp);
         g.n_inflight++;
         g.t_last_submit = std::chrono::steady_clock::now();
+        g.last_submit_async = async_call;
     }
     g.qcv_sched.notify_one();
     *job_ = new rafft_job{bp};
@@ -1759,7 +1765,7 @@ int rafft_fold_batch(const rafft_params *p, int n_seq, const char *const *seqs, 
     rafft_job *job = nullptr;
     {
         std::lock_guard<std::mutex> lk(g.mu);
-        if (int rc = submit_locked(p, n_seq, seqs, lens, device, &job)) return rc;
+        if (int rc = submit_locked(p, n_seq, seqs, lens, device, &job, false)) return rc;      // (this caller cannot be streaming: no linger)
     }
     return wait_job(job, out_);
 }
