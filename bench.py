@@ -6,12 +6,16 @@ benchmark_results/bench_fft.py:8): the 2296 sequences of benchmark_cleaned_all_l
 max_stack ms=50, max_branch=1000 (CLI default).  One "step" = one pass of the whole hot path over that set.
 
 N = 1: every step folds the whole set on the one GPU.
-N > 1: the set is LPT-sharded over the ranks (rafft_amd/sharding.py - what the reference does with a process pool,
-       benchmark_results/bench_fft.py:17-22); every step folds the whole set once, each rank its shard, no data-path
-       collective (RCCL carries only the barriers and the max-reduction of the elapsed time): STRONG scaling,
-       value = 2296 * K / max-over-ranks time.  The gathered result of one extra pass is parity-checked on rank 0
-       outside the timed region.  `weak_replica_value` (every rank folds a full replica) and `cfg4_sharded`
+N > 1: WEAK scaling, per-GPU work fixed: the global batch of a step is N copies of the set (N x 2296 sequences),
+       LPT-sharded over the ranks (rafft_amd/sharding.py - what the reference does with a process pool,
+       benchmark_results/bench_fft.py:17-22), each rank folds its shard, no data-path collective (RCCL carries only the
+       barriers and the max-reduction of the elapsed time): value = N * 2296 * K / max-over-ranks time.  The gathered
+       result of one extra pass is parity-checked on rank 0 outside the timed region.  `strong_sharded_value` (ONE copy
+       of the set sharded over the ranks - rounds 2 and 3 reported this as `value` at N > 1) and `cfg4_sharded`
        (BASELINE configs[3]: 16 384 random sequences L 100..3000, ms=200, LPT-sharded) ride along as extra keys.
+       Started without a launcher (`python bench.py --gpus N`, WORLD_SIZE unset) it starts its N ranks itself - what
+       the reference's driver does with Pool(int(argv[1])), benchmark_results/bench_fft.py:17 - before anything touches
+       the GPU, relays rank 0's line and fails if any rank does.
 
 Steps are issued through the library's asynchronous C-ABI (rafft_fold_submit / rafft_fold_wait) with up to ten batches
 in flight - continuous batching: queued batches with identical parameters are folded as ONE wave by the library's
@@ -146,6 +150,49 @@ class Folder:
         return out
 
 
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without torchrun: start the N ranks as child processes (one per GPU, rendezvous on
+    127.0.0.1), relay rank 0's JSON line, exit non-zero if any rank fails.  Runs before this process imports torch or
+    touches the GPU (mirrors benchmark_results/bench_fft.py:17-21: the reference's driver takes N and starts its own
+    workers)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(n_ranks))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n_ranks):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [l for l in (out0 or "").splitlines() if l.startswith("{")]
+    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
+    if bad or not lines:
+        print(f"bench.py --gpus {n_ranks}: ranks failed (rank, exit code): {bad}; rank 0 printed {len(lines)} JSON lines", file=sys.stderr)
+        sys.exit(1)
+    line = json.loads(lines[-1])
+    assert line["n_gpus"] == n_ranks, (line["n_gpus"], n_ranks)
+    print(lines[-1], flush=True)
+    sys.exit(0)
+
+
+def csrc_digest():
+    """digest of the device/host sources of the library: the PMC summary under profiles/ carries the digest of the tree it was
+    measured on (tools/profile_r04.sh), so a summary older than the build is flagged (`traffic_stale`) - the GPU box has no .git"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rafft_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,7 +209,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("BENCH_SAME_GPU"):      # rehearsal of the N>1 path on a one-GPU box
         local_rank = 0
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args.gpus)                # never returns
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` or with "
+              f"torch.distributed.run --nproc-per-node N", file=sys.stderr)
+        sys.exit(2)
     # CPU baseline first, on rank 0 at N=1 only, BEFORE this process touches the GPU
     # (fork-based pool; the timed GPU region below is unaffected)
     seqs = load_bench_sequences()
@@ -196,10 +249,13 @@ def main():
     n = len(seqs)
     full = Folder(lib, N, p, seqs, local_rank)
     if world > 1:
-        shard_idx = sharding.lpt_shards([len(s) for s in seqs], world)[rank]
-        mine = Folder(lib, N, p, [seqs[i] for i in shard_idx], local_rank)
+        # weak scaling: the global batch of a step is `world` copies of the set, LPT-sharded (global index i = copy i // n of
+        # sequence i % n); `strong`: ONE copy sharded over the ranks (what rounds 2 and 3 timed at N > 1)
+        shard_idx = sharding.lpt_shards([len(s) for s in seqs] * world, world)[rank]
+        mine = Folder(lib, N, p, [seqs[i % n] for i in shard_idx], local_rank)
+        strong = Folder(lib, N, p, [seqs[i] for i in sharding.lpt_shards([len(s) for s in seqs], world)[rank]], local_rank)
     else:
-        shard_idx, mine = list(range(n)), full
+        shard_idx, mine, strong = list(range(n)), full, None
 
     def barrier():
         if world > 1:
@@ -237,10 +293,9 @@ def main():
                   "energy_mae_kcal_per_mol": abs_err / max(rows, 1)}
 
     # ---------------------------------------------------------------- the timed region
-    # Steps in flight: PIPELINE_DEPTH at one GPU.  With N ranks a step hands every rank 1/N of the set, so N times as
-    # many steps are kept in flight - the scheduler then still folds waves of the size the single GPU folds
-    # (~9000 sequences), instead of N times smaller ones whose lock-step steps no longer fill the chip.
-    DEPTH_RUN = PIPELINE_DEPTH * max(1, world)
+    # Steps in flight: PIPELINE_DEPTH on every rank - a step hands every rank as many sequences as the single GPU folds
+    # (weak scaling), so every rank's scheduler sees the N = 1 stream of batches.
+    DEPTH_RUN = PIPELINE_DEPTH
     # (a fresh box hands over a GPU in its low-power state: half a second of the same work, untimed, before the W warm-up
     #  steps, so that the clocks have ramped whatever W is)
     t_pre = time.perf_counter()
@@ -285,7 +340,7 @@ def main():
             if flag == 0.0:
                 break
         barrier()
-        extras["steady_state_value"] = round(n * n_ss / allmax(time.perf_counter() - t1), 2)
+        extras["steady_state_value"] = round(n * world * n_ss / allmax(time.perf_counter() - t1), 2)
         extras["steady_state_steps"] = n_ss
         # latency of one synchronous call (no second batch in flight)
         mine.run(2, depth=1)
@@ -295,28 +350,30 @@ def main():
         barrier()
         extras["ms_per_call_sequential"] = round(allmax(time.perf_counter() - t1) / max(3, args.steps // 2) * 1e3, 3)
         if world > 1:
-            # (a) every rank folds a full replica: the weak-scaling figure of round 1, kept for continuity
-            full.run(2)
+            # (a) strong scaling: ONE copy of the set LPT-sharded over the ranks, `world` times as many steps in flight so that a
+            # rank's scheduler still merges its 1/N-sized shards into full waves (rounds 2 and 3 reported this as `value`)
+            strong.run(2 * world, depth=PIPELINE_DEPTH * world)
             barrier()
             t1 = time.perf_counter()
-            full.run(args.steps)
+            strong.run(args.steps, depth=PIPELINE_DEPTH * world)
             barrier()
-            extras["weak_replica_value"] = round(world * n * args.steps / allmax(time.perf_counter() - t1), 2)
-            # (b) the gathered result of the sharded path == rank 0's own fold of the whole set
+            extras["strong_sharded_value"] = round(n * args.steps / allmax(time.perf_counter() - t1), 2)
+            # (b) the gathered result of the sharded path (every copy of every sequence, whichever rank folded it) == rank 0's own
+            # fold of the whole set
             res = mine.wait(mine.submit(), keep=True, stats=False)
             payload = list(zip(shard_idx, mine.beams(res)))
             lib.rafft_free_result(res)
             gathered = [None] * world if rank == 0 else None
             dist.gather_object(payload, gathered, dst=0, group=gloo)
             if rank == 0:
-                got = [None] * n
+                got = [None] * (n * world)
                 for part in gathered:
                     for i, b in part:
                         got[i] = b
                 res = full.wait(full.submit(), keep=True, stats=False)
                 want = full.beams(res)
                 lib.rafft_free_result(res)
-                extras["sharded_parity"] = {"sequences": n, "final_beam_identical_to_single_gpu_fold": sum(int(a == b) for a, b in zip(got, want))}
+                extras["sharded_parity"] = {"sequences": n * world, "final_beam_identical_to_single_gpu_fold": sum(int(a == want[i % n]) for i, a in enumerate(got))}
         # (c) BASELINE configs[3]: 16 384 random sequences, L ~ U[100, 3000], ms=200, LPT-sharded over the ranks
         if (world > 1 and not os.environ.get("BENCH_SKIP_CFG4")) or os.environ.get("BENCH_CFG4"):
             import numpy as np
@@ -389,7 +446,7 @@ def main():
         # HBM traffic and SQ counters of the dominant kernel come from rocprofv3 PMC passes (separate runs,
         # gfx950 correction applied by tools/pmc_traffic.py); counters cannot be read in-process.
         traffic, traffic_src, issue, traffic_batch, tj = None, None, None, None, None
-        for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
@@ -435,18 +492,21 @@ def main():
                                 "counter_bytes_per_batch": cb, "issue_frac": fr})
         out = {
             "metric": "sequences/sec (whole node) on benchmark set, beam N=100; kcal/mol MAE vs CPU",
-            "value": round(n * args.steps / el, 2),
+            "value": round(n * world * args.steps / el, 2),
             "unit": "sequences/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(el / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "scaling_note": "per-GPU work fixed: a step folds n_gpus copies of the set, LPT-sharded, value = n_gpus x 2296 x steps / time "
+                            "(rounds 2 and 3 reported strong scaling - one copy sharded - as `value` at N > 1: now `strong_sharded_value`; "
+                            "N = 1 values are like-for-like across all rounds)",
             "dtype": "f32 FFT -> exact int counts, f64 scores, i32 dcal energies",
             "data": "benchmark_cleaned_all_length.csv sequences (committed fixture tests/golden/bench_inputs.tsv.gz)"
-                    + ("; LPT-sharded over the ranks, every step folds the whole set once" if world > 1 else ""),
+                    + (f"; a step folds {world} copies of the set, LPT-sharded over the ranks" if world > 1 else ""),
             "config": {"workload": "BASELINE configs[2]: 2296 seqs of benchmark_cleaned_all_length.csv "
                                    "(L 28..2968), nb_mode n=100, max_stack ms=50, max_branch=1000",
                        "nb_mode": args.nb_mode, "max_stack": args.max_stack, "max_branch": args.max_branch,
-                       "sequences_per_step": n, "sequences_on_rank0": mine.n,
+                       "sequences_per_step": n * world, "sequences_on_rank0": mine.n,
                        "parallelism": (f"LPT sequence shards x{world}, no collective" if world > 1 else "1 GPU"),
                        "batches_in_flight": DEPTH_RUN,
                        "scheduler": "queued batches with equal parameters are folded as ONE wave of up to "
@@ -459,6 +519,8 @@ def main():
                          "mean_launch_ms": round(dur_s * 1e3, 4), "launches_per_step": launches / args.steps,
                          "issue_roofline": issue,
                          "traffic_age": (tj or {}).get("commit"),
+                         # the PMC summary was measured on another build of rafft_amd/csrc than the one that just ran
+                         "traffic_stale": (tj or {}).get("csrc_digest") != csrc_digest(),
                          "kernels": kernels},
             "kernel_ms_per_step": {"ms_expand": round(agg.get("ms_expand", 0.0) / args.steps, 3),
                                    "batch_latency_ms_mean": round(agg.get("ms_total", 0.0) / args.steps, 3)},

@@ -106,6 +106,7 @@ typedef struct {
     int64_t alg_bytes_expand_c2;    /* ... of expand_kernel<256> (ms_expand_c2) */
     int64_t alg_bytes_expand_c3;    /* ... of expand_kernel<512> (ms_expand_c3) */
     int64_t alg_bytes_beam;         /* 2L + 8 per new structure: beam_step_kernel + materialize_kernel (ms_beam + ms_materialize) */
+    int64_t n_regrows_prod;         /* ... of n_regrows: a structure had more productive regions than the short lists hold (same arenas, long lists) */
 } rafft_stats;
 
 /* Select the GPU (HIP ordinal) and upload the energy tables.  Optional: every other

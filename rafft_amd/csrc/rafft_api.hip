@@ -23,6 +23,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <pthread.h>
 
 // kernels (rafft_kernels.hip is compiled into the same translation unit so the
 // templates and the Dev struct are shared without a device-link step)
@@ -582,8 +583,12 @@ struct Wave {
     }
     std::chrono::steady_clock::time_point t_issued;      // when the running step was issued (the scheduler blocks on the oldest)
     int after_beam();
-    int finish();
-    int finish_done();
+    // (every error exit of the two leaves `finished` and `result` set: the scheduler reads `result` of a finished wave, and a failure
+    //  while the rows are gathered - a device error, a pinned allocation - must not be released as a batch-level success)
+    int finish() { const int rc = finish_body(); if (rc) { finished = true; draining = false; if (!result) result = rc; } return rc; }
+    int finish_done() { const int rc = finish_done_body(); if (rc) { finished = true; if (!result) result = rc; } return rc; }
+    int finish_body();
+    int finish_done_body();
 };
 
 int Wave::setup()
@@ -988,7 +993,7 @@ int Wave::emit_rows(size_t first, size_t count, bool early, double *t_gather)
 // the scheduler thread goes back to the other waves: it used to sit in a stream synchronize here for the 1-3 ms the rows of a
 // wave of five batches take (32 MB D2H), during which no other wave's step was read back or issued.  ready() / after_beam()
 // see the end of that copy through Workspace::ev_hot (finish_done).
-int Wave::finish()
+int Wave::finish_body()
 {
     hipStream_t st = g.stream;
     finished = true;
@@ -1064,7 +1069,7 @@ int Wave::finish()
     return 0;
 }
 
-int Wave::finish_done()
+int Wave::finish_done_body()
 {
     finished = true;
     const auto tw2 = tw2_;
@@ -1353,7 +1358,7 @@ static void scheduler_main()
         if (sl.job.members.size() <= 1 || rc == RAFFT_ERR_NO_DEVICE) { release(sl.job, rc, err); return; }
         for (size_t i = 0; i < sl.job.members.size(); i++) {
             Job one;
-            one.est = sl.job.est; one.depth = sl.job.depth; one.no_merge = true;
+            one.est = sl.job.est; one.depth = sl.job.depth; one.no_merge = true; one.big_prod = sl.job.big_prod;
             one.members.assign(1, sl.job.members[i]);
             for (SeqIn sq : sl.job.seqs) if (sq.bi == (int)i) { sq.bi = 0; one.seqs.push_back(sq); }
             if (one.seqs.empty()) { if (--sl.job.members[i]->pending == 0) { finalize_batch(sl.job.members[i]); n_active_batches--; } continue; }
@@ -1361,6 +1366,8 @@ static void scheduler_main()
         }
         sl.job.members.clear();
     };
+    bool big_prod_seen = false;               // a wave with `big_prod_params` met a structure with more productive regions than the short lists hold
+    rafft_params big_prod_params{};
     auto last_progress = std::chrono::steady_clock::now();
     for (;;) {
         {
@@ -1411,13 +1418,18 @@ static void scheduler_main()
             }
             int rc = sl.wave->after_beam();
             if (sl.wave->finished) {
-                rc = sl.wave->result;
+                if (sl.wave->result || !rc) rc = sl.wave->result;      // (a failure on the way out that left no result keeps its own code)
                 if (rc == RAFFT_ERR_CAPACITY) {
                     if (sl.job.depth >= 12)
                         release(sl.job, RAFFT_ERR_CAPACITY, "HBM arena overflow after 12 regrowths (bits " + std::to_string(sl.wave->ovf) + ")");
                     else {                                   // re-run with larger arenas, ahead of everything queued
                         sl.job.members[0]->stats.n_regrows++;
-                        if (sl.wave->want_big_prod) sl.job.big_prod = true;          // (same arenas, longer lists)
+                        if (sl.wave->want_big_prod) {                                // (same arenas, longer lists)
+                            sl.job.big_prod = true;
+                            sl.job.members[0]->stats.n_regrows_prod++;
+                            // sticky: later waves with these parameters start with the long lists instead of paying the double fold again
+                            big_prod_seen = true; big_prod_params = sl.job.members[0]->p;
+                        }
                         else sl.job.est *= (sl.job.depth >= 2 ? 4.0 : 2.0);
                         sl.job.depth++;
                         queue[sl.lane].push_front(std::move(sl.job));
@@ -1509,8 +1521,8 @@ static void scheduler_main()
                     for (int k = 0; k < MAX_PIPES; k++) if (slot[k].wave && slot[k].wave->c.bytes > big_wave) fits_now = false;
                 if ((cc.bytes > budget || (!fits_now && n_running == 0)) && job.seqs.size() > 1) {
                     const size_t h = job.seqs.size() / 2;          // too big for one wave: two jobs, one after the other
-                    Job a{std::vector<SeqIn>(job.seqs.begin(), job.seqs.begin() + h), job.est, job.depth, job.members, true};
-                    Job c{std::vector<SeqIn>(job.seqs.begin() + h, job.seqs.end()), job.est, job.depth, job.members, true};
+                    Job a{std::vector<SeqIn>(job.seqs.begin(), job.seqs.begin() + h), job.est, job.depth, job.members, true, job.big_prod};
+                    Job c{std::vector<SeqIn>(job.seqs.begin() + h, job.seqs.end()), job.est, job.depth, job.members, true, job.big_prod};
                     for (auto &m : job.members) m->pending++;      // one job became two (halves of a split are not merged again)
                     queue[ln].push_front(std::move(c));
                     queue[ln].push_front(std::move(a));
@@ -1525,7 +1537,7 @@ static void scheduler_main()
                 if (!rc) {
                     sl.wave.reset(new Wave(g.ws[w], sl.job.members, sl.job.seqs, sl.job.est));
                     sl.wave->depth = sl.job.depth;
-                    sl.wave->big_prod = sl.job.big_prod;
+                    sl.wave->big_prod = sl.job.big_prod || (big_prod_seen && same_params(big_prod_params, sl.job.members[0]->p));
                     rc = sl.wave->setup();
                     if (!rc) rc = sl.wave->issue_step();
                 }
@@ -1567,14 +1579,30 @@ static void scheduler_main()
 }
 
 extern "C" void rafft_shutdown(void);
+// In the child of a fork() the scheduler thread does not exist (only the forking thread survives), yet the inherited Ctx says it
+// was started and the inherited atexit(rafft_shutdown) would join it: the child forgets the thread object (never joined, never
+// destructed as joinable) and starts a scheduler of its own if it ever submits.  (A HIP context does not survive a fork either:
+// a child that folds must initialise the GPU itself - this only keeps a child that does NOT fold from hanging in exit().)
+static void atfork_child()
+{
+    new (&g.sched_thread) std::thread();      // placement-new over the stale handle: ~thread() of a joinable thread would terminate()
+    g.sched_started = false; g.stop = false; g.n_inflight = 0;
+    new (&g.qmu) std::mutex(); new (&g.mu) std::mutex();       // (may have been held by another thread of the parent at fork time)
+}
 static void start_scheduler()
 {
+    std::lock_guard<std::mutex> lk(g.qmu);    // (sched_started / sched_thread: the same mutex as rafft_shutdown)
     if (g.sched_started) return;
     g.sched_started = true;
     g.sched_thread = std::thread(scheduler_main);
-    // stopped and joined at process exit BEFORE the HIP runtime tears down (atexit handlers run in reverse order of
-    // registration and the runtime registered its own when it was initialised, earlier than this)
-    atexit(rafft_shutdown);
+    static bool registered = false;
+    if (!registered) {
+        registered = true;
+        // stopped and joined at process exit BEFORE the HIP runtime tears down (atexit handlers run in reverse order of
+        // registration and the runtime registered its own when it was initialised, earlier than this)
+        atexit(rafft_shutdown);
+        pthread_atfork(nullptr, nullptr, atfork_child);
+    }
 }
 
 // no batch may be in flight when the device tables change or a seam call borrows workspace 0

@@ -188,7 +188,7 @@ __host__ __device__ inline int node_class(int n, int span, int nbr, int merge_cl
 {
     if (merge_cls == 0 && n >= 2 && n <= sm_n5 && 2 * n - 1 <= K && span <= SM_SPAN) {
         if (n <= sm_n4 && nbr <= 16) return 4;
-        if (nbr <= 32) return 5;
+        if (sm_n5 > sm_n4 && nbr <= 32) return 5;       // (equal limits: class 5 is off - issue_step never launches it - and the region takes the general kernel)
     }
     // few regions in this step (the tail of a batch): all of them go to one kernel, the widest one that is
     // configured - one launch and one region per workgroup instead of three nearly empty kernels in a row

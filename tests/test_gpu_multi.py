@@ -50,17 +50,42 @@ def test_gpu_two_ranks_one_gpu_sharded_fold(tmp_path):
     assert 0 < st["n_structs"] and st["n_regrows"] == 0           # rank 0 really folded (its shard) on the GPU
 
 
+def _check_two_rank_line(out):
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["steps"] == 4
+    # a step folds two copies of the set, LPT-sharded: every rank holds about one set's worth of sequences
+    assert out["config"]["sequences_per_step"] == 2 * 2296 and 2000 < out["config"]["sequences_on_rank0"] < 2600
+    assert out["sharded_parity"] == {"sequences": 2 * 2296, "final_beam_identical_to_single_gpu_fold": 2 * 2296}
+    assert out["strong_sharded_value"] > 0 and out["roofline"]["frac"] > 0
+
+
 def test_gpu_bench_two_ranks_sharded_mode():
-    """bench.py as the driver starts it for N > 1 (here: 2 ranks on the one GPU, gloo instead of RCCL): strong scaling
-    over LPT shards, the gathered result equal to a single-GPU fold of the whole set"""
+    """bench.py as the driver starts it for N > 1 (here: 2 ranks on the one GPU, gloo instead of RCCL): weak scaling over LPT
+    shards of two copies of the set, the gathered result equal to a single-GPU fold of the whole set"""
     env = dict(os.environ, BENCH_SAME_GPU="1", BENCH_BACKEND="gloo", BENCH_SKIP_CFG4="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29657", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0 and out["steps"] == 4
-    assert out["config"]["sequences_per_step"] == 2296 and 0 < out["config"]["sequences_on_rank0"] < 2296
-    assert out["sharded_parity"] == {"sequences": 2296, "final_beam_identical_to_single_gpu_fold": 2296}
-    assert out["weak_replica_value"] > 0 and out["roofline"]["frac"] > 0
+    _check_two_rank_line(json.loads(line))
+
+
+def test_gpu_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` started plainly (no torchrun, WORLD_SIZE unset) starts its two ranks itself, relays rank 0's
+    line with n_gpus == 2 (benchmark_results/bench_fft.py:17: the reference's driver takes N and starts its own workers)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(BENCH_SAME_GPU="1", BENCH_BACKEND="gloo", BENCH_SKIP_CFG4="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    _check_two_rank_line(json.loads(lines[0]))
+
+
+def test_gpu_bench_refuses_a_world_size_that_is_not_gpus():
+    """--gpus 2 under a launcher that started one rank: fails loudly instead of folding on one GPU and calling it two"""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr
