@@ -525,7 +525,9 @@ def main():
             "kernel_ms_per_step": {"ms_expand": round(agg.get("ms_expand", 0.0) / args.steps, 3),
                                    "batch_latency_ms_mean": round(agg.get("ms_total", 0.0) / args.steps, 3)},
             "stage_ms_untimed_pass": stage_ms,
-            "memoization": {"regions_created": agg.get("n_nodes_created", 0) // args.steps,
+            "memoization": {"region_instances": agg.get("n_node_instances", 0) // args.steps,      # (structure, region) pairs
+                            "regions_created": agg.get("n_nodes_created", 0) // args.steps,      # records written: first pick of a (parent region, candidate, side)
+                            "regions_aliased": agg.get("n_nodes_aliased", 0) // args.steps,      # ... that turned out to be a known loop (another path)
                             "regions_expanded": agg.get("n_node_expansions", 0) // args.steps},
             "allocations_in_timed_region": timed_allocs,
             "cpu_baseline": cpu,

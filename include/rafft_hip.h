@@ -91,8 +91,8 @@ typedef struct {
                                  send their regions to one of the wide kernels instead) */
     int64_t n_steps;          /* folding steps executed (max over sequences) */
     int64_t n_node_expansions;/* regions really expanded (identical loops are expanded once) */
-    int64_t n_nodes_created;  /* (structure,node) pairs created, incl. aliases of known loops */
-    int64_t n_nodes_aliased;  /* regions that re-used an earlier identical loop's expansion */
+    int64_t n_nodes_created;  /* region records written: one per (parent region, candidate, side) that a beam member picked, whoever picked it first */
+    int64_t n_nodes_aliased;  /* ... of these: loops reached before along another path, which re-use that region's expansion */
     int64_t sum_node_len;     /* sum of n over expansions */
     int64_t sum_lags;         /* sum of min(nb_mode, 2n-1) over expansions */
     int64_t n_structs;        /* structures materialized (beam survivors) */
@@ -106,6 +106,7 @@ typedef struct {
     int64_t alg_bytes_expand_c2;    /* ... of expand_kernel<256> (ms_expand_c2) */
     int64_t alg_bytes_expand_c3;    /* ... of expand_kernel<512> (ms_expand_c3) */
     int64_t alg_bytes_beam;         /* 2L + 8 per new structure: beam_step_kernel + materialize_kernel (ms_beam + ms_materialize) */
+    int64_t n_node_instances;       /* (structure, region) pairs: entries of the structures' node lists (n_nodes_created of them needed a record) */
     int64_t n_regrows_prod;         /* ... of n_regrows: a structure had more productive regions than the short lists hold (same arenas, long lists) */
 } rafft_stats;
 

@@ -35,7 +35,7 @@ class Stats(C.Structure):
                 ("n_children", C.c_int64), ("sum_struct_len", C.c_int64), ("alg_bytes", C.c_int64),
                 ("alg_bytes_expand", C.c_int64), ("alg_bytes_expand_all", C.c_int64), ("n_regrows", C.c_int64),
                 ("alg_bytes_expand_small", C.c_int64), ("alg_bytes_expand_c2", C.c_int64), ("alg_bytes_expand_c3", C.c_int64),
-                ("alg_bytes_beam", C.c_int64), ("n_regrows_prod", C.c_int64)]
+                ("alg_bytes_beam", C.c_int64), ("n_node_instances", C.c_int64), ("n_regrows_prod", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

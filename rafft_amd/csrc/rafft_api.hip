@@ -64,13 +64,13 @@ struct Workspace {
     void *hot = nullptr;                 // pinned, 512 B
     // named device buffers (grow-only)
     Buf codes, seq_off, seq_len, beam, beam_n, done, nsteps, ch_parent, ch_combo, ch_dcal, ch_h, seen, seen_off,
-        seen_cap, seen_cnt, st, prod, nd, nd_canon, pos, br, db, cand, looptab, trec, tsid,
+        seen_cap, seen_cnt, st, prod, nd, nlist, nd_slot, cslot, pos, br, db, cand, looptab, trec, tsid,
         work0, work1, work2, work3, work4, work5, mat, counters,
         row_sid, row_off, out_db, out_dcal, row_off2, out_db2, out_dcal2, dbg, big;
     void release_buffers()
     {
         for (Buf *b : {&codes, &seq_off, &seq_len, &beam, &beam_n, &done, &nsteps, &ch_parent, &ch_combo, &ch_dcal, &ch_h, &seen,
-                       &seen_off, &seen_cap, &seen_cnt, &st, &prod, &nd, &nd_canon, &pos, &br, &db, &cand, &looptab, &trec, &tsid,
+                       &seen_off, &seen_cap, &seen_cnt, &st, &prod, &nd, &nlist, &nd_slot, &cslot, &pos, &br, &db, &cand, &looptab, &trec, &tsid,
                        &work0, &work1, &work2, &work3, &work4, &work5, &mat, &counters, &row_sid, &row_off, &out_db, &out_dcal, &row_off2, &out_db2,
                        &out_dcal2, &dbg, &big})
             if (b->p) { hipError_t e_ = hipFree(b->p); (void)e_; b->p = nullptr; b->cap = 0; }
@@ -79,7 +79,7 @@ struct Workspace {
     {
         size_t t = 0;
         for (const Buf *b : {&codes, &seq_off, &seq_len, &beam, &beam_n, &done, &nsteps, &ch_parent, &ch_combo, &ch_dcal, &ch_h, &seen,
-                             &seen_off, &seen_cap, &seen_cnt, &st, &prod, &nd, &nd_canon, &pos, &br, &db, &cand, &looptab, &trec, &tsid,
+                             &seen_off, &seen_cap, &seen_cnt, &st, &prod, &nd, &nlist, &nd_slot, &cslot, &pos, &br, &db, &cand, &looptab, &trec, &tsid,
                              &work0, &work1, &work2, &work3, &work4, &work5, &mat, &counters, &row_sid, &row_off, &out_db, &out_dcal, &row_off2, &out_db2,
                              &out_dcal2, &dbg, &big})
             t += b->cap;
@@ -426,7 +426,7 @@ Caps plan_caps(size_t S, size_t sumL, const rafft_params &p, double est)
     // keys of one step: children + old beam; only the max_stack selected ones are sorted (padded to a power of two)
     int m2 = 2; while (m2 < p.max_stack) m2 <<= 1;
     c.sort_cap = std::max((need + 1) & ~1, m2);
-    c.bytes = c.st * 128 + c.nd * (64 + 4 + 4 * 4 + 16) + c.pos * 2 + c.br * 4 + c.db + c.cand * 32 + c.seen * 16 +
+    c.bytes = c.st * 128 + c.nd * (64 + 4 + 4 + 6 * 4 + 16) + c.pos * 2 + c.br * 4 + c.db + c.cand * (32 + 8) + c.seen * 16 +
               c.looptab * 8 + c.trec * 16 + c.tsid * 4 + c.mat * 48 + S * (size_t)c.ch_cap * 32 + S * B * 4;
     return c;
 }
@@ -667,7 +667,7 @@ int Wave::setup()
     ENS(ch_parent, Sr * c.ch_cap * 2); ENS(ch_combo, Sr * c.ch_cap * 8); ENS(ch_dcal, Sr * c.ch_cap * 4); ENS(ch_h, Sr * c.ch_cap * 16);
     ENS(seen, cr.seen * 16); ENS(seen_off, Sr * 8); ENS(seen_cap, Sr * 4); ENS(seen_cnt, Sr * 4);
     ENS(st, cr.st * sizeof(StRec)); ENS(prod, cr.nd * 16);
-    ENS(nd, cr.nd * sizeof(NodeRec)); ENS(nd_canon, cr.nd * 4);
+    ENS(nd, cr.nd * sizeof(NodeRec)); ENS(nlist, cr.nd * 4); ENS(nd_slot, cr.nd * 4); ENS(cslot, cr.cand * 8);
     ENS(pos, cr.pos * 2); ENS(br, cr.br * 4); ENS(db, cr.db); ENS(cand, cr.cand * 32);
     ENS(looptab, cr.looptab * 8);
     ENS(trec, cr.trec * 16); ENS(tsid, cr.tsid * 4);
@@ -726,7 +726,7 @@ int Wave::setup()
     d.st = (StRec *)g.st.p;
     d.prod = (ProdEnt *)g.prod.p; d.prod_shard_cap = c.nd / NSHARD;
     d.nd_cap = (uint32_t)c.nd;
-    d.nd = (NodeRec *)g.nd.p; d.nd_canon = (int *)g.nd_canon.p;
+    d.nd = (NodeRec *)g.nd.p; d.nlist = (int *)g.nlist.p; d.nd_slot = (uint32_t *)g.nd_slot.p; d.cslot = (unsigned long long *)g.cslot.p;
     d.looptab = (unsigned long long *)g.looptab.p; d.looptab_cap = c.looptab;
     d.pos = (uint16_t *)g.pos.p; d.pos_cap = c.pos; d.br = (uint32_t *)g.br.p; d.br_cap = c.br;
     d.db = (uint8_t *)g.db.p; d.db_cap = c.db;
@@ -781,7 +781,7 @@ int Wave::setup()
         const size_t nt = v ? 1024 : 256;
         bs_lds[v] = std::max((size_t)c.sort_cap * 8, 24 * nt) + RL_CAP * 12 + B * sizeof(ParentInfo) + (B + 1) * 8 + ((B + 3) & ~(size_t)3) * 4 + 128;
     }
-    mat_lds = 12 * (size_t)d.max_prod + (((size_t)maxL + 15) & ~(size_t)15);
+    mat_lds = 20 * (size_t)d.max_prod + (((size_t)maxL + 15) & ~(size_t)15);
     if (const char *e = getenv("RAFFT_DEDUPE_PER_CU")) dedupe_per_cu = (unsigned)std::max(1, atoi(e));
     n_active = (unsigned)S;
     ms_setup = since(tw0);
@@ -905,6 +905,12 @@ int Wave::after_beam()
         merged_now = d.merge_cls;
         hipLaunchKernelGGL(dedupe_kernel, dim3(::g.n_cu * dedupe_per_cu), dim3(DEDUPE_NT), 0, st, d);
         HIPCHK(hipGetLastError());
+        if (d.memo) {         // node lists: slot numbers -> canonical region ids (without memoization materialize_kernel wrote ids)
+            const unsigned long long ent = (unsigned long long)hc.n_mat * 16ULL;        // (any grid is correct: the kernel strides)
+            const unsigned rgrid = (unsigned)std::max<unsigned long long>(1ULL, std::min<unsigned long long>((unsigned long long)::g.n_cu * 4ULL, (ent + DEDUPE_NT - 1) / DEDUPE_NT));
+            hipLaunchKernelGGL(resolve_kernel, dim3(rgrid), dim3(DEDUPE_NT), 0, st, d);
+            HIPCHK(hipGetLastError());
+        }
         SPAN_REC(sp.b, st, sp.kind);
         spans.push_back(sp);
     }
@@ -1022,9 +1028,10 @@ int Wave::finish_body()
             hc.n_alias += x.alias; hc.n_children += x.children; hc.sum_struct_len += x.struct_len;
         }
     {
-        unsigned long long nn = S;
-        for (int i = 0; i < NSHARD; i++) nn += hc.node[i].v;
+        unsigned long long nn = S, ni = S;
+        for (int i = 0; i < NSHARD; i++) { nn += hc.node[i].v; ni += hc.nlist[i].v; }
         bt.stats.n_nodes_created += (int64_t)nn;
+        bt.stats.n_node_instances += (int64_t)ni;
     }
     bt.stats.n_node_expansions += hc.n_expand;
     bt.stats.n_nodes_aliased += (int64_t)hc.n_alias;

@@ -357,6 +357,7 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
                     cd.set_cuts(br_lower(brl, nbr, pos[mi]), br_lower(brl, nbr, pos[mj]), br_lower(brl, nbr, pos[mi - nb + 1]), br_lower(brl, nbr, pos[mj + nb - 1]));
                     cd.h1 = h1; cd.h2 = h2;
                     d.cand[cbase + toff + rank] = cd;
+                    d.cslot[cbase + toff + rank] = 0ULL;      // (both child slots: nobody has asked yet)
                     if (dbg && d.dbg.kept) d.dbg.kept[rank] = w_rank[s];
                 }
         }

@@ -11,7 +11,14 @@
 //                       ordered unpaired positions `pos` and the ordered branch helices
 //                       `br` hanging in that loop.  Its candidate stems depend on
 //                       nothing else, so identical loops met in different structures
-//                       are expanded ONCE (nd_canon -> canonical node; `loop table`).
+//                       are created and expanded ONCE:
+//   child slots cslot[] one word per candidate, two halves: the region INSIDE / OUTSIDE the stem (rafft/utils.py:141-152).  A child
+//                       region is a function of (parent region, candidate, side) alone, so the first beam member that
+//                       picks the candidate claims the slot (one compare-and-swap) and creates the region; everybody
+//                       else only notes the slot in its node list.  Loops reached along different paths (stems formed
+//                       in another order) still meet in the `loop table`, which sees created regions only.
+//   node lists nlist[]  the regions of a structure, in the reference's node_list order (rafft/rafft.py:187-190):
+//                       slot numbers when materialize_kernel writes them, canonical region ids once resolve_kernel has run
 //   pos arena           uint16 root positions of every node, ascending
 //   br arena            uint32 (p | q<<16) outermost pair of every branch, ascending
 //   cand arena          32-byte stem candidates, dE-sorted per canonical node
@@ -84,6 +91,7 @@ struct Counters {
     unsigned long long cls_items[NCLS], cls_sum_n[NCLS], cls_sum_lags[NCLS];   // per size class
     // sharded bump pointers of the arenas filled by materialize / expand
     ShardCtr node[NSHARD], pos[NSHARD], br[NSHARD], db[NSHARD], cand[NSHARD], node_prev[NSHARD], prod[NSHARD];
+    ShardCtr nlist[NSHARD], nlist_prev[NSHARD];     // node-list entries (one per region of a structure; `node` counts the regions CREATED)
     // statistics the kernels add to once per wavefront / workgroup: one 64-byte line per (size class, shard), summed by the
     // host at the end of the wave.  (As single counters they were a same-address atomic storm at the end of every expand
     // launch - 3000-4000 wavefronts x 7 atomics on one line - a fixed 150-300 us per launch.)
@@ -136,7 +144,10 @@ struct Dev {
     uint32_t nd_cap;
     uint64_t nd_base, nd_shard_cap, pos_base, pos_shard_cap, br_shard_cap, db_base, db_shard_cap, cand_shard_cap;
     NodeRec *nd;                 // one 64-byte record per region (one cache line: header reads and writes are one transaction)
-    int *nd_canon;               // canonical region of every region (its own array: the beam step scans it along a structure)
+    int *nlist;                  // node lists of the structures (st.node0, st.nnodes): canonical region ids (see the file header)
+    unsigned long long *cslot;   // child slots, one word per candidate: inner | outer << 32; a half is 0 (nobody has asked yet), bit 31 alone
+                                 // (claimed: being created in this step) or bit 31 | (region id + 1)
+    uint32_t *nd_slot;           // the slot a created region hangs in (dedupe_kernel points it at the canonical region when the loop is known already)
     // loop table: open addressing, word = (hash tag << 32) | (node id + 1)
     unsigned long long *looptab; uint64_t looptab_cap;   // power of two
     // arenas

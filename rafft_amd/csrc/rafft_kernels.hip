@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                 cd.ddcal = my; cd.mi = (uint16_t)mi; cd.mj = (uint16_t)mj; cd.nb = (uint16_t)nb;
                 cd.set_cuts(br_lower(brl, nbr, pos[mi]), br_lower(brl, nbr, pos[mj]), br_lower(brl, nbr, pos[mi - nb + 1]), br_lower(brl, nbr, pos[mj + nb - 1]));
                 cd.h1 = h1; cd.h2 = h2;
-                if (!dry) d.cand[cbase + rank] = cd;
+                if (!dry) { d.cand[cbase + rank] = cd; d.cslot[cbase + rank] = 0ULL; }   // (both child slots: nobody has asked yet)
                 if (dbg.kept) dbg.kept[rank] = r;
             }
         }
@@ -1162,7 +1162,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int sq = blockIdx.x;
     // snapshot of the region allocators: whatever materialize adds after this kernel is "new"
-    if (sq == 0 && tid < NSHARD) d.c->node_prev[tid].v = d.c->node[tid].v;
+    if (sq == 0 && tid < NSHARD) { d.c->node_prev[tid].v = d.c->node[tid].v; d.c->nlist_prev[tid].v = d.c->nlist[tid].v; }
     // the expand kernels of this step are done with their work lists: reset them for dedupe_kernel / the next step
     if (sq == 0 && tid < NCLS) d.c->n_work[tid] = 0;
     if (sq == 0) for (int i = tid; i < NCLS * NSHARD; i += BS_NT) d.c->wcur[i / NSHARD][i % NSHARD].v = 0;
@@ -1240,7 +1240,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
                     int i = base + gl, cnt = 0, cn = 0;
                     unsigned long long coff = 0;
                     if (i < nn) {
-                        cn = d.nd_canon[node0 + i];
+                        cn = d.nlist[node0 + i];
                         cnt = d.nd[cn].ncand;
                         if (cnt > 0) {
                             coff = d.nd[cn].cand;
@@ -1676,19 +1676,20 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
 // tile (binary search element -> child region), so every load of the wavefront is independent and in
 // flight at once instead of one dependent round trip per region.
 struct MatDesc {
-    unsigned long long srcpos, srcbr;
-    int pn, mi, mj, nb, n, nbr, ci, cj, lo0, hi0, loo, hio, a0, b0, ao, bo, flags;
+    unsigned long long srcpos, srcbr, cidx;      // cidx: the candidate (its two child slots are cslot[2 cidx], cslot[2 cidx + 1])
+    int pn, mi, mj, nb, n, nbr, ci, cj, lo0, hi0, loo, hio, a0, b0, ao, bo, flags, win;   // flags: which children exist (1 inner, 2 outer); win: which of them THIS structure creates
     uint32_t newbr;        // the stem as a branch of the outer child: outermost pair, in the arena's (packed) form
     int nnod, npos_in, npos_out, nbr_in, nbr_out;
 };
-__device__ inline MatDesc mat_describe(const Dev &d, int pn, int selk)
+// (`cidx` comes from the parent's productive-region list: the candidate record and the region header are independent loads)
+__device__ inline MatDesc mat_describe(const Dev &d, int pn, unsigned long long cidx)
 {
     MatDesc m;
     m.pn = pn;
-    const unsigned long long coff = d.nd[pn].cand;
+    const Cand cd = d.cand[cidx];
     m.n = d.nd[pn].n; m.nbr = d.nd[pn].nbr; m.ci = d.nd[pn].ci; m.cj = d.nd[pn].cj;
     m.srcpos = d.nd[pn].pos; m.srcbr = d.nd[pn].br;
-    const Cand cd = d.cand[coff + selk];
+    m.cidx = cidx;
     m.mi = cd.mi; m.mj = cd.mj; m.nb = cd.nb;
     const uint16_t *pp = d.pos + m.srcpos;
     const int pm = d.pos_packed ? 0x0FFF : 0xFFFF;
@@ -1696,7 +1697,7 @@ __device__ inline MatDesc mat_describe(const Dev &d, int pn, int selk)
     m.a0 = pp[m.mi] & pm; m.b0 = pp[m.mj] & pm; m.ao = (int)rao & pm; m.bo = (int)rbo & pm;
     m.newbr = rao | (rbo << 16);          // (with Dev::pos_packed the base codes ride in bits 12-15 and 28-31)
     cd.get_cuts(m.lo0, m.hi0, m.loo, m.hio);      // where the stem cuts the branch list (found by expand_kernel)
-    m.flags = 0; m.nnod = 0; m.npos_in = m.npos_out = m.nbr_in = m.nbr_out = 0;
+    m.flags = 0; m.win = 0; m.nnod = 0; m.npos_in = m.npos_out = m.nbr_in = m.nbr_out = 0;
     if (m.mj - m.mi > 1) { m.flags |= 1; m.nnod++; m.npos_in = m.mj - m.mi - 1; m.nbr_in = m.hi0 - m.lo0; }
     if (m.mi - (m.nb - 1) > 0 || m.mj + m.nb < m.n) {
         m.flags |= 2; m.nnod++; m.npos_out = (m.mi - m.nb + 1) + (m.n - (m.mj + m.nb)); m.nbr_out = m.loo + 1 + (m.nbr - m.hio);
@@ -1714,7 +1715,8 @@ __global__ __launch_bounds__(MAT_NT, RAFFT_MAT_WAVES) void materialize_kernel(De
 {
     extern __shared__ __align__(16) uint8_t mat_dyn[];
     // dynamic LDS: the productive-region lists (d.max_prod entries each), then the dot-bracket staging row
-    int *prod_node = (int *)mat_dyn;
+    unsigned long long *prod_off = (unsigned long long *)mat_dyn;
+    int *prod_node = (int *)(prod_off + d.max_prod);
     int *prod_cnt = prod_node + d.max_prod;
     int *sel = prod_cnt + d.max_prod;
     uint8_t *sdb = (uint8_t *)(sel + d.max_prod);
@@ -1722,7 +1724,7 @@ __global__ __launch_bounds__(MAT_NT, RAFFT_MAT_WAVES) void materialize_kernel(De
     __shared__ unsigned long long k_srcpos[64], k_srcbr[64];
     __shared__ int k_mi[64], k_mj[64], k_nb[64], k_lo0[64], k_loo[64], k_hio[64], k_newbr[64];
     __shared__ int ps[129], bs[129], ns[65];
-    __shared__ unsigned long long sh64[4];
+    __shared__ unsigned long long sh64[5];
     __shared__ int shi[8];
     const int tid = threadIdx.x;
     // diagnostic phase stamps (RAFFT_TRACE=3) of every 64th workgroup, kept in the slots of class 0
@@ -1737,7 +1739,7 @@ __global__ __launch_bounds__(MAT_NT, RAFFT_MAT_WAVES) void materialize_kernel(De
     if (mprod > d.max_prod) mprod = d.max_prod;
     {
         const ProdEnt *pl = d.prod + rec.prod;             // the parent's productive regions (beam_step prepass)
-        for (int k = tid; k < mprod; k += MAT_NT) { prod_node[k] = pl[k].node; prod_cnt[k] = (int)pl[k].cnt; sel[k] = 0; }
+        for (int k = tid; k < mprod; k += MAT_NT) { const ProdEnt pe = pl[k]; prod_node[k] = pe.node; prod_cnt[k] = (int)pe.cnt; prod_off[k] = pe.off; sel[k] = 0; }
     }
     // the parent's dot-bracket row (rafft/rafft.py:97,127-128); the stems are marked below
     const uint8_t *pdb = d.db + rec.pdb;
@@ -1759,92 +1761,124 @@ __global__ __launch_bounds__(MAT_NT, RAFFT_MAT_WAVES) void materialize_kernel(De
     __syncthreads();
     MSTAMP(0);   // header, productive-region list, parent row, combo digits
 
-    // pass 1: sizes (a single tile - the usual case - keeps its descriptors in registers for pass 2)
+    // pass 1: sizes, and who creates what.  A child region is a function of (parent region, candidate, side) alone
+    // (rafft/rafft.py:127-152, rafft/utils.py:141-152): the beam member whose compare-and-swap finds the slot empty creates it, everybody
+    // else - the other members of this step that picked the same stem, and every later step - only notes the slot number in its node
+    // list (resolve_kernel turns slot numbers into region ids once this kernel and dedupe_kernel are done: nobody reads a slot's
+    // value in here).  Without memoization (min_nrj != 0: a region's filter depends on its parent's energy) every member creates its own.
+    // (a single tile - the usual case - keeps its descriptors in registers for pass 2; with several the claims ride in sel[])
     const int TILE = d.mat_tile;          // 64; smaller only in tests (several tiles per structure)
     const bool one_tile = mprod <= TILE;
+    const bool memo = d.memo != 0;
     MatDesc md;
-    md.flags = 0; md.nnod = 0; md.npos_in = md.npos_out = md.nbr_in = md.nbr_out = 0; md.nb = 0;
-    int tot_nodes = 0, tot_pos = 0, tot_br = 0;
+    md.flags = 0; md.win = 0; md.nnod = 0; md.npos_in = md.npos_out = md.nbr_in = md.nbr_out = 0; md.nb = 0; md.cidx = 0;
+    int tot_nodes = 0, tot_new = 0, tot_pos = 0, tot_br = 0;
     for (int base = 0; base < mprod; base += TILE) {
         const int k = base + tid;
-        int nnod = 0, npos = 0, nbrr = 0;
+        int nnod = 0, nnew = 0, npos = 0, nbrr = 0;
         if (k < mprod && tid < TILE) {
-            md = mat_describe(d, prod_node[k], sel[k]);
-            nnod = md.nnod; npos = md.npos_in + md.npos_out; nbrr = md.nbr_in + md.nbr_out;
+            // the claim of both child slots of the chosen candidate: ONE returning atomic, issued before anything else is loaded (its
+            // round trip runs beside those of the region header, the candidate and the positions).  A slot word is inner | outer << 32;
+            // bit 31 of a half says "claimed", and whoever finds it clear has claimed that half.  (Claiming the half of a child that
+            // does not exist - an empty inside, nothing left outside - is harmless: nobody ever looks at it.)
+            const unsigned long long cidx = prod_off[k] + (unsigned long long)sel[k];
+            unsigned long long old = 0;
+            if (memo) old = atomicOr(&d.cslot[cidx], 0x8000000080000000ULL);
+            md = mat_describe(d, prod_node[k], cidx);
+            int win = md.flags;
+            if (memo) win &= ((old >> 31) & 1ULL ? 0 : 1) | ((old >> 63) & 1ULL ? 0 : 2);
+            md.win = win;
+            if (!one_tile) sel[k] |= win << 28;
+            nnod = md.nnod; nnew = (win & 1) + (win >> 1);
+            npos = ((win & 1) ? md.npos_in : 0) + ((win & 2) ? md.npos_out : 0);
+            nbrr = ((win & 1) ? md.nbr_in : 0) + ((win & 2) ? md.nbr_out : 0);
         }
         for (int o = 32; o > 0; o >>= 1) {
-            nnod += __shfl_xor(nnod, o, 64); npos += __shfl_xor(npos, o, 64); nbrr += __shfl_xor(nbrr, o, 64);
+            nnod += __shfl_xor(nnod, o, 64); nnew += __shfl_xor(nnew, o, 64); npos += __shfl_xor(npos, o, 64); nbrr += __shfl_xor(nbrr, o, 64);
         }
-        tot_nodes += nnod; tot_pos += npos; tot_br += nbrr;
+        tot_nodes += nnod; tot_new += nnew; tot_pos += npos; tot_br += nbrr;
     }
     MSTAMP(1);   // pass 1
-    if (tid < 4) {
+    if (tid < 5) {
         // bump allocation from one of NSHARD sub-arenas (spreads the same-address atomics); one lane per arena
         const int shd = blockIdx.x & (NSHARD - 1);
-        unsigned long long *ctr = tid == 0 ? &d.c->node[shd].v : tid == 1 ? &d.c->pos[shd].v : tid == 2 ? &d.c->db[shd].v : &d.c->br[shd].v;
-        const unsigned long long want = tid == 0 ? (unsigned long long)tot_nodes : tid == 1 ? (unsigned long long)tot_pos
-                                      : tid == 2 ? (unsigned long long)L : (unsigned long long)tot_br;
-        const unsigned long long cap = tid == 0 ? d.nd_shard_cap : tid == 1 ? d.pos_shard_cap : tid == 2 ? d.db_shard_cap : d.br_shard_cap;
-        const unsigned long long b0 = atomicAdd(ctr, want);
+        unsigned long long *ctr = tid == 0 ? &d.c->node[shd].v : tid == 1 ? &d.c->pos[shd].v : tid == 2 ? &d.c->db[shd].v : tid == 3 ? &d.c->br[shd].v : &d.c->nlist[shd].v;
+        const unsigned long long want = tid == 0 ? (unsigned long long)tot_new : tid == 1 ? (unsigned long long)tot_pos
+                                      : tid == 2 ? (unsigned long long)L : tid == 3 ? (unsigned long long)tot_br : (unsigned long long)tot_nodes;
+        const unsigned long long cap = tid == 0 || tid == 4 ? d.nd_shard_cap : tid == 1 ? d.pos_shard_cap : tid == 2 ? d.db_shard_cap : d.br_shard_cap;
+        const unsigned long long b0 = want ? atomicAdd(ctr, want) : 0ULL;
         const bool bad = b0 + want > cap;
-        if (bad) atomicOr(&d.c->overflow, tid == 0 ? OVF_NODE : tid == 1 ? OVF_POS : tid == 2 ? OVF_DB : OVF_BR);
-        const unsigned long long origin = tid == 0 ? d.nd_base : tid == 1 ? d.pos_base : tid == 2 ? d.db_base : 0ULL;
+        if (bad) atomicOr(&d.c->overflow, tid == 0 || tid == 4 ? OVF_NODE : tid == 1 ? OVF_POS : tid == 2 ? OVF_DB : OVF_BR);
+        const unsigned long long origin = tid == 0 || tid == 4 ? d.nd_base : tid == 1 ? d.pos_base : tid == 2 ? d.db_base : 0ULL;
         sh64[tid] = origin + (unsigned long long)shd * cap + b0;
         const unsigned long long anybad = __ballot(bad);
         if (tid == 0) shi[0] = anybad ? 0 : 1;
     }
     __syncthreads();
     if (!shi[0]) { if (tid == 0) { d.st[sid].nnodes = 0; d.st[sid].node0 = 0; d.st[sid].db = 0; } return; }
-    const unsigned long long nbase = sh64[0], pbase = sh64[1], tbase = sh64[2], bbase = sh64[3];
+    const unsigned long long nbase = sh64[0], pbase = sh64[1], tbase = sh64[2], bbase = sh64[3], lbase = sh64[4];
     MSTAMP(2);   // allocation
 
-    // pass 2: per tile: descriptors -> LDS, prefix sums, region records, flat copies
-    int run_nodes = 0, run_pos = 0, run_br = 0;
+    // pass 2: per tile: descriptors -> LDS, prefix sums, node-list entries, records and flat copies of the regions created here
+    int run_nodes = 0, run_new = 0, run_pos = 0, run_br = 0;
     for (int base = 0; base < mprod; base += TILE) {
         const int k = base + tid;
         const int kt = mprod - base < TILE ? mprod - base : TILE;
         if (!one_tile) {
-            md.flags = 0; md.nnod = 0; md.npos_in = md.npos_out = md.nbr_in = md.nbr_out = 0; md.nb = 0;
-            if (k < mprod && tid < TILE) md = mat_describe(d, prod_node[k], sel[k]);
+            md.flags = 0; md.win = 0; md.nnod = 0; md.npos_in = md.npos_out = md.nbr_in = md.nbr_out = 0; md.nb = 0;
+            if (k < mprod && tid < TILE) { md = mat_describe(d, prod_node[k], prod_off[k] + (unsigned long long)(sel[k] & 0x0FFFFFFF)); md.win = (sel[k] >> 28) & 3; }
         }
         const bool act = k < mprod && tid < TILE;
-        // inclusive scans over the tile: nodes, pos elements, branch elements, stem pairs
-        int xn = act ? md.nnod : 0, xp = act ? md.npos_in + md.npos_out : 0, xb = act ? md.nbr_in + md.nbr_out : 0, xs = act ? md.nb : 0;
-        const int vn = xn, vp = xp, vb = xb, vs = xs;
+        const int cp_in = act && (md.win & 1) ? md.npos_in : 0, cp_out = act && (md.win & 2) ? md.npos_out : 0;
+        const int cb_in = act && (md.win & 1) ? md.nbr_in : 0, cb_out = act && (md.win & 2) ? md.nbr_out : 0;
+        // inclusive scans over the tile: node-list entries, regions created, their pos and branch elements, stem pairs
+        int xn = act ? md.nnod : 0, xw = act ? (md.win & 1) + (md.win >> 1) : 0, xp = cp_in + cp_out, xb = cb_in + cb_out, xs = act ? md.nb : 0;
+        const int vn = xn, vw = xw, vp = xp, vb = xb, vs = xs;
         for (int o = 1; o < 64; o <<= 1) {
-            const int yn = __shfl_up(xn, o, 64), yp = __shfl_up(xp, o, 64), yb = __shfl_up(xb, o, 64), ys = __shfl_up(xs, o, 64);
-            if (tid >= o) { xn += yn; xp += yp; xb += yb; xs += ys; }
+            const int yn = __shfl_up(xn, o, 64), yw = __shfl_up(xw, o, 64), yp = __shfl_up(xp, o, 64), yb = __shfl_up(xb, o, 64), ys = __shfl_up(xs, o, 64);
+            if (tid >= o) { xn += yn; xw += yw; xp += yp; xb += yb; xs += ys; }
         }
-        const int tn = __shfl(xn, 63, 64), tp = __shfl(xp, 63, 64), tb = __shfl(xb, 63, 64), ts = __shfl(xs, 63, 64);
+        const int tn = __shfl(xn, 63, 64), tw = __shfl(xw, 63, 64), tp = __shfl(xp, 63, 64), tb = __shfl(xb, 63, 64), ts = __shfl(xs, 63, 64);
         const int p0 = xp - vp, b0 = xb - vb;          // exclusive
-        ps[2 * tid] = p0; ps[2 * tid + 1] = p0 + (act ? md.npos_in : 0);
-        bs[2 * tid] = b0; bs[2 * tid + 1] = b0 + (act ? md.nbr_in : 0);
+        ps[2 * tid] = p0; ps[2 * tid + 1] = p0 + cp_in;
+        bs[2 * tid] = b0; bs[2 * tid + 1] = b0 + cb_in;
         ns[tid] = xs - vs;
         if (tid == 0) { ps[128] = tp; bs[128] = tb; ns[64] = ts; }
         if (act) {
             k_srcpos[tid] = md.srcpos; k_srcbr[tid] = md.srcbr;
             k_mi[tid] = md.mi; k_mj[tid] = md.mj; k_nb[tid] = md.nb; k_lo0[tid] = md.lo0; k_loo[tid] = md.loo; k_hio[tid] = md.hio;
             k_newbr[tid] = (int)md.newbr;
-            // region records (rafft/utils.py:141-152): inner, then outer
-            int nid = (int)(nbase + run_nodes + (xn - vn));
+            // region records (rafft/utils.py:141-152) of the children created here, and the node list (rafft/rafft.py:187-190): inner, then outer
+            int nid = (int)(nbase + run_new + (xw - vw));
+            unsigned long long le = lbase + run_nodes + (xn - vn);
             const unsigned long long poff = pbase + run_pos + p0, boff = bbase + run_br + b0;
+            const int slot0 = (int)(2 * md.cidx);
             if (md.flags & 1) {
-                d.nd[nid].seq = sq; d.nd[nid].pdcal = my_dcal; d.nd[nid].pos = poff; d.nd[nid].n = md.npos_in;
-                d.nd[nid].L = L; d.nd[nid].soff = soff;
-                d.nd[nid].ci = md.a0; d.nd[nid].cj = md.b0; d.nd[nid].br = boff; d.nd[nid].nbr = md.nbr_in;
-                d.nd[nid].ncand = -1; d.nd[nid].cand = 0; d.nd_canon[nid] = nid;
-                nid++;
+                if (md.win & 1) {
+                    d.nd[nid].seq = sq; d.nd[nid].pdcal = my_dcal; d.nd[nid].pos = poff; d.nd[nid].n = md.npos_in;
+                    d.nd[nid].L = L; d.nd[nid].soff = soff;
+                    d.nd[nid].ci = md.a0; d.nd[nid].cj = md.b0; d.nd[nid].br = boff; d.nd[nid].nbr = md.nbr_in;
+                    d.nd[nid].ncand = -1; d.nd[nid].cand = 0;
+                    if (memo) { d.nd_slot[nid] = (uint32_t)slot0; ((uint32_t *)d.cslot)[slot0] = (uint32_t)(nid + 1) | 0x80000000u; }
+                    d.nlist[le] = memo ? slot0 : nid;
+                    nid++;
+                } else d.nlist[le] = slot0;
+                le++;
             }
             if (md.flags & 2) {
-                d.nd[nid].seq = sq; d.nd[nid].pdcal = my_dcal; d.nd[nid].pos = poff + md.npos_in; d.nd[nid].n = md.npos_out;
-                d.nd[nid].L = L; d.nd[nid].soff = soff;
-                d.nd[nid].ci = md.ci; d.nd[nid].cj = md.cj; d.nd[nid].br = boff + md.nbr_in; d.nd[nid].nbr = md.nbr_out;
-                d.nd[nid].ncand = -1; d.nd[nid].cand = 0; d.nd_canon[nid] = nid;
+                if (md.win & 2) {
+                    d.nd[nid].seq = sq; d.nd[nid].pdcal = my_dcal; d.nd[nid].pos = poff + cp_in; d.nd[nid].n = md.npos_out;
+                    d.nd[nid].L = L; d.nd[nid].soff = soff;
+                    d.nd[nid].ci = md.ci; d.nd[nid].cj = md.cj; d.nd[nid].br = boff + cb_in; d.nd[nid].nbr = md.nbr_out;
+                    d.nd[nid].ncand = -1; d.nd[nid].cand = 0;
+                    if (memo) { d.nd_slot[nid] = (uint32_t)(slot0 + 1); ((uint32_t *)d.cslot)[slot0 + 1] = (uint32_t)(nid + 1) | 0x80000000u; }
+                    d.nlist[le] = memo ? slot0 + 1 : nid;
+                } else d.nlist[le] = slot0 + 1;
             }
         }
         __syncthreads();
         MSTAMP(4);   // pass 2 descriptors + records
-        // unpaired positions of the child regions
+        // unpaired positions of the regions created here
         for (int f = tid; f < tp; f += MAT_NT) {
             int lo = 0, hi = 2 * kt - 1;                 // last slot starting at or before f (empty slots share starts)
             while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (ps[mid] <= f) lo = mid; else hi = mid - 1; }
@@ -1855,7 +1889,7 @@ __global__ __launch_bounds__(MAT_NT, RAFFT_MAT_WAVES) void materialize_kernel(De
             else { const int left = k_mi[kk] - k_nb[kk] + 1; src = off < left ? off : k_mj[kk] + k_nb[kk] + (off - left); }
             d.pos[pbase + run_pos + f] = pp[src];
         }
-        // branch helices of the child regions
+        // their branch helices
         for (int f = tid; f < tb; f += MAT_NT) {
             int lo = 0, hi = 2 * kt - 1;
             while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (bs[mid] <= f) lo = mid; else hi = mid - 1; }
@@ -1877,13 +1911,13 @@ __global__ __launch_bounds__(MAT_NT, RAFFT_MAT_WAVES) void materialize_kernel(De
             const uint16_t *pp = d.pos + k_srcpos[lo];
             sdb[pp[k_mi[lo] - t] & pmask] = '('; sdb[pp[k_mj[lo] + t] & pmask] = ')';
         }
-        run_nodes += tn; run_pos += tp; run_br += tb;
+        run_nodes += tn; run_new += tw; run_pos += tp; run_br += tb;
         __syncthreads();
         MSTAMP(5);   // region copies
     }
     uint8_t *odb = d.db + tbase;
     for (int x = tid; x < L; x += MAT_NT) odb[x] = sdb[x];
-    if (tid == 0) { d.st[sid].node0 = (int)nbase; d.st[sid].nnodes = tot_nodes; d.st[sid].db = tbase; }
+    if (tid == 0) { d.st[sid].node0 = (int)lbase; d.st[sid].nnodes = tot_nodes; d.st[sid].db = tbase; }
     MSTAMP(6);   // row out
     if (mprof) for (int k = 0; k < 7; k++) atomicAdd(&d.prof_e[k], macc[k]);
 #undef MSTAMP
@@ -1965,7 +1999,7 @@ __global__ __launch_bounds__(DEDUPE_NT) void dedupe_kernel(Dev d)
                     cls = node_class(n, span, d.nd[nid].nbr, d.merge_cls, d.cls1_P, d.cls1_br, d.K, d.sm_n4, d.sm_n5);
                 }
             }
-            else { d.nd_canon[nid] = canon; aliases++; }
+            else { ((uint32_t *)d.cslot)[d.nd_slot[nid]] = (uint32_t)(canon + 1) | 0x80000000u; aliases++; }      // (the loop is known - reached along another path: the slot points at it)
         }
         // work-list appends, aggregated over the WORKGROUP: one atomic per class and pass (per wavefront they were
         // 4096 x 4-6 returning atomics on one cache line per pass - the kernel's whole duration)
@@ -1992,6 +2026,32 @@ __global__ __launch_bounds__(DEDUPE_NT) void dedupe_kernel(Dev d)
     if (lane == 0 && aliases) atomicAdd(&d.c->xstat[0][blockIdx.x & (NSHARD - 1)].alias, aliases);
 }
 
+// One thread per node-list entry written in this step: slot number -> region id.  Runs after dedupe_kernel, when every slot of the
+// step holds the id of a canonical region (the one materialize_kernel created in it, or the known loop dedupe_kernel found for it).
+__global__ __launch_bounds__(DEDUPE_NT) void resolve_kernel(Dev d)
+{
+    __shared__ unsigned int pre[NSHARD + 1];
+    __shared__ unsigned int prev[NSHARD];
+    const int tid = threadIdx.x;
+    if (d.c->overflow) return;
+    if (tid < NSHARD) {
+        prev[tid] = (unsigned int)d.c->nlist_prev[tid].v;
+        pre[tid + 1] = (unsigned int)(d.c->nlist[tid].v - d.c->nlist_prev[tid].v);
+    }
+    if (tid == 0) pre[0] = 0;
+    __syncthreads();
+    if (tid == 0) for (int i = 1; i <= NSHARD; i++) pre[i] += pre[i - 1];
+    __syncthreads();
+    const unsigned int total = pre[NSHARD];
+    const unsigned int stride = gridDim.x * blockDim.x;
+    for (unsigned int f = blockIdx.x * blockDim.x + tid; f < total; f += stride) {
+        int lo = 0, hi = NSHARD;             // shard with pre[lo] <= f < pre[lo+1]
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (pre[mid] <= f) lo = mid; else hi = mid; }
+        const unsigned long long e = d.nd_base + (unsigned long long)lo * d.nd_shard_cap + prev[lo] + (f - pre[lo]);
+        d.nlist[e] = (int)(((const uint32_t *)d.cslot)[d.nlist[e]] & 0x7FFFFFFFu) - 1;
+    }
+}
+
 // ------------------------------------------------------------- init kernel
 
 __global__ void init_roots_kernel(Dev d)
@@ -2011,7 +2071,7 @@ __global__ void init_roots_kernel(Dev d)
         d.st[sq].parent = -1; d.st[sq].combo = 0;
         d.nd[sq].seq = sq; d.nd[sq].pdcal = 0; d.nd[sq].pos = off; d.nd[sq].n = L; d.nd[sq].ci = -1; d.nd[sq].cj = L;
         d.nd[sq].L = L; d.nd[sq].soff = off;
-        d.nd[sq].br = 0; d.nd[sq].nbr = 0; d.nd_canon[sq] = sq;
+        d.nd[sq].br = 0; d.nd[sq].nbr = 0; d.nlist[sq] = sq;
         d.nd[sq].ncand = -1; d.nd[sq].cand = 0;
         d.beam[(size_t)sq * d.B] = sq; d.beam_n[sq] = 1; d.nsteps[sq] = 0;
         d.done[sq] = L > 0 ? 0 : 1;

@@ -149,6 +149,7 @@ inline bool tok_int(const std::string &t, int &v, bool *is_def = nullptr)
     char *end = nullptr;
     const double d = strtod(t.c_str(), &end);
     if (end == t.c_str() || *end) return false;
+    if (!(d >= -(double)INF_ && d <= (double)INF_)) return false;       // (NaN, infinities, values no int holds: a conversion would be undefined)
     v = (int)d;
     return true;
 }
@@ -271,7 +272,7 @@ inline bool parse(const std::string &text, ParamSet &P, std::string &err)
             if (!tok_int(tk[0], P.duplex_init[0]) || !tok_int(tk[1], P.duplex_init[1]) || !tok_int(tk[2], P.term_au[0]) || !tok_int(tk[3], P.term_au[1])) { err = "section '# Misc': bad token"; return false; }
             char *end = nullptr;
             P.lxc = strtod(tk[4].c_str(), &end);
-            if (end == tk[4].c_str()) { err = "section '# Misc': bad LXC"; return false; }
+            if (end == tk[4].c_str() || !(P.lxc > -1e6 && P.lxc < 1e6)) { err = "section '# Misc': bad LXC"; return false; }
         } else all_dH = false;
     }
     struct SL { const char *n; std::vector<SpecialLoop> *v; size_t len; };

@@ -285,13 +285,20 @@ def test_gpu_large_nb_mode_on_long_sequences_vs_oracle():
 
 
 def test_gpu_more_productive_regions_than_the_short_lists_hold(monkeypatch):
-    """a structure with more productive regions than materialize_kernel's short LDS lists hold (256; here the hook makes it 3)
-    is no error: the wave is folded again with the long lists - same trajectories, one regrowth on record"""
+    """a structure with more productive regions than materialize_kernel's short LDS lists hold (64; here the hook makes it 3)
+    is no error: the wave is folded again with the long lists - same trajectories, one regrowth on record - and later waves
+    with the same parameters start with the long lists (no second double fold)"""
+    from rafft_amd import _native
+    _native.lib().rafft_shutdown()          # a fresh scheduler: it remembers which parameter sets needed the long lists
     rng = np.random.default_rng(256)
     seqs = ["".join(rng.choice(list("ACGU"), int(n))) for n in (300, 500, 120, 800)]
     want = [as_lists(t) for _, t in rafft_amd.fold_batch(seqs, 100, 8, 1000, traj=True)]
     monkeypatch.setenv("RAFFT_TEST_MAX_PROD", "3")
     got = [as_lists(t) for _, t in rafft_amd.fold_batch(seqs, 100, 8, 1000, traj=True)]
-    assert rafft_amd.last_stats()["n_regrows"] >= 1
+    st = rafft_amd.last_stats()
+    assert st["n_regrows"] >= 1 and st["n_regrows_prod"] >= 1
+    again = [as_lists(t) for _, t in rafft_amd.fold_batch(seqs, 100, 8, 1000, traj=True)]
+    assert rafft_amd.last_stats()["n_regrows"] == 0
     monkeypatch.delenv("RAFFT_TEST_MAX_PROD")
-    assert got == want
+    assert got == want and again == want
+    _native.lib().rafft_shutdown()

@@ -245,3 +245,68 @@ def test_malformed_blocks_are_rejected_with_their_line(synthetic_par):
     bad = lines[:last + 2] + ["/* never closed"] + [l for l in lines[last + 2:] if "*/" not in l]
     assert f"line {last + 3}: unterminated comment" in load(bad, "comment")
     assert params.params_info()["source"].startswith("built-in")         # failed loads changed nothing
+
+
+def test_parameter_reader_under_sanitizers(synthetic_par, tmp_path):
+    """rafft_params.h (reader, writer, temperature rescaling - the library's one parser of untrusted input) built host-only with
+    ASan + UBSan and fed well-formed files, the malformed corpus of the tests above, truncations, byte flips and oversized
+    files: no sanitizer report, every file either accepted (and stable under write + re-read) or rejected with a message.
+    (CPU build only: GPU AddressSanitizer is not available; this code needs no GPU.)"""
+    import subprocess
+    path, par = synthetic_par
+    exe = tmp_path / "params_san_driver"
+    src = os.path.join(ROOT, "tests", "san", "params_san_driver.cpp")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.check_call([hipcc, "-x", "hip", "--offload-host-only", "-O1", "-g", "-std=c++17", "-fno-omit-frame-pointer",
+                           "-fsanitize=address,undefined,float-cast-overflow", "-fno-sanitize-recover=all", src, "-o", str(exe)])
+    text = open(path).read()
+    builtin = tmp_path / "builtin_only.par"
+    params.reset_params()
+    params.save_params(builtin)
+    lines = text.split("\n")
+    corpus = {"good_synthetic": text, "good_builtin": open(builtin).read(), "empty": "", "header_only": "## RNAfold parameter file v2.0\n",
+              "no_header": "\n".join(l for l in lines if not l.startswith("##"))}
+    i11 = lines.index("# int11")
+    row = next(k for k in range(i11 + 1, len(lines)) if lines[k].strip() and not lines[k].strip().startswith("/*"))
+    for tag, tok in (("badtoken", "x1y"), ("huge", "1e300"), ("nan", "nan"), ("inf", "-inf"), ("big_int", "99999999999999999999"), ("hex", "0x7fffffff")):
+        bad = list(lines); bad[row] = bad[row].replace(bad[row].split()[0], tok, 1)
+        corpus[tag] = "\n".join(bad)
+    bad = list(lines); del bad[row + 2]; corpus["shortrow"] = "\n".join(bad)
+    bad = list(lines); bad.insert(row + 1, "  1 2 3"); corpus["surplus"] = "\n".join(bad)
+    last = max(k for k, l in enumerate(lines) if "*/" in l)
+    corpus["comment"] = "\n".join(lines[:last + 2] + ["/* never closed"] + [l for l in lines[last + 2:] if "*/" not in l])
+    corpus["misc_lxc"] = text.replace("107.856000", "1e999")
+    corpus["long_special"] = text.replace("# Tetraloops\n", "# Tetraloops\n" + "G" * 100000 + " 1 2\n")
+    corpus["many_special"] = text.replace("# Tetraloops\n", "# Tetraloops\n" + "GAAAAC 1 2\n" * 5000)
+    corpus["oversized_block"] = text.replace("# stack\n", "# stack\n" + " ".join(["7"] * 2000000) + "\n")
+    corpus["long_line"] = text + "\n# junk\n" + "9 " * 3000000
+    corpus["many_sections"] = text.replace("# END", "\n".join(f"# s{k}\n{k}" for k in range(50000)) + "\n# END")
+    corpus["crlf"] = text.replace("\n", "\r\n")
+    corpus["nul_bytes"] = text[:5000] + "\0\0\0" + text[5000:]
+    rng = np.random.default_rng(11)
+    for k, cut in enumerate(sorted(rng.integers(0, len(text), size=150))):      # truncated files
+        corpus[f"trunc{k:03d}"] = text[:int(cut)]
+    raw = bytearray(text.encode())
+    files = []
+    for tag, body in corpus.items():
+        f = tmp_path / f"c_{tag}.par"
+        f.write_text(body)
+        files.append(str(f))
+    for k in range(150):                                                         # byte flips
+        b = bytearray(raw)
+        for pos in rng.integers(0, len(b), size=int(rng.integers(1, 8))):
+            b[int(pos)] = int(rng.integers(0, 256))
+        f = tmp_path / f"c_flip{k:03d}.par"
+        f.write_bytes(bytes(b))
+        files.append(str(f))
+    out = subprocess.run([str(exe)] + files, capture_output=True, timeout=600,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1"))
+    stdout, stderr = out.stdout.decode("latin-1"), out.stderr.decode("latin-1")      # (messages quote the offending bytes)
+    assert out.returncode == 0, (stdout[-1500:], stderr[-3000:])
+    verdicts = dict(zip([os.path.basename(f)[2:-4] for f in files], stdout.strip().split("\n")))
+    assert len(verdicts) == len(files)
+    assert verdicts["good_synthetic"].startswith("ok ") and verdicts["good_builtin"].startswith("ok ") and verdicts["crlf"].startswith("ok ")
+    for tag in ("empty", "no_header", "badtoken", "huge", "nan", "inf", "big_int", "hex", "shortrow", "surplus", "comment", "misc_lxc", "long_special",
+                "many_special", "oversized_block"):
+        assert verdicts[tag].startswith("rejected: "), (tag, verdicts[tag])
+    assert all(v.startswith(("ok ", "rejected: ")) for v in verdicts.values())
