@@ -107,6 +107,9 @@ typedef struct {
     int64_t alg_bytes_expand_c3;    /* ... of expand_kernel<512> (ms_expand_c3) */
     int64_t alg_bytes_beam;         /* 2L + 8 per new structure: beam_step_kernel + materialize_kernel (ms_beam + ms_materialize) */
     int64_t n_node_instances;       /* (structure, region) pairs: entries of the structures' node lists (n_nodes_created of them needed a record) */
+    int64_t n_dE_evals;             /* built-in tables only (0 with a loaded parameter file): candidate stems whose dE was evaluated, */
+    int64_t n_dE_guessed;           /* ... those whose dE read an interior-loop table entry that no reference-held energy row exercises */
+    int64_t n_kept_guessed;         /* ... and the ones of these that passed the filter dE < min_nrj (rafft/rafft.py:102): candidates a beam member may pick */
     int64_t n_regrows_prod;         /* ... of n_regrows: a structure had more productive regions than the short lists hold (same arenas, long lists) */
 } rafft_stats;
 
@@ -158,6 +161,15 @@ int rafft_eval_structures(int n, const char *const *seqs, const char *const *dbs
 /* the same at md.temperature = temp (rafft/utils.py:18) */
 int rafft_eval_structures_at(double temp, int n, const char *const *seqs, const char *const *dbs, int *dcal_out,
                              int *status_out);
+
+/* The same at 37 C, and for every structure whether its energy reads an entry of the built-in interior-loop tables (1x1, 2x1, 2x2,
+ * the interior mismatches, bulge / interior sizes) that no reference-held (sequence, structure, energy) row exercises - a rule or
+ * model value, right in ~9 of 10 cases: guessed_out[i] = 1.  Always 0 with a loaded parameter file.  No
+ * counterpart in the reference, whose ViennaRNA has the real tables (rafft/utils.py:135-138). */
+int rafft_eval_structures_info(int n, const char *const *seqs, const char *const *dbs, int *dcal_out, int *status_out,
+                               int *guessed_out);
+/* counts[0..2] = entries of the current 1x1 / 2x1 / 2x2 tables that are such rule / model values (0 with a loaded file) */
+int rafft_params_unpinned(int counts[3]);
 
 /* Energy parameters.  Replaces: the parameter set behind RNA.md() / RNA.fold_compound(sequence, md)
  * (rafft/utils.py:17-21) - ViennaRNA's compiled-in Turner 2004 set, or whatever the user loaded with

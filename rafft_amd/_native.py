@@ -35,7 +35,8 @@ class Stats(C.Structure):
                 ("n_children", C.c_int64), ("sum_struct_len", C.c_int64), ("alg_bytes", C.c_int64),
                 ("alg_bytes_expand", C.c_int64), ("alg_bytes_expand_all", C.c_int64), ("n_regrows", C.c_int64),
                 ("alg_bytes_expand_small", C.c_int64), ("alg_bytes_expand_c2", C.c_int64), ("alg_bytes_expand_c3", C.c_int64),
-                ("alg_bytes_beam", C.c_int64), ("n_node_instances", C.c_int64), ("n_regrows_prod", C.c_int64)]
+                ("alg_bytes_beam", C.c_int64), ("n_node_instances", C.c_int64), ("n_dE_evals", C.c_int64), ("n_dE_guessed", C.c_int64),
+                ("n_kept_guessed", C.c_int64), ("n_regrows_prod", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -44,7 +45,7 @@ class Stats(C.Structure):
 EXPORTS = ["rafft_init", "rafft_fold_batch", "rafft_fold_submit", "rafft_fold_wait", "rafft_free_result", "rafft_last_error", "rafft_eval_structure",
            "rafft_eval_structures", "rafft_eval_structures_at", "rafft_expand_node", "rafft_get_stats", "rafft_version",
            "rafft_load_params", "rafft_load_params_text", "rafft_reset_params", "rafft_save_params", "rafft_params_info",
-           "rafft_param_value", "rafft_kin_rate_matrix", "rafft_shutdown", "rafft_alloc_counters"]
+           "rafft_param_value", "rafft_kin_rate_matrix", "rafft_shutdown", "rafft_alloc_counters", "rafft_eval_structures_info", "rafft_params_unpinned"]
 
 _lib = None
 
@@ -110,6 +111,8 @@ def lib():
                                     C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int),
                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.rafft_eval_structures_at.argtypes = [C.c_double] + L.rafft_eval_structures.argtypes
+    L.rafft_eval_structures_info.argtypes = L.rafft_eval_structures.argtypes + [C.POINTER(C.c_int)]
+    L.rafft_params_unpinned.argtypes = [C.POINTER(C.c_int * 3)]
     L.rafft_load_params.argtypes = [C.c_char_p]
     L.rafft_load_params_text.argtypes = [C.c_char_p, C.c_char_p]
     L.rafft_save_params.argtypes = [C.c_char_p]

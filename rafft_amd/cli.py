@@ -104,6 +104,20 @@ def format_result(sequence, result, args):
     return "\n".join(out)
 
 
+def _table_note():
+    """one line on stderr when the fold used rule / model values of the built-in tables (never with ViennaRNA's own tables loaded)"""
+    try:
+        from .rafft import last_stats
+        st = last_stats()
+    except Exception:
+        return
+    import os
+    if st.get("n_kept_guessed", 0) > 0 and not os.environ.get("RAFFT_QUIET"):
+        sys.stderr.write(f"rafft: built-in energy tables - {st['n_dE_guessed']} of {st['n_dE_evals']} stem energies ({st['n_kept_guessed']} kept "
+                         "candidates) read an interior-loop entry that no published energy pins; set RAFFT_PARAMS=<ViennaRNA parameter file> "
+                         "for ViennaRNA's own values (RAFFT_QUIET=1 silences this)\n")
+
+
 def main(argv=None, fold_batch=None):
     args = parse_arguments(argv)
     seqs = read_sequences(args)
@@ -132,6 +146,7 @@ def main(argv=None, fold_batch=None):
                     write_sidecar(side, s, results[k][1])
         if out is not None:
             out.flush()
+        _table_note()
     finally:
         if args.output:
             out.close()

@@ -61,7 +61,7 @@ struct Workspace {
     hipStream_t cls_stream[NCLS] = {};
     hipStream_t copy_stream = nullptr;   // result rows of sequences that finish early leave while the others still fold
     hipEvent_t ev_fork = nullptr, ev_join[NCLS] = {}, ev_hot = nullptr, ev_copy = nullptr;
-    void *hot = nullptr;                 // pinned, 512 B
+    void *hot = nullptr;                 // pinned, 1 KiB
     // named device buffers (grow-only)
     Buf codes, seq_off, seq_len, beam, beam_n, done, nsteps, ch_parent, ch_combo, ch_dcal, ch_h, seen, seen_off,
         seen_cap, seen_cnt, st, prod, nd, nlist, nd_slot, cslot, pos, br, db, cand, looptab, trec, tsid,
@@ -201,8 +201,8 @@ int init_ws(Workspace &w)
     HIPCHK(hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&w.ev_copy, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&w.ev_hot, hipEventDisableTiming | hipEventBlockingSync));   // (the scheduler sleeps on it when it has spun long enough)
-    static_assert(offsetof(Counters, node) <= 512, "hot counters must fit the pinned read-back slot");
-    HIPCHK(hipHostMalloc(&w.hot, 512, hipHostMallocDefault));
+    static_assert(offsetof(Counters, node) <= 1024, "hot counters must fit the pinned read-back slot");
+    HIPCHK(hipHostMalloc(&w.hot, 1024, hipHostMallocDefault));
     w.ready = true;
     return 0;
 }
@@ -239,7 +239,7 @@ int init_ctx(int device)
     return init_ws(g.ws[0]);
 }
 
-struct ClsCfg { int nt, Pmax, Lmax, nmax, brmax, Kmax, lds, grid; bool tab; int wpb; bool nofft; };   // grid: teams (wavefronts of the packed one-wavefront class, workgroups otherwise)
+struct ClsCfg { int nt, Pmax, Lmax, nmax, brmax, Kmax, lds, grid; bool tab; int wpb; bool nofft; bool direct3 = false; };   // grid: teams (wavefronts of the packed one-wavefront class, workgroups otherwise)
 
 // limits of the one-wavefront class: its LDS per wavefront (hence its occupancy) follows from them
 // (not below 256: the kernel addresses the staged bases through a pointer shifted back by up to 4095 positions, which must stay
@@ -252,7 +252,7 @@ static int cls1_br() { return std::min(CLS1_BR, (8 * cls1_P() - 16) / 10 - 1); }
 // wavefronts leaves ~32 KiB of a CU's LDS - room for a workgroup of the small-region kernel beside it.
 // `nofft2`: the same for the 256-thread class when Dev::direct_n covers all of its regions (<= 1024 positions): 46 -> 39 KiB, four
 // workgroups per CU instead of three.
-int class_cfg(int K, int maxL, ClsCfg out[NGEN], bool nofft1 = false, bool nofft2 = false)
+int class_cfg(int K, int maxL, ClsCfg out[NGEN], bool nofft1 = false, bool nofft2 = false, bool direct3_ok = false)
 {
     // sequences longer than LDS_SEQ: classes 2 and 3 read the bases of a loop from HBM/L2 (no LDS copy), class 0 takes the
     // regions whose FFT would not fit
@@ -297,6 +297,23 @@ int class_cfg(int K, int maxL, ClsCfg out[NGEN], bool nofft1 = false, bool nofft
             return fail(RAFFT_ERR_PARAM, "nb_mode too large for the LDS-resident expand kernel: it must stay below 2048 (below ~400 when a "
                                          "sequence is longer than 4096 nt)");
         if (l.total > 160 * 1024) out[c].lds = 160 * 1024, out[c].Kmax = 1;    // never launched with work
+    }
+    // Regions of 1025-4096 positions (class 3) without the 128-KiB FFT buffers: the kernel of the class for regions beyond 4096
+    // positions - exact direct correlation on multi-word bit masks, lag values in a per-workgroup HBM scratch - with an LDS plan
+    // sized for 4096 positions: ~50 KiB, so a CU holds two or three workgroups of it (four wavefronts per SIMD) instead of one.
+    // Same integer pair counts, same fp64 values (tests/test_gpu_parity.py::test_gpu_fft_and_direct_correlation_agree).
+    static const int c3_direct = getenv("RAFFT_C3_DIRECT") ? atoi(getenv("RAFFT_C3_DIRECT")) : 0;
+    if (c3_direct && direct3_ok && !longseq) {
+        const int Kmax = std::max(1, std::min(K, MAX_P - 1)), nmax = MAX_P / 2, Pd = 2048;
+        // (256 threads: at the 168 VGPRs the kernel needs without spilling a SIMD holds three wavefronts - three 256-thread
+        //  workgroups per CU; a 512-thread workgroup is two wavefronts per SIMD, and two of those would need 128 VGPRs: 44 spilled)
+        const int Cc = std::max(1, std::min(8, 256 / std::max(Kmax, 1)));
+        const bool fits = 80 * (nmax / 64) + 24 * Cc * Kmax + 2048 + 64 <= 16 * Pd && 10 * (MAX_BR + 1) + 16 + 8 * Kmax + 2048 <= 16 * Pd;
+        ExpandLds l = expand_lds(Pd, 0, nmax, MAX_BR, Kmax, false, 1, false, 256);
+        if (fits && l.total <= 80 * 1024) {
+            const int per_cu = std::max(1, std::min(3, (160 * 1024) / l.total));
+            out[3] = {256, Pd, 0, nmax, MAX_BR, Kmax, l.total, g.n_cu * per_cu, false, 1, false, true};
+        }
     }
     return 0;
 }
@@ -349,6 +366,8 @@ int launch_expand_cls(const Dev &d, int cls, const ClsCfg cf[NGEN], unsigned n_b
         if (prod && !cf[2].tab) return launch_expand<256, false, 1, 0, 1>(d, 2 | nf, cf[2], n_blocks, st);
         return cf[2].tab ? launch_expand<256, true>(d, 2 | nf, cf[2], n_blocks, st) : launch_expand<256, false>(d, 2 | nf, cf[2], n_blocks, st);
     }
+    if (cf[3].direct3 && nodiag) return launch_expand<256, false, 1, 2, 3>(d, 3, cf[3], n_blocks, st);
+    if (cf[3].direct3) return launch_expand<256, false, 1, 2>(d, 3, cf[3], n_blocks, st);
     if (nodiag && !cf[3].tab) return launch_expand<512, false, 1, 0, 2>(d, 3, cf[3], n_blocks, st);
     return cf[3].tab ? launch_expand<512, true>(d, 3, cf[3], n_blocks, st) : launch_expand<512, false>(d, 3, cf[3], n_blocks, st);
 }
@@ -627,7 +646,7 @@ int Wave::setup()
     const bool nofft1 = !seam && !force_fft_ && direct_n_ >= cls1_P() / 2 && p.gc_wei >= 0.0 && p.au_wei >= 0.0 && p.gu_wei >= 0.0 &&
                         !(getenv("RAFFT_C1_FFT") && atoi(getenv("RAFFT_C1_FFT")));
     const bool nofft2 = nofft1 && direct_n_ >= CLS2_P / 2 && !(getenv("RAFFT_C2_FFT") && atoi(getenv("RAFFT_C2_FFT")));
-    if (int rc = class_cfg(p.nb_mode, maxL, cf, nofft1, nofft2)) return rc;
+    if (int rc = class_cfg(p.nb_mode, maxL, cf, nofft1, nofft2, nofft1)) return rc;      // (direct class 3: the same conditions as the other FFT-free plans)
     if (getenv("RAFFT_TRACE"))
         for (int c = 0; c < NGEN; c++)
             fprintf(stderr, "[rafft] expand class %d: %d threads x %d regions per workgroup, P <= %d, branches <= %d, lags <= %d, LDS %d B%s\n", c, cf[c].nt, cf[c].wpb,
@@ -699,6 +718,10 @@ int Wave::setup()
     if (longseq) {       // scratch of the class for regions beyond 4096 positions: lag values (fp64) + lag column, per workgroup
         d.big_stride = (size_t)2 * BIG_N + (size_t)2 * BIG_N / 4;
         if (int rc = ensure(g.big, (size_t)cf[0].grid * d.big_stride * 8)) return rc;
+        d.big_keyv = (double *)g.big.p;
+    } else if (cf[3].direct3) {      // ... and of class 3 when it runs without FFT buffers: FFT size 8192 at most
+        d.big_stride = (size_t)MAX_P + (size_t)MAX_P / 4;
+        if (int rc = ensure(g.big, (size_t)cf[3].grid * d.big_stride * 8)) return rc;
         d.big_keyv = (double *)g.big.p;
     }
     d.cls1_P = cls1_P(); d.cls1_br = cf[1].brmax;
@@ -905,12 +928,6 @@ int Wave::after_beam()
         merged_now = d.merge_cls;
         hipLaunchKernelGGL(dedupe_kernel, dim3(::g.n_cu * dedupe_per_cu), dim3(DEDUPE_NT), 0, st, d);
         HIPCHK(hipGetLastError());
-        if (d.memo) {         // node lists: slot numbers -> canonical region ids (without memoization materialize_kernel wrote ids)
-            const unsigned long long ent = (unsigned long long)hc.n_mat * 16ULL;        // (any grid is correct: the kernel strides)
-            const unsigned rgrid = (unsigned)std::max<unsigned long long>(1ULL, std::min<unsigned long long>((unsigned long long)::g.n_cu * 4ULL, (ent + DEDUPE_NT - 1) / DEDUPE_NT));
-            hipLaunchKernelGGL(resolve_kernel, dim3(rgrid), dim3(DEDUPE_NT), 0, st, d);
-            HIPCHK(hipGetLastError());
-        }
         SPAN_REC(sp.b, st, sp.kind);
         spans.push_back(sp);
     }
@@ -918,7 +935,7 @@ int Wave::after_beam()
         Counters h2;
         HIPCHK(hipMemcpyAsync(&h2, g.counters.p, hot_len, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        fprintf(stderr, "[rafft] step %d: n_mat %u -> work %u %u %u %u | small %u %u\n", steps, hc.n_mat, h2.n_work[0], h2.n_work[1], h2.n_work[2], h2.n_work[3], h2.n_work[4], h2.n_work[5]);
+        fprintf(stderr, "[rafft] step %d: n_mat %u -> work %u %u %u %u | small %u %u\n", steps, hc.n_mat, h2.n_work[0].v, h2.n_work[1].v, h2.n_work[2].v, h2.n_work[3].v, h2.n_work[4].v, h2.n_work[5].v);
     }
     return issue_step();
 }
@@ -1026,6 +1043,7 @@ int Wave::finish_body()
             hc.n_expand += x.items; hc.sum_n += x.n; hc.sum_lags += x.lags; hc.sum_nbr += x.nbr;
             hc.cls_items[c] += x.items; hc.cls_sum_n[c] += x.n; hc.cls_sum_lags[c] += x.lags;
             hc.n_alias += x.alias; hc.n_children += x.children; hc.sum_struct_len += x.struct_len;
+            bt.stats.n_dE_evals += (int64_t)x.evals; bt.stats.n_dE_guessed += (int64_t)x.guessed; bt.stats.n_kept_guessed += (int64_t)x.kept_guessed;
         }
     {
         unsigned long long nn = S, ni = S;
@@ -1200,7 +1218,7 @@ int run_seam(Batch &bt, const std::vector<SeqIn> &one, const SeamIn &sm)
     int cls = node_class(n, (sm.ci < 0 || one[0].len > LDS_SEQ) ? one[0].len : sm.cj + 1 - sm.ci, nbr, 0, w.d.cls1_P, w.d.cls1_br, w.d.K, w.d.sm_n4, w.d.sm_n5);
     int zero = 0;
     memset(&w.hc.n_work, 0, sizeof w.hc.n_work);
-    w.hc.n_work[cls] = 1;
+    w.hc.n_work[cls].v = 1;
     HIPCHK(hipMemcpy(W.counters.p, &w.hc, sizeof w.hc, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(w.d.work[cls], &zero, 4, hipMemcpyHostToDevice));
     if (int rc = launch_expand_cls(w.d, cls, w.cf, 1, W.stream)) return rc;
@@ -1835,7 +1853,7 @@ static int parse_db(const char *seq, const char *db, int L, std::vector<int16_t>
 
 static thread_local bool g_ws_locked_by_me = false;     // rafft_expand_node holds ws_mu across its nested evaluation
 
-static int eval_structures_impl(int n, const char *const *seqs, const char *const *dbs, int *dcal_out, int *status_out, double temp = 37.0)
+static int eval_structures_impl(int n, const char *const *seqs, const char *const *dbs, int *dcal_out, int *status_out, double temp = 37.0, int *guessed_out = nullptr)
 {
     if (int rc = init_ctx(-1)) return rc;
     drain();                                   // (g.mu is held: nothing new is submitted meanwhile)
@@ -1867,21 +1885,23 @@ static int eval_structures_impl(int n, const char *const *seqs, const char *cons
         }
         if (status[i]) len[i] = 0;
     }
-    void *dc = nullptr, *dp = nullptr, *doff = nullptr, *dlen = nullptr, *dout = nullptr, *dst = nullptr;
+    void *dc = nullptr, *dp = nullptr, *doff = nullptr, *dlen = nullptr, *dout = nullptr, *dst = nullptr, *dg = nullptr;
     HIPCHK(hipMalloc(&dc, tot + 16)); HIPCHK(hipMalloc(&dp, (tot + 16) * 2)); HIPCHK(hipMalloc(&doff, n * 8 + 8));
-    HIPCHK(hipMalloc(&dlen, n * 4 + 4)); HIPCHK(hipMalloc(&dout, n * 4 + 4)); HIPCHK(hipMalloc(&dst, n * 4 + 4));
+    HIPCHK(hipMalloc(&dlen, n * 4 + 4)); HIPCHK(hipMalloc(&dout, n * 4 + 4)); HIPCHK(hipMalloc(&dst, n * 4 + 4)); HIPCHK(hipMalloc(&dg, n * 4 + 4));
     HIPCHK(hipMemcpy(dc, codes.data(), tot + 16, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dp, pts.data(), (tot + 16) * 2, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(doff, off.data(), n * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dlen, len.data(), n * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(eval_kernel, dim3(n), dim3(64), 0, g.ws[0].stream, g.T, n, (const uint8_t *)dc, (const int16_t *)dp,
-                       (const long long *)doff, (const int *)dlen, (int *)dout, (int *)dst);
+                       (const long long *)doff, (const int *)dlen, (int *)dout, (int *)dst, (int *)dg);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(g.ws[0].stream));
     std::vector<int> st2(n);
     HIPCHK(hipMemcpy(dcal_out, dout, n * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(st2.data(), dst, n * 4, hipMemcpyDeviceToHost));
-    for (void *q : {dc, dp, doff, dlen, dout, dst}) { hipError_t fe = hipFree(q); (void)fe; }
+    if (guessed_out) HIPCHK(hipMemcpy(guessed_out, dg, n * 4, hipMemcpyDeviceToHost));
+    for (void *q : {dc, dp, doff, dlen, dout, dst, dg}) { hipError_t fe = hipFree(q); (void)fe; }
+    if (guessed_out) for (int i = 0; i < n; i++) if (status[i]) guessed_out[i] = 0;
     int worst = 0;
     for (int i = 0; i < n; i++) {
         int s = status[i] ? status[i] : st2[i];
@@ -1907,6 +1927,21 @@ int rafft_eval_structures_at(double temp, int n, const char *const *seqs, const 
 {
     std::lock_guard<std::mutex> lk(g.mu);
     return eval_structures_impl(n, seqs, dbs, dcal_out, status_out, temp);
+}
+
+int rafft_eval_structures_info(int n, const char *const *seqs, const char *const *dbs, int *dcal_out, int *status_out, int *guessed_out)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    return eval_structures_impl(n, seqs, dbs, dcal_out, status_out, 37.0, guessed_out);
+}
+
+int rafft_params_unpinned(int counts[3])
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!counts) return fail(RAFFT_ERR_PARAM, "null argument");
+    counts[0] = counts[1] = counts[2] = 0;
+    if (param_set().builtin_set) rafft_par::builtin_unpinned_counts(counts);
+    return 0;
 }
 
 // ---- energy parameters (no GPU needed to load, inspect or save a parameter set; the upload happens with the next fold)

@@ -18,6 +18,10 @@ struct SmallT {
     int16_t d5[7][5], d3[7][5];
     int32_t hairpin[31], bulge[31], interior[31];
     int32_t ml_base, ml_closing, ml_intern, ninio, max_ninio, term_au;
+    // 1 with the built-in tables: bit 0 of an entry of the interior-loop tables (int11, int21, int22, mmI, mm1n, mm23, bulge,
+    // interior) then says "rule / model value, no reference-held energy row exercises it" (the values themselves are multiples
+    // of 10); 0 with a loaded parameter file, whose every entry is ViennaRNA's (rafft_params.h: scaled_tables)
+    int32_t lsb, pad_lsb_[3];
     // special hairpins (tri-, tetra-, hexaloops) in one open-addressing hash table: key = 3 bits per base of
     // the loop with its closing pair, tagged with the loop size in bits 28..; 0 = empty slot
     uint32_t sp_key[128]; int32_t sp_e[128];
@@ -73,13 +77,16 @@ __device__ inline int e_hairpin(const SmallT *T, const BigT *B, int size, int ty
     return e + T->mmH[type][S[ci + 1]][S[cj - 1]];
 }
 
+// `g`: set when the value read is a rule / model value of the built-in tables (SmallT::lsb)
 __device__ inline int e_intloop(const SmallT *T, const BigT *B, int n1, int n2, int type, int type2,
-                                int si1, int sj1, int sp1, int sq1)
+                                int si1, int sj1, int sp1, int sq1, int &g)
 {
+    const int lsb = T->lsb;
+#define RAFFT_TV(x) ([&](int v_) { g |= v_ & lsb; return v_ & ~lsb; }((int)(x)))
     int nl = n1 > n2 ? n1 : n2, ns = n1 > n2 ? n2 : n1, e, u;
     if (nl == 0) return T->stack[type][type2];
     if (ns == 0) {
-        e = (nl <= 30) ? T->bulge[nl] : T->bulge[30] + B->logext[nl];
+        e = (nl <= 30) ? RAFFT_TV(T->bulge[nl]) : RAFFT_TV(T->bulge[30]) + B->logext[nl];
         if (nl == 1) e += T->stack[type][type2];
         else {
             if (type > 2) e += T->term_au;
@@ -88,30 +95,31 @@ __device__ inline int e_intloop(const SmallT *T, const BigT *B, int n1, int n2, 
         return e;
     }
     if (ns == 1) {
-        if (nl == 1) return B->int11[type][type2][si1][sj1];
+        if (nl == 1) return RAFFT_TV(B->int11[type][type2][si1][sj1]);
         if (nl == 2) {
-            if (n1 == 1) return B->int21[type][type2][si1][sq1][sj1];
-            return B->int21[type2][type][sq1][si1][sp1];
+            if (n1 == 1) return RAFFT_TV(B->int21[type][type2][si1][sq1][sj1]);
+            return RAFFT_TV(B->int21[type2][type][sq1][si1][sp1]);
         }
         u = nl + 1;
-        e = (u <= 30) ? T->interior[u] : T->interior[30] + B->logext[u];
+        e = (u <= 30) ? RAFFT_TV(T->interior[u]) : RAFFT_TV(T->interior[30]) + B->logext[u];
         e += min(T->max_ninio, (nl - ns) * T->ninio);
-        e += T->mm1n[type][si1][sj1] + T->mm1n[type2][sq1][sp1];
+        e += RAFFT_TV(T->mm1n[type][si1][sj1]) + RAFFT_TV(T->mm1n[type2][sq1][sp1]);
         return e;
     }
     if (ns == 2) {
-        if (nl == 2) return B->int22[type][type2][si1][sp1][sq1][sj1];
+        if (nl == 2) return RAFFT_TV(B->int22[type][type2][si1][sp1][sq1][sj1]);
         if (nl == 3) {
-            e = T->interior[5] + T->ninio;
-            e += T->mm23[type][si1][sj1] + T->mm23[type2][sq1][sp1];
+            e = RAFFT_TV(T->interior[5]) + T->ninio;
+            e += RAFFT_TV(T->mm23[type][si1][sj1]) + RAFFT_TV(T->mm23[type2][sq1][sp1]);
             return e;
         }
     }
     u = nl + ns;
-    e = (u <= 30) ? T->interior[u] : T->interior[30] + B->logext[u];
+    e = (u <= 30) ? RAFFT_TV(T->interior[u]) : RAFFT_TV(T->interior[30]) + B->logext[u];
     e += min(T->max_ninio, (nl - ns) * T->ninio);
-    e += T->mmI[type][si1][sj1] + T->mmI[type2][sq1][sp1];
+    e += RAFFT_TV(T->mmI[type][si1][sj1]) + RAFFT_TV(T->mmI[type2][sq1][sp1]);
     return e;
+#undef RAFFT_TV
 }
 
 // si1/sj1 < 0: neighbour does not exist (sequence end)
@@ -139,14 +147,14 @@ __device__ inline int loop_energy(const SmallT *T, const BigT *B, const uint8_t 
             int q = pv(p);
             if (q < 0) { p++; continue; }
             int tt = pair_type(S[p], S[q]);
-            if (!tt) { *bad = 1; return 0; }
+            if (!tt) { *bad |= 1; return 0; }
             e += e_stem(T, tt, p > 0 ? (int)S[p - 1] : -1, q < L - 1 ? (int)S[q + 1] : -1, true);
             p = q + 1;
         }
         return e;
     }
     int type = pair_type(S[ci], S[cj]);
-    if (!type) { *bad = 1; return 0; }
+    if (!type) { *bad |= 1; return 0; }
     int nbr = 0, p1 = 0, q1 = 0;
     for (int p = ci + 1; p < cj;) {
         int q = pv(p);
@@ -158,15 +166,18 @@ __device__ inline int loop_energy(const SmallT *T, const BigT *B, const uint8_t 
     if (nbr == 0) return e_hairpin(T, B, cj - ci - 1, type, S, ci, cj);
     if (nbr == 1) {
         int t2 = pair_type(S[p1], S[q1]);
-        if (!t2) { *bad = 1; return 0; }
-        return e_intloop(T, B, p1 - ci - 1, cj - q1 - 1, type, rtype(t2), S[ci + 1], S[cj - 1], S[p1 - 1], S[q1 + 1]);
+        if (!t2) { *bad |= 1; return 0; }
+        int g = 0;
+        const int e1 = e_intloop(T, B, p1 - ci - 1, cj - q1 - 1, type, rtype(t2), S[ci + 1], S[cj - 1], S[p1 - 1], S[q1 + 1], g);
+        if (g) *bad |= 2;                 // (bit 1: not an error - the loop's energy involves a rule / model value of the built-in tables)
+        return e1;
     }
     int e = 0, u = cj - ci - 1;
     for (int p = ci + 1; p < cj;) {
         int q = pv(p);
         if (q < 0) { p++; continue; }
         int tt = pair_type(S[p], S[q]);
-        if (!tt) { *bad = 1; return 0; }
+        if (!tt) { *bad |= 1; return 0; }
         e += e_stem(T, tt, S[p - 1], S[q + 1], false);
         u -= q - p + 1;
         p = q + 1;
@@ -214,7 +225,7 @@ struct BrList {
     }
 };
 
-__device__ inline int loop_energy_br(const SmallT *T, const BigT *B, const uint8_t *S, int L, int ci, int cj, const BrList &bl)
+__device__ inline int loop_energy_br(const SmallT *T, const BigT *B, const uint8_t *S, int L, int ci, int cj, const BrList &bl, int &g)
 {
     const int k = bl.count();
     if (ci < 0) {
@@ -231,7 +242,7 @@ __device__ inline int loop_energy_br(const SmallT *T, const BigT *B, const uint8
     if (k == 1) {
         int p, q;
         bl.get(0, p, q);
-        return e_intloop(T, B, p - ci - 1, cj - q - 1, type, rtype(pair_type(S[p], S[q])), S[ci + 1], S[cj - 1], S[p - 1], S[q + 1]);
+        return e_intloop(T, B, p - ci - 1, cj - q - 1, type, rtype(pair_type(S[p], S[q])), S[ci + 1], S[cj - 1], S[p - 1], S[q + 1], g);
     }
     int e = 0, u = cj - ci - 1;
     for (int i = 0; i < k; i++) {
@@ -248,7 +259,7 @@ __device__ inline int loop_energy_br(const SmallT *T, const BigT *B, const uint8
 // terms of branches < i as exterior-loop / multiloop branches, psp[i] = sum of their spans.  O(1) per loop
 // whatever the number of branches; integer sums, so identical to loop_energy_br.
 struct BrPrefix { const int *pe_ext, *pe_ml; const uint16_t *psp; };
-__device__ inline int loop_energy_pre(const SmallT *T, const BigT *B, const uint8_t *S, int L, int ci, int cj, const BrList &bl, const BrPrefix &pf)
+__device__ inline int loop_energy_pre(const SmallT *T, const BigT *B, const uint8_t *S, int L, int ci, int cj, const BrList &bl, const BrPrefix &pf, int &g)
 {
     const int k = bl.count();
     if (ci < 0) {
@@ -262,7 +273,7 @@ __device__ inline int loop_energy_pre(const SmallT *T, const BigT *B, const uint
     if (k == 1) {
         int p, q;
         bl.get(0, p, q);
-        return e_intloop(T, B, p - ci - 1, cj - q - 1, type, rtype(pair_type(S[p], S[q])), S[ci + 1], S[cj - 1], S[p - 1], S[q + 1]);
+        return e_intloop(T, B, p - ci - 1, cj - q - 1, type, rtype(pair_type(S[p], S[q])), S[ci + 1], S[cj - 1], S[p - 1], S[q + 1], g);
     }
     int e = pf.pe_ml[bl.a1] - pf.pe_ml[bl.a0] + pf.pe_ml[bl.b1] - pf.pe_ml[bl.b0];
     int u = cj - ci - 1 - ((int)pf.psp[bl.a1] - (int)pf.psp[bl.a0] + (int)pf.psp[bl.b1] - (int)pf.psp[bl.b0]);

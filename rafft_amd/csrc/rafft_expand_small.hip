@@ -76,12 +76,13 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
     unsigned long long *ck = (unsigned long long *)(lds + LY::off_ck);
     double *val = (double *)(lds + LY::off_val);
 
-    const unsigned n_items = d.c->n_work[cls];
+    const unsigned n_items = d.c->n_work[cls].v;
     if (diag == 3) return;
     const unsigned gw = blockIdx.x * SM_WG_WAVES + wv, n_waves = gridDim.x * SM_WG_WAVES;
     if (gw == 0 && lane == 0) d.c->n_mat = 0;                // the beam step that follows counts its new structures here
     const int shard = gw & (NSHARD - 1);
     unsigned long long st_items = 0, st_n = 0, st_lags = 0, st_nbr = 0;      // statistics (lane 0 of every team)
+    unsigned int st_eval = 0, st_guess = 0, st_kguess = 0;                   // stem energies evaluated / involving a rule or model value / kept ones that do (every lane its own)
     const unsigned FETCH = n_items > 4u * TPW * n_waves ? (unsigned)d.fetch_bulk : 1u;            // groups of TPW regions claimed per atomic
     unsigned fetch_base = 0, fetch_left = 0;                                  // uniform across the wavefront
     int fshard = (int)(gw & (NSHARD - 1));
@@ -226,24 +227,25 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
         bool w_keep[2];
         {
             const bool anystem = act && (w_nb[0] > 0 || w_nb[1] > 0);
-            int e_old = 0;
+            int e_old = 0, g_old = 0;         // (g: the energy involves a rule / model value of the built-in tables - SmallT::lsb)
             if (anystem) {
                 const BrList all_br{brl, 0, nbr, 0, 0, 0, 0, 0};
-                e_old = loop_energy_pre(T, B, Sl, L, ci, cj, all_br, pf);      // the loop as it is (same for every stem)
+                e_old = loop_energy_pre(T, B, Sl, L, ci, cj, all_br, pf, g_old);      // the loop as it is (same for every stem)
             }
 #pragma unroll
             for (int s = 0; s < 2; s++) {
                 w_dd[s] = 0; w_keep[s] = false;
                 const int nb = w_nb[s];
                 if (act && nb > 0) {
+                    int g = g_old;
                     const int mi = w_mi[s], mj = w_mj[s];
                     const int a0 = pos[mi], b0 = pos[mj], ao = pos[mi - nb + 1], bo = pos[mj + nb - 1];
                     int lo = br_lower(brl, nbr, a0), hi = br_lower(brl, nbr, b0);
                     const int lo_o = br_lower(brl, nbr, ao), hi_o = br_lower(brl, nbr, bo);
                     BrList outer{brl, 0, lo_o, hi_o, nbr, 1, ao, bo};
-                    int e_new = loop_energy_pre(T, B, Sl, L, ci, cj, outer, pf);
+                    int e_new = loop_energy_pre(T, B, Sl, L, ci, cj, outer, pf, g);
                     BrList inner{brl, lo, hi, 0, 0, 0, 0, 0};
-                    e_new += loop_energy_pre(T, B, Sl, L, a0, b0, inner, pf);
+                    e_new += loop_energy_pre(T, B, Sl, L, a0, b0, inner, pf, g);
                     int pa = a0, pb = b0, ty_in = pair_type(Sl[a0], Sl[b0]);
                     for (int t = 1; t < nb; t++) {
                         const int a = pos[mi - t], b = pos[mj + t];
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
                         else {
                             const int lo2 = br_lower(brl, nbr, a), hi2 = br_lower(brl, nbr, b);
                             BrList mid{brl, lo2, lo, hi, hi2, 1, pa, pb};
-                            e_new += loop_energy_pre(T, B, Sl, L, a, b, mid, pf);
+                            e_new += loop_energy_pre(T, B, Sl, L, a, b, mid, pf, g);
                             lo = lo2; hi = hi2;
                         }
                         pa = a; pb = b; ty_in = ty;
@@ -262,6 +264,7 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
                     w_dd[s] = ddc;
                     const double dE = dcal_to_energy(par_dcal + ddc) - par_e;
                     w_keep[s] = dE < d.min_nrj;                  // rafft/rafft.py:102
+                    st_eval++; st_guess += g ? 1 : 0; st_kguess += (g && w_keep[s]) ? 1 : 0;
                 }
             }
         }
@@ -380,6 +383,7 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
     for (int o = 32; o > 0; o >>= 1) {
         st_items += __shfl_xor(st_items, o, 64); st_n += __shfl_xor(st_n, o, 64);
         st_lags += __shfl_xor(st_lags, o, 64); st_nbr += __shfl_xor(st_nbr, o, 64);
+        st_eval += __shfl_xor(st_eval, o, 64); st_guess += __shfl_xor(st_guess, o, 64); st_kguess += __shfl_xor(st_kguess, o, 64);
     }
     if (lane == 0 && st_items) {
         Counters::StatLine *sl = &d.c->xstat[cls][gw & (NSHARD - 1)];
@@ -387,5 +391,10 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
         atomicAdd(&sl->n, st_n);
         atomicAdd(&sl->lags, st_lags);
         atomicAdd(&sl->nbr, st_nbr);
+        if (T->lsb && st_eval) {          // (built-in tables: stem energies evaluated / involving a rule or model value / kept ones that do)
+            atomicAdd(&sl->evals, (unsigned long long)st_eval);
+            if (st_guess) atomicAdd(&sl->guessed, (unsigned long long)st_guess);
+            if (st_kguess) atomicAdd(&sl->kept_guessed, (unsigned long long)st_kguess);
+        }
     }
 }

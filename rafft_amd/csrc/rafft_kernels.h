@@ -17,8 +17,9 @@
 //                       picks the candidate claims the slot (one compare-and-swap) and creates the region; everybody
 //                       else only notes the slot in its node list.  Loops reached along different paths (stems formed
 //                       in another order) still meet in the `loop table`, which sees created regions only.
-//   node lists nlist[]  the regions of a structure, in the reference's node_list order (rafft/rafft.py:187-190):
-//                       slot numbers when materialize_kernel writes them, canonical region ids once resolve_kernel has run
+//   node lists nlist[]  the regions of a structure, in the reference's node_list order (rafft/rafft.py:187-190): -(slot + 1) as
+//                       materialize_kernel writes them (the beam step reads the region id out of the slot when it first
+//                       visits the structure - by then dedupe_kernel has run), region ids without memoization and for roots
 //   pos arena           uint16 root positions of every node, ascending
 //   br arena            uint32 (p | q<<16) outermost pair of every branch, ascending
 //   cand arena          32-byte stem candidates, dE-sorted per canonical node
@@ -78,20 +79,24 @@ struct ProdEnt { uint32_t cnt; int32_t node; uint64_t off; };   // one productiv
 struct alignas(16) MatRec { int32_t sid, sq, L, dcal, nprod, pad; uint64_t combo, prod, pdb; };
 
 struct Counters {
-    // hot part: read back by the host once per folding step (first 64 bytes)
-    unsigned int n_work[NCLS];     // expand work items per size class (filled by dedupe_kernel)
+    // hot part: read back by the host once per folding step.  Every counter that the kernels of a step add to with a RETURNING atomic
+    // has a 64-byte line of its own: same-line atomics are served one after the other, 11.4 ns each chip-wide
+    // (tools/micro/atomic_spacing.hip) - a beam step of 11 500 sequences does 23 000 of them on n_struct and n_mat alone.
     unsigned int n_mat;            // structures to materialize (filled by beam_step_kernel)
-    unsigned int pad_[6];
     unsigned int overflow;         // bit mask of which arena overflowed
     unsigned int n_done;
     unsigned int max_nprod;        // largest number of productive regions seen in one structure
-    unsigned long long n_struct, seen_top, trec_n, tsid_top;
+    unsigned int pad0_[12];
+    unsigned long long n_struct, pad1_[7];
+    unsigned long long trec_n, tsid_top, pad2_[6];       // (one finishing sequence adds to both)
+    unsigned long long seen_top, pad3_[7];
+    struct WorkCtr { unsigned int v; unsigned int pad[15]; } n_work[NCLS];     // expand work items per size class (filled by dedupe_kernel)
     // statistics
     unsigned long long n_expand, sum_n, sum_lags, n_children, sum_struct_len, n_alias, sum_nbr;
     unsigned long long cls_items[NCLS], cls_sum_n[NCLS], cls_sum_lags[NCLS];   // per size class
     // sharded bump pointers of the arenas filled by materialize / expand
     ShardCtr node[NSHARD], pos[NSHARD], br[NSHARD], db[NSHARD], cand[NSHARD], node_prev[NSHARD], prod[NSHARD];
-    ShardCtr nlist[NSHARD], nlist_prev[NSHARD];     // node-list entries (one per region of a structure; `node` counts the regions CREATED)
+    ShardCtr nlist[NSHARD];      // node-list entries (one per region of a structure; `node` counts the regions CREATED)
     // statistics the kernels add to once per wavefront / workgroup: one 64-byte line per (size class, shard), summed by the
     // host at the end of the wave.  (As single counters they were a same-address atomic storm at the end of every expand
     // launch - 3000-4000 wavefronts x 7 atomics on one line - a fixed 150-300 us per launch.)
@@ -102,7 +107,7 @@ struct Counters {
     ShardCtr wcur[NCLS][NSHARD];
     unsigned long long wdone[NCLS];           // bit s: the last chunk of shard s has been claimed
     unsigned long long wdone_pad[8 - NCLS];
-    struct StatLine { unsigned long long items, n, lags, nbr, alias, children, struct_len, pad; } xstat[NCLS][NSHARD];
+    struct StatLine { unsigned long long items, n, lags, nbr, alias, children, struct_len, evals, guessed, kept_guessed, pad[6]; } xstat[NCLS][NSHARD];
 };
 
 enum { OVF_STRUCT = 1, OVF_NODE = 2, OVF_POS = 4, OVF_DB = 8, OVF_CAND = 16, OVF_SEEN = 32,
@@ -144,7 +149,7 @@ struct Dev {
     uint32_t nd_cap;
     uint64_t nd_base, nd_shard_cap, pos_base, pos_shard_cap, br_shard_cap, db_base, db_shard_cap, cand_shard_cap;
     NodeRec *nd;                 // one 64-byte record per region (one cache line: header reads and writes are one transaction)
-    int *nlist;                  // node lists of the structures (st.node0, st.nnodes): canonical region ids (see the file header)
+    int *nlist;                  // node lists of the structures (st.node0, st.nnodes): region id, or -(child slot + 1) (see the file header)
     unsigned long long *cslot;   // child slots, one word per candidate: inner | outer << 32; a half is 0 (nobody has asked yet), bit 31 alone
                                  // (claimed: being created in this step) or bit 31 | (region id + 1)
     uint32_t *nd_slot;           // the slot a created region hangs in (dedupe_kernel points it at the canonical region when the loop is known already)

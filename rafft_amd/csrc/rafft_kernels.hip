@@ -248,8 +248,11 @@ __device__ __forceinline__ void wave_sync()
 // PROD: the production build of a class without FFT buffers (no seam, no forced FFT, no negative weights, no diagnostics): the
 // debug-seam stores, the phase stamps, the FFT and the cell-by-cell window_slide are compiled out - fewer live registers, fewer spills.
 // PROD 2: the same for a class that keeps its FFT (regions beyond Dev::direct_n positions): only the diagnostics go.
+// PROD 3 (with LONGSEQ 2): the same kernel as the class for regions beyond 4096 positions, compiled for FOUR wavefronts per SIMD: it
+//         serves the regions of 1025-4096 positions of ordinary sequences when the host routes them here (RAFFT_C3_DIRECT, class_cfg) -
+//         ~50 KiB of LDS instead of the 150 KiB of the FFT plan, two or three workgroups per CU instead of one.
 template <int NT, bool TAB_LDS, int WPB, int LONGSEQ = 0, int PROD = 0>
-__global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND64_WAVES) : NT == 256 ? (PROD == 1 ? RAFFT_EXPAND256_PROD_WAVES : 3) : 2)) void expand_kernel(Dev d, int cls_arg, int Pmax, int Lmax, int nmax, int brmax, int Kmax)
+__global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND64_WAVES) : NT == 256 ? (PROD == 1 ? RAFFT_EXPAND256_PROD_WAVES : 3) : (PROD == 3 ? 4 : 2))) void expand_kernel(Dev d, int cls_arg, int Pmax, int Lmax, int nmax, int brmax, int Kmax)
 {
     const int cls = cls_arg & 0xFF;
     const DebugOut dbg = PROD ? DebugOut{} : d.dbg;
@@ -304,10 +307,11 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
         int tp = pair_type(a, b);
         wtab[tid] = (tp == 5 || tp == 6) ? d.au : (tp == 1 || tp == 2) ? d.gc : (tp == 3 || tp == 4) ? d.gu : 0.0;
     }
-    const unsigned n_items = d.c->n_work[cls];
+    const unsigned n_items = d.c->n_work[cls].v;
     if (gteam == 0 && tid == 0) d.c->n_mat = 0;                // the beam step that follows counts its new structures here
     const int shard = gteam & (NSHARD - 1);
     unsigned long long st_items = 0, st_n = 0, st_lags = 0, st_nbr = 0;   // per-block statistics
+    unsigned int st_eval = 0, st_guess = 0, st_kguess = 0;                // per wavefront: stem energies evaluated / involving a rule or model value / kept ones that do
 
     // Work items are fetched FETCH at a time and candidate slots are reserved in slabs, so that the
     // two atomics with a returned value (a full L2 round trip each) are paid once per several regions.
@@ -375,13 +379,13 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
         for (int rep_ = 0; rep_ < 1 + ((rep >> 4) & 1); rep_++) {
         for (int t = tid; t < n; t += NT) {
             const int p = posg[t];
-            if (LONGSEQ == 0 && d.pos_packed) { pos[t] = (uint16_t)(p & 0x0FFF); code[t] = (uint8_t)(p >> 12); }   // (Dev::pos_packed)
+            if (d.pos_packed) { pos[t] = (uint16_t)(p & 0x0FFF); code[t] = (uint8_t)(p >> 12); }   // (Dev::pos_packed: no sequence beyond 4096 nt in this wave)
             else { pos[t] = (uint16_t)p; code[t] = codes[p]; }
         }
         if (LONGSEQ == 0) {   // bases: only the span of this loop is ever looked at (closing pair, its neighbours inside, branches)
             for (int x = sx0 + tid; x < sx1; x += NT) Sl_lds[x - sx0] = codes[x];
         }
-        for (int t = tid; t < nbr; t += NT) brl[t] = (LONGSEQ == 0 && d.pos_packed) ? (brg[t] & 0x0FFF0FFFu) : brg[t];   // (Dev::pos_packed: the codes ride along)
+        for (int t = tid; t < nbr; t += NT) brl[t] = d.pos_packed ? (brg[t] & 0x0FFF0FFFu) : brg[t];   // (Dev::pos_packed: the codes ride along)
         ESYNC();
         }
 
@@ -919,21 +923,23 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
         FSTAMP(10);  // (dE: branch prefix sums)
         const BrPrefix pf{pe_ext, pe_ml, psp};
         const BrList all_br{brl, 0, nbr, 0, 0, 0, 0, 0};
-        const int e_old = loop_energy_pre(T, B, Sl, L, ci, cj, all_br, pf);      // the loop as it is (same for every stem)
+        int g_old = 0;           // (g: the energy involves a rule / model value of the built-in tables - SmallT::lsb)
+        const int e_old = loop_energy_pre(T, B, Sl, L, ci, cj, all_br, pf, g_old);      // the loop as it is (same for every stem)
         for (int rep_ = 0; rep_ < 1 + ((rep >> 3) & 1); rep_++)
             for (int r = tid; r < Kp; r += NT) {
                 const int nb = wnb[r];
                 keep[r] = 0;
                 dd[r] = 0;
                 if (nb > 0) {
+                    int g = g_old;
                     const int mi = wmi[r], mj = wmj[r];
                     const int a0 = pos[mi], b0 = pos[mj], ao = pos[mi - nb + 1], bo = pos[mj + nb - 1];
                     int lo = br_lower(brl, nbr, a0), hi = br_lower(brl, nbr, b0);
                     const int lo_o = br_lower(brl, nbr, ao), hi_o = br_lower(brl, nbr, bo);
                     BrList outer{brl, 0, lo_o, hi_o, nbr, 1, ao, bo};
-                    int e_new = loop_energy_pre(T, B, Sl, L, ci, cj, outer, pf);
+                    int e_new = loop_energy_pre(T, B, Sl, L, ci, cj, outer, pf, g);
                     BrList inner{brl, lo, hi, 0, 0, 0, 0, 0};
-                    e_new += loop_energy_pre(T, B, Sl, L, a0, b0, inner, pf);
+                    e_new += loop_energy_pre(T, B, Sl, L, a0, b0, inner, pf, g);
                     int pa = a0, pb = b0, ty_in = pair_type(Sl[a0], Sl[b0]);
                     for (int t = 1; t < nb; t++) {
                         const int a = pos[mi - t], b = pos[mj + t];
@@ -943,7 +949,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                         else {
                             const int lo2 = br_lower(brl, nbr, a), hi2 = br_lower(brl, nbr, b);
                             BrList mid{brl, lo2, lo, hi, hi2, 1, pa, pb};
-                            e_new += loop_energy_pre(T, B, Sl, L, a, b, mid, pf);
+                            e_new += loop_energy_pre(T, B, Sl, L, a, b, mid, pf, g);
                             lo = lo2; hi = hi2;
                         }
                         pa = a; pb = b; ty_in = ty;
@@ -951,7 +957,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                     const int ddc = e_new - e_old;
                     dd[r] = ddc;
                     const double dE = dcal_to_energy(par_dcal + ddc) - par_e;
-                    keep[r] = (dE < d.min_nrj) ? 1 : 0;
+                    keep[r] = (uint16_t)(((dE < d.min_nrj) ? 1 : 0) | (g ? 2 : 0) | 4);     // bit 0 kept, bit 1 involves a rule / model value, bit 2 evaluated
                     if (dbg.ddcal) dbg.ddcal[r] = ddc;
                 } else if (dbg.ddcal)
                     dbg.ddcal[r] = INT_MIN;
@@ -968,9 +974,13 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
             const int lane = tid & 63, wv = tid >> 6;
             for (int base = 0; base < Kp; base += NT) {
                 const int r = base + tid;
-                const int f = (r < Kp) ? keep[r] : 0;
+                const int kf = (r < Kp) ? keep[r] : 0;
+                const int f = kf & 1;
                 ESYNC();                      // everyone has read keep[] of this slab
                 const unsigned long long bal = __ballot(f != 0);
+                if (T->lsb) {                 // (built-in tables: how many stem energies of this launch involved a rule / model value)
+                    st_eval += __popcll(__ballot((kf & 4) != 0)); st_guess += __popcll(__ballot((kf & 6) == 6)); st_kguess += __popcll(__ballot((kf & 3) == 3));
+                }
                 int pre = __popcll(bal & ((1ULL << lane) - 1));
                 if (NT > 64) {
                     if (lane == 0) wave_tot[wv] = __popcll(bal);
@@ -1084,6 +1094,12 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
         atomicAdd(&sl->lags, st_lags);
         atomicAdd(&sl->nbr, st_nbr);
     }
+    if ((threadIdx.x & 63) == 0 && st_eval) {       // (every wavefront of a wide team counted its own lanes)
+        Counters::StatLine *sl = &d.c->xstat[cls][(gteam + (threadIdx.x >> 6)) & (NSHARD - 1)];
+        atomicAdd(&sl->evals, (unsigned long long)st_eval);
+        if (st_guess) atomicAdd(&sl->guessed, (unsigned long long)st_guess);
+        if (st_kguess) atomicAdd(&sl->kept_guessed, (unsigned long long)st_kguess);
+    }
 }
 
 #include "rafft_expand_small.hip"
@@ -1162,12 +1178,18 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int sq = blockIdx.x;
     // snapshot of the region allocators: whatever materialize adds after this kernel is "new"
-    if (sq == 0 && tid < NSHARD) { d.c->node_prev[tid].v = d.c->node[tid].v; d.c->nlist_prev[tid].v = d.c->nlist[tid].v; }
+    if (sq == 0 && tid < NSHARD) d.c->node_prev[tid].v = d.c->node[tid].v;
     // the expand kernels of this step are done with their work lists: reset them for dedupe_kernel / the next step
-    if (sq == 0 && tid < NCLS) d.c->n_work[tid] = 0;
+    if (sq == 0 && tid < NCLS) d.c->n_work[tid].v = 0;
     if (sq == 0) for (int i = tid; i < NCLS * NSHARD; i += BS_NT) d.c->wcur[i / NSHARD][i % NSHARD].v = 0;
     if (sq == 0 && tid < NCLS) d.c->wdone[tid] = 0;
     if (d.done[sq]) return;
+    // an arena overflowed while the last step's structures were materialized: some child slots were claimed and never filled, some
+    // node lists point at them.  Nothing of that step may be read; the host sees the flag in this step's read-back and regrows.
+    // (one thread looks: other workgroups of this launch may set the flag while this one starts)
+    if (tid == 0) sh[27] = d.c->overflow != 0 ? 1 : 0;
+    __syncthreads();
+    if (sh[27]) return;
     const bool prof = !PROD && d.prof && (d.prof_seq < 0 || sq == d.prof_seq) && tid == 0;   // diagnostic stamps (RAFFT_TRACE=3; RAFFT_PROF_SEQ=-1: summed over all sequences)
     unsigned long long tprev = prof ? clock64() : 0;
     unsigned long long *const prof_ws = PROD ? nullptr : d.prof_ws;
@@ -1241,7 +1263,10 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
                     unsigned long long coff = 0;
                     if (i < nn) {
                         cn = d.nlist[node0 + i];
-                        cnt = d.nd[cn].ncand;
+                        // (written by materialize_kernel as -(slot + 1): the region that hangs in that child slot - created there by
+                        //  whichever beam member asked first, or the known loop dedupe_kernel found for it)
+                        if (cn < 0) cn = (int)(((const uint32_t *)d.cslot)[-cn - 1] & 0x7FFFFFFFu) - 1;
+                        cnt = cn >= 0 ? d.nd[cn].ncand : 0;
                         if (cnt > 0) {
                             coff = d.nd[cn].cand;
                             const Cand *cp = &d.cand[coff];
@@ -1764,7 +1789,7 @@ __global__ __launch_bounds__(MAT_NT, RAFFT_MAT_WAVES) void materialize_kernel(De
     // pass 1: sizes, and who creates what.  A child region is a function of (parent region, candidate, side) alone
     // (rafft/rafft.py:127-152, rafft/utils.py:141-152): the beam member whose compare-and-swap finds the slot empty creates it, everybody
     // else - the other members of this step that picked the same stem, and every later step - only notes the slot number in its node
-    // list (resolve_kernel turns slot numbers into region ids once this kernel and dedupe_kernel are done: nobody reads a slot's
+    // list (the next beam step reads the region id out of the slot, once this kernel and dedupe_kernel are done: nobody reads a slot's
     // value in here).  Without memoization (min_nrj != 0: a region's filter depends on its parent's energy) every member creates its own.
     // (a single tile - the usual case - keeps its descriptors in registers for pass 2; with several the claims ride in sel[])
     const int TILE = d.mat_tile;          // 64; smaller only in tests (several tiles per structure)
@@ -1860,9 +1885,9 @@ __global__ __launch_bounds__(MAT_NT, RAFFT_MAT_WAVES) void materialize_kernel(De
                     d.nd[nid].ci = md.a0; d.nd[nid].cj = md.b0; d.nd[nid].br = boff; d.nd[nid].nbr = md.nbr_in;
                     d.nd[nid].ncand = -1; d.nd[nid].cand = 0;
                     if (memo) { d.nd_slot[nid] = (uint32_t)slot0; ((uint32_t *)d.cslot)[slot0] = (uint32_t)(nid + 1) | 0x80000000u; }
-                    d.nlist[le] = memo ? slot0 : nid;
+                    d.nlist[le] = memo ? -(slot0 + 1) : nid;
                     nid++;
-                } else d.nlist[le] = slot0;
+                } else d.nlist[le] = -(slot0 + 1);
                 le++;
             }
             if (md.flags & 2) {
@@ -1872,8 +1897,8 @@ __global__ __launch_bounds__(MAT_NT, RAFFT_MAT_WAVES) void materialize_kernel(De
                     d.nd[nid].ci = md.ci; d.nd[nid].cj = md.cj; d.nd[nid].br = boff + cb_in; d.nd[nid].nbr = md.nbr_out;
                     d.nd[nid].ncand = -1; d.nd[nid].cand = 0;
                     if (memo) { d.nd_slot[nid] = (uint32_t)(slot0 + 1); ((uint32_t *)d.cslot)[slot0 + 1] = (uint32_t)(nid + 1) | 0x80000000u; }
-                    d.nlist[le] = memo ? slot0 + 1 : nid;
-                } else d.nlist[le] = slot0 + 1;
+                    d.nlist[le] = memo ? -(slot0 + 2) : nid;
+                } else d.nlist[le] = -(slot0 + 2);
             }
         }
         __syncthreads();
@@ -2013,7 +2038,7 @@ __global__ __launch_bounds__(DEDUPE_NT) void dedupe_kernel(Dev d)
         if (tid < NCLS) {
             unsigned int tot = 0;
             for (int w = 0; w < DEDUPE_NT / 64; w++) tot += wcnt[w][tid];
-            unsigned int b = tot ? atomicAdd(&d.c->n_work[tid], tot) : 0u;
+            unsigned int b = tot ? atomicAdd(&d.c->n_work[tid].v, tot) : 0u;
             for (int w = 0; w < DEDUPE_NT / 64; w++) { wbase[w][tid] = b; b += wcnt[w][tid]; }
         }
         __syncthreads();
@@ -2024,32 +2049,6 @@ __global__ __launch_bounds__(DEDUPE_NT) void dedupe_kernel(Dev d)
     }
     for (int o = 32; o > 0; o >>= 1) aliases += __shfl_xor(aliases, o, 64);
     if (lane == 0 && aliases) atomicAdd(&d.c->xstat[0][blockIdx.x & (NSHARD - 1)].alias, aliases);
-}
-
-// One thread per node-list entry written in this step: slot number -> region id.  Runs after dedupe_kernel, when every slot of the
-// step holds the id of a canonical region (the one materialize_kernel created in it, or the known loop dedupe_kernel found for it).
-__global__ __launch_bounds__(DEDUPE_NT) void resolve_kernel(Dev d)
-{
-    __shared__ unsigned int pre[NSHARD + 1];
-    __shared__ unsigned int prev[NSHARD];
-    const int tid = threadIdx.x;
-    if (d.c->overflow) return;
-    if (tid < NSHARD) {
-        prev[tid] = (unsigned int)d.c->nlist_prev[tid].v;
-        pre[tid + 1] = (unsigned int)(d.c->nlist[tid].v - d.c->nlist_prev[tid].v);
-    }
-    if (tid == 0) pre[0] = 0;
-    __syncthreads();
-    if (tid == 0) for (int i = 1; i <= NSHARD; i++) pre[i] += pre[i - 1];
-    __syncthreads();
-    const unsigned int total = pre[NSHARD];
-    const unsigned int stride = gridDim.x * blockDim.x;
-    for (unsigned int f = blockIdx.x * blockDim.x + tid; f < total; f += stride) {
-        int lo = 0, hi = NSHARD;             // shard with pre[lo] <= f < pre[lo+1]
-        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (pre[mid] <= f) lo = mid; else hi = mid; }
-        const unsigned long long e = d.nd_base + (unsigned long long)lo * d.nd_shard_cap + prev[lo] + (f - pre[lo]);
-        d.nlist[e] = (int)(((const uint32_t *)d.cslot)[d.nlist[e]] & 0x7FFFFFFFu) - 1;
-    }
 }
 
 // ------------------------------------------------------------- init kernel
@@ -2078,7 +2077,7 @@ __global__ void init_roots_kernel(Dev d)
         d.seen_off[sq] = (uint64_t)sq * SEEN0; d.seen_cap[sq] = SEEN0; d.seen_cnt[sq] = 0;   // zeroed by the host memset
         if (L > 0) {
             int cls = node_class(L, L, 0, 0, d.cls1_P, d.cls1_br);
-            unsigned int w = atomicAdd(&d.c->n_work[cls], 1u);
+            unsigned int w = atomicAdd(&d.c->n_work[cls].v, 1u);
             d.work[cls][w] = sq;
         }
     }
@@ -2109,7 +2108,7 @@ __global__ void output_kernel(Dev d, int nrows, int nrec, const OutRec *recs, ch
 
 // one wavefront per structure: sum of loop energies (rafft/utils.py:135-138)
 __global__ __launch_bounds__(64) void eval_kernel(const EnergyTables *ET, int n, const uint8_t *codes, const int16_t *pts,
-                                                  const long long *off, const int *len, int *out, int *status)
+                                                  const long long *off, const int *len, int *out, int *status, int *guessed)
 {
     const int s = blockIdx.x, lane = threadIdx.x;
     if (s >= n) return;
@@ -2125,5 +2124,5 @@ __global__ __launch_bounds__(64) void eval_kernel(const EnergyTables *ET, int n,
         if (j > i) e += loop_energy(T, B, S, L, pv, i, j, &bad);
     }
     for (int o = 32; o > 0; o >>= 1) { e += __shfl_xor(e, o, 64); bad |= __shfl_xor(bad, o, 64); }
-    if (lane == 0) { out[s] = e; status[s] = bad ? 8 : 0; }
+    if (lane == 0) { out[s] = e; status[s] = (bad & 1) ? 8 : 0; if (guessed) guessed[s] = (bad >> 1) & 1; }
 }

@@ -36,6 +36,7 @@ struct SpecialLoop { std::string seq; int e37, dH; };
 // One parameter set in ViennaRNA's own array shapes (index 0 of a pair axis = no pair, of a base axis = N).
 struct ParamSet {
     bool has_dH = false;
+    bool builtin_set = false;          // the compiled-in tables: their rule / model entries are marked in the device tables (scaled_tables)
     std::string source = "built-in Turner 2004, 37 C (params/turner2004_tables.h)";
     int stack[2][NBP + 1][NBP + 1] = {};
     int hairpin[2][31] = {}, bulge[2][31] = {}, interior[2][31] = {};
@@ -79,6 +80,20 @@ inline void builtin(ParamSet &P)
     for (int i = 0; i < T04_N_TRILOOPS; i++) P.tri.push_back({t04_triloops_seq[i], t04_triloops_e[i], 0});
     for (int i = 0; i < T04_N_TETRALOOPS; i++) P.tetra.push_back({t04_tetraloops_seq[i], t04_tetraloops_e[i], 0});
     for (int i = 0; i < T04_N_HEXALOOPS; i++) P.hexa.push_back({t04_hexaloops_seq[i], t04_hexaloops_e[i], 0});
+    P.builtin_set = true;
+}
+
+// entries of the built-in interior-loop tables that no reference-held energy row exercises (rule / model values)
+inline void builtin_unpinned_counts(int out[3])
+{
+    out[0] = out[1] = out[2] = 0;
+    for (int t = 1; t < 7; t++) for (int u = 1; u < 7; u++) for (int a = 1; a < 5; a++) for (int b = 1; b < 5; b++) {
+        out[0] += !t04_int11_pinned[t][u][a][b];
+        for (int c = 1; c < 5; c++) {
+            out[1] += !t04_int21_pinned[t][u][a][b][c];
+            for (int e = 1; e < 5; e++) out[2] += !t04_int22_pinned[t][u][a][b][c][e];
+        }
+    }
 }
 
 // ---------------------------------------------------------------- reader
@@ -292,6 +307,7 @@ inline bool parse(const std::string &text, ParamSet &P, std::string &err)
     }
     if (P.tri.size() + P.tetra.size() + P.hexa.size() > 96) { err = "more than 96 special hairpin loops"; return false; }
     P.has_dH = all_dH;
+    P.builtin_set = false;             // every entry is the file's (sections it leaves out keep built-in values: they are not marked either)
     return true;
 }
 
@@ -432,6 +448,38 @@ inline bool scaled_tables(const ParamSet &P, double temp, EnergyTables *h, std::
         }
     }
     if (!ok) { err = "a table value does not fit 16 bits"; return false; }
+    // The built-in set at 37 C: bit 0 of an interior-loop table entry says "rule / model value: no reference-held energy row
+    // exercises it" (SmallT::lsb; the values are multiples of 10 dcal, the device strips the bit) - a fold can then say how many of
+    // its stem energies involved one.  A loaded file's entries are all ViennaRNA's: no marks.
+    h->s.lsb = 0;
+    if (P.builtin_set && at37) {
+        bool even = true;
+        for (int t = 1; t < 7 && even; t++) for (int u = 1; u < 7; u++) for (int a = 0; a < 5; a++) for (int b = 0; b < 5; b++) {
+            even &= !(h->b.int11[t][u][a][b] & 1);
+            for (int c = 0; c < 5; c++) { even &= !(h->b.int21[t][u][a][b][c] & 1); for (int d = 0; d < 5; d++) even &= !(h->b.int22[t][u][a][b][c][d] & 1); }
+        }
+        for (int t = 1; t < 7; t++) for (int a = 0; a < 5; a++) for (int b = 0; b < 5; b++) even &= !((h->s.mmI[t][a][b] | h->s.mm1n[t][a][b] | h->s.mm23[t][a][b]) & 1);
+        for (int i = 0; i < 31; i++) even &= !((h->s.bulge[i] | h->s.interior[i]) & 1);
+        if (even) {
+            h->s.lsb = 1;
+            for (int t = 1; t < 7; t++) for (int u = 1; u < 7; u++) for (int a = 0; a < 5; a++) for (int b = 0; b < 5; b++) {
+                h->b.int11[t][u][a][b] |= (int16_t)!t04_int11_pinned[t][u][a][b];
+                for (int c = 0; c < 5; c++) {
+                    h->b.int21[t][u][a][b][c] |= (int16_t)!t04_int21_pinned[t][u][a][b][c];
+                    for (int d = 0; d < 5; d++) h->b.int22[t][u][a][b][c][d] |= (int16_t)!t04_int22_pinned[t][u][a][b][c][d];
+                }
+            }
+            for (int t = 1; t < 7; t++) for (int a = 0; a < 5; a++) for (int b = 0; b < 5; b++) {
+                h->s.mmI[t][a][b] |= (int16_t)!t04_mismatch_interior_pinned[t][a][b];
+                h->s.mm1n[t][a][b] |= (int16_t)!t04_mismatch_interior_1n_pinned[t][a][b];
+                h->s.mm23[t][a][b] |= (int16_t)!t04_mismatch_interior_23_pinned[t][a][b];
+            }
+            for (int i = 1; i < 31; i++) {
+                if (h->s.bulge[i] < INF_) h->s.bulge[i] |= !t04_bulge_pinned[i];
+                if (h->s.interior[i] < INF_) h->s.interior[i] |= !t04_interior_pinned[i];
+            }
+        }
+    }
     h->s.ml_base = sc(P.ml_base[0], P.ml_base[1]); h->s.ml_closing = sc(P.ml_closing[0], P.ml_closing[1]);
     h->s.ml_intern = sc(P.ml_intern[0], P.ml_intern[1]);
     h->s.ninio = sc(P.ninio[0], P.ninio[1]); h->s.max_ninio = P.max_ninio;

@@ -55,6 +55,14 @@ def params_info():
     return {"source": buf.value.decode(), "has_enthalpies": bool(has.value)}
 
 
+def unpinned_entries():
+    """How many entries of the current 1x1 / 2x1 / 2x2 interior-loop tables are rule / model values that no reference-held
+    energy row exercises (the built-in set; all zero with a loaded ViennaRNA parameter file)."""
+    c = (C.c_int * 3)()
+    N.check(N.lib().rafft_params_unpinned(C.byref(c)))
+    return {"int11": c[0], "int21": c[1], "int22": c[2]}
+
+
 def param_value(table, index, enthalpy=False):
     v = C.c_int()
     N.check(N.lib().rafft_param_value(table.encode(), 1 if enthalpy else 0, int(index), C.byref(v)))

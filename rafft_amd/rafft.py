@@ -229,6 +229,20 @@ def eval_structures(seqs, dbs, temp=37.0):
     return list(out), list(st)
 
 
+def eval_structures_info(seqs, dbs):
+    """eval_structures at 37 C plus, per structure, whether its energy reads an entry of the BUILT-IN interior-loop tables that no
+    reference-held energy row exercises (a rule / model value - DESIGN.md 2.1): (dcal, status, guessed).  All zeros with a
+    loaded ViennaRNA parameter file, whose every entry is ViennaRNA's."""
+    L = N.lib()
+    _params_mod.ensure_default_params()
+    n = len(seqs)
+    a = (C.c_char_p * n)(*[s.encode() for s in seqs])
+    b = (C.c_char_p * n)(*[s.encode() for s in dbs])
+    out, st, gs = (C.c_int * n)(), (C.c_int * n)(), (C.c_int * n)()
+    N.check(L.rafft_eval_structures_info(n, a, b, out, st, gs))
+    return list(out), list(st), list(gs)
+
+
 def expand_node(seq, db, pos, nb_mode=100, min_hp=3, min_nrj=0.0, gc=3.0, au=2.0, gu=1.0):
     """Kernel-level seam (tests): same dict as oracle.expand_node."""
     L = N.lib()

@@ -94,4 +94,8 @@ def test_gpu_cfg5_graph_rate_matrix_and_kinetics():
     free = lambda p: float((p * (en + 0.61 * np.log(np.maximum(p, 1e-300)))).sum())
     f = [free(p) for p in P]
     assert all(b <= a + 1e-6 for a, b in zip(f, f[1:]))            # the free energy of the ensemble never rises
+    # the sparse integrator (host, SuperLU on the non-zeros) and the dense one (device, rocSOLVER getrf) are the same scheme
+    ta = np.array(rafft_kin.kinetics_gpu(traj, 30, 6, method="implicit", substeps=4)[0])
+    tb = np.array(rafft_kin.kinetics_gpu(traj, 30, 6, method="implicit-dense", substeps=4)[0])
+    assert np.abs(ta - tb).max() < 1e-7
     print(f"cfg5: fold {t_fold * 1e3:.1f} ms, {S} structures, rate matrix {t_rate * 1e3:.1f} ms, populations (40 times) {t_kin:.2f} s")

@@ -86,3 +86,71 @@ def test_gpu_switching_parameter_sets_and_temperatures(synthetic):
     assert [(x.str_struct, x.dcal) for x in rafft_amd.fold(s, 100, 10, 1000)] == base
     with pytest.raises(_native.RafftError):
         rafft_amd.fold(s, temp=25.0)
+
+
+def _oracle_tracks_the_interior_loop_tables_only():
+    """the oracle marks every unpinned entry of every table; the device marks the tables an interior loop reads (1x1, 2x1, 2x2,
+    the three interior mismatch tables, bulge / interior sizes): the others count as pinned for this comparison"""
+    import os
+    from conftest import ROOT
+    oracle.set_pinned(os.path.join(ROOT, "params", "turner2004_fitted.json"))
+    L = oracle.oracle.lib()
+    for name, n in (("stack", 49), ("hairpin", 31), ("mismatch_hairpin", 175), ("mismatch_multi", 175), ("mismatch_exterior", 175),
+                    ("dangle5", 35), ("dangle3", 35)):
+        assert L.oracle_set_pinned(name.encode(), bytes([1] * n), n) == 0, name
+    L.oracle_set_pinned_scalars(1, 1, 1, 1)
+    for kind in range(3):
+        k = 0
+        while L.oracle_special_seq(kind, k) is not None:
+            k += 1
+        assert L.oracle_set_pinned_special(kind, bytes([1] * k), k) == 0
+
+
+def test_gpu_says_which_energies_read_a_rule_or_model_value(bench_rows):
+    """built-in tables: rafft_eval_structures_info flags exactly the structures whose energy reads an interior-loop table entry that
+    no reference-held energy row exercises (the oracle tracks the same look-ups), and a fold counts the stem energies that did;
+    a loaded parameter file - every entry ViennaRNA's - is never flagged"""
+    params.reset_params()
+    import json, os
+    from conftest import ROOT
+    J = json.load(open(os.path.join(ROOT, "params", "turner2004_fitted.json")))
+    pinned = [k.split("|") for k in J["pinned"]]
+    n11 = len({t for k in pinned if k[0] == "int11" for t in (tuple(k[1:]), (k[2], k[1], k[4], k[3]))})
+    n21 = sum(1 for k in pinned if k[0] == "int21")
+    n22 = len({t for k in pinned if k[0] == "int22" for t in (tuple(k[1:]), (k[2], k[1], k[5], k[6], k[3], k[4]))})
+    assert params.unpinned_entries() == {"int11": 576 - n11, "int21": 2304 - n21, "int22": 9216 - n22}
+    rng = np.random.default_rng(77)
+    seqs = [r["seq"] for r in bench_rows[5::97] if len(r["seq"]) <= 500] + ["".join(rng.choice(list("ACGU"), 200)) for _ in range(12)]
+    res = rafft_amd.fold_batch(seqs, 100, 50, 1000)
+    st = rafft_amd.last_stats()
+    assert st["n_dE_evals"] > 10000 and 0 < st["n_kept_guessed"] <= st["n_dE_guessed"] < 0.1 * st["n_dE_evals"]
+    ss, dbs = [], []
+    for s, beam in zip(seqs, res):
+        for x in beam[:25]:
+            ss.append(s); dbs.append(x.str_struct)
+    dcal, status, guessed = R.eval_structures_info(ss, dbs)
+    assert not any(status) and 0 < sum(guessed) < len(guessed)
+    _oracle_tracks_the_interior_loop_tables_only()
+    oracle.track(True)
+    try:
+        for s, db, d, g in zip(ss, dbs, dcal, guessed):
+            od, n_unp = oracle.eval_structure_tracked(s, db)
+            assert od == d and (n_unp > 0) == bool(g), (s, db, n_unp, g)
+    finally:
+        oracle.track(False)
+        oracle.reset_tables()
+    # ViennaRNA's own tables loaded (here: the built-in values written out and read back as a parameter file): nothing is a guess
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "b.par")
+        params.save_params(p)
+        params.load_params(p)
+        try:
+            assert params.unpinned_entries() == {"int11": 0, "int21": 0, "int22": 0}
+            res2 = rafft_amd.fold_batch(seqs, 100, 50, 1000)
+            st2 = rafft_amd.last_stats()
+            assert st2["n_dE_evals"] == 0 and st2["n_dE_guessed"] == 0 and st2["n_kept_guessed"] == 0
+            assert [[(x.str_struct, x.dcal) for x in b] for b in res2] == [[(x.str_struct, x.dcal) for x in b] for b in res]
+            assert R.eval_structures_info(ss[:50], dbs[:50])[2] == [0] * 50
+        finally:
+            params.reset_params()

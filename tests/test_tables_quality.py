@@ -3,7 +3,7 @@
 The 11 505 reference-held energy rows are reproduced exactly (tests/test_oracle.py) - by construction, the tables
 were fitted to them.  These tests keep the OUT-OF-SAMPLE numbers honest: a by-sequence hold-out of the fit, and the
 share of fold decisions that involve a table entry no row pins (tools/unpinned_stats.py has the full-size numbers,
-profiles/r02_unpinned_lookups.json).  With a ViennaRNA parameter file loaded (rafft_load_params) none of this
+profiles/r04_unpinned_lookups.json).  With a ViennaRNA parameter file loaded (rafft_load_params) none of this
 applies: every entry is ViennaRNA's."""
 import json
 import os
@@ -15,20 +15,25 @@ from conftest import ROOT
 
 
 def test_holdout_of_the_table_fit_one_fold():
-    """fit on 4/5 of the sequences, evaluate the structures of the other 1/5 (tools/turner_fit/holdout.py):
-    structures whose entries were all exercised in training are right (>98 %), structures touching an entry the
-    training rows never exercised are right about half of the time - the unpinned entries are educated guesses"""
+    """fit on 4/5 of the sequences, evaluate the structures of the other 1/5 (tools/turner_fit/holdout.py).  Round 4 (the unseen
+    2x2 entries from the half-unit model of how the published table was built, the 2x1 blocks closed by G.U from the rule
+    except the handful of loops that carry the GC-CG value): structures whose entries were all exercised in training are right
+    (> 99.5 %; 98.9 % in round 2), structures touching an entry the training rows never exercised are right nine times in ten
+    (one in two in round 2) - still educated guesses, and `rafft_stats.n_kept_guessed` / rafft_eval_structures_info say when
+    a fold used one"""
     from tools.turner_fit import holdout
     r = holdout.run(k=5, seed=0, folds=[0])["total"]
     assert r["test"] > 2000
-    assert r["wrong_rate_when_all_seen"] < 0.02, r
-    assert 0.25 < r["wrong_rate_when_touching_unseen"] < 0.75, r
-    assert r["wrong_rate"] < 0.07, r
-    committed = json.load(open(os.path.join(ROOT, "profiles", "r02_turner_holdout.json")))
+    assert r["wrong_rate_when_all_seen"] < 0.005, r
+    assert r["wrong_rate_when_touching_unseen"] < 0.15, r
+    assert r["wrong_rate"] < 0.015, r
+    committed = json.load(open(os.path.join(ROOT, "profiles", "r04_turner_holdout.json")))
     f0 = committed["folds"][0]
     assert f0["test"] == r["test"] and f0["exact_when_all_seen"] == r["exact_when_all_seen"] \
         and f0["exact_when_touching_unseen"] == r["exact_when_touching_unseen"]
-    assert abs(committed["total"]["wrong_rate"] - 0.047) < 0.01
+    assert committed["total"]["wrong_rate"] < 0.0125 and committed["total"]["wrong_rate_when_touching_unseen"] < 0.15
+    before = json.load(open(os.path.join(ROOT, "profiles", "r02_turner_holdout.json")))["total"]          # (the round-2 tables, kept for the record)
+    assert before["wrong_rate"] > 4 * committed["total"]["wrong_rate"]
 
 
 def test_share_of_fold_decisions_touching_unpinned_entries(bench_rows):
@@ -54,6 +59,13 @@ def test_share_of_fold_decisions_touching_unpinned_entries(bench_rows):
         assert n == 0
     finally:
         oracle.track(False)
-    full = json.load(open(os.path.join(ROOT, "profiles", "r02_unpinned_lookups.json")))
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_unpinned_lookups.json")))
     assert 0.01 < full["cfg3_benchmark_set"]["dE_share"] < 0.03
-    assert full["cfg3_vs_published_lowest_energy"]["identical"] == 2141
+    # the reference's PUBLISHED lowest-energy structures (fft_100n_50ms_best_nrj_scores.csv - made with the real ViennaRNA): an
+    # out-of-sample check of the guessed entries.  Round 2's tables agreed on 2141 of 2296 sequences, with a guessed entry behind 26 of
+    # the 155 differences; round 4's agree on 2166, the rest are energy ties (116), differences of the older rafft.py that made the CSV
+    # (12) - and 2 with a guessed entry involved
+    vs = full["cfg3_vs_published_lowest_energy"]
+    assert vs["identical"] == 2166 and vs["any_unpinned_entry_involved"] == 2
+    before = json.load(open(os.path.join(ROOT, "profiles", "r02_unpinned_lookups.json")))["cfg3_vs_published_lowest_energy"]
+    assert before["identical"] == 2141

@@ -6,13 +6,13 @@ it: k-fold split BY SEQUENCE (all structures of a sequence go to the same fold),
 make_tables.fit_tables() on k-1 folds, exact-dcal rate on the held-out fold - overall and split by whether the
 held-out structure touches a table entry that no training row exercised.
 
-    python -m tools.turner_fit.holdout [k]      -> profiles/r02_turner_holdout.json
+    python -m tools.turner_fit.holdout [k]      -> profiles/r04_turner_holdout.json
 """
 import json, os, sys, time
 import numpy as np
 from . import kats, model, make_tables
 
-OUT = os.path.join(os.path.dirname(__file__), "..", "..", "profiles", "r02_turner_holdout.json")
+OUT = os.path.join(os.path.dirname(__file__), "..", "..", "profiles", "r04_turner_holdout.json")
 
 
 def run(k=5, seed=0, folds=None):

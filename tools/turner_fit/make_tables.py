@@ -146,8 +146,20 @@ def fit_tables(ks):
     pred22 = halfunit_int22(th1, cnt1) if INT22_MODEL == "halfunit" else additive_int22(th1, cnt1)
     P.int22_prior = pred22
 
+    # 2x1 loops closed by G.U pairs (blocks GU-CG, GC-UG, GU-UG): most entries follow the rule; a handful of loops (A/AA, A/GA, ...)
+    # carry the value of the GC-CG block whatever the closing pairs.  Which ones is read off the exercised entries: those whose
+    # value equals the GC-CG block's and differs from the rule.  (Round 2 propagated EVERY GC-CG entry: of the held-out structures
+    # whose only unseen entry sat in these blocks 17 of 28 then came out 0.7 or 1.4 kcal/mol too low.)
+    gu_blocks = ((3, 1), (2, 4), (3, 4))
+    copied = set()
+    for k, v in th1.items():
+        if k[0] == "int21" and (k[1], k[2]) in gu_blocks and cnt1[k] >= 2:
+            k21 = ("int21", 2, 1) + k[3:]
+            if k21 in th1 and th1[k21] == v and v != int21_rule(k[1], k[2], *k[3:]):
+                copied.add(k[3:])
+
     def int21_p2(t1, t2, a, b, c):
-        if (t1, t2) in ((3, 1), (2, 4), (3, 4)):
+        if (t1, t2) in gu_blocks and (a, b, c) in copied:
             k = ("int21", 2, 1, a, b, c)
             if k in th1 and cnt1[k] >= 2:
                 return th1[k]

@@ -15,7 +15,7 @@ and, for the benchmark set, the comparison with the reference's published lowest
 (fft_100n_50ms_best_nrj_scores.csv): for every sequence where ours differs - is the reference's structure in our
 final beam, is its energy (our tables) lower/equal/higher than our best, do the two touch unpinned entries.
 
-    python tools/unpinned_stats.py  -> profiles/r02_unpinned_lookups.json
+    python tools/unpinned_stats.py  -> profiles/r04_unpinned_lookups.json
 """
 import gzip, json, os, sys, time
 import multiprocessing as mp
@@ -90,7 +90,7 @@ def main():
                     reference_structure_lower_than_our_best=sum(1 for r in diff if r["ref_dcal_ours"] < r["our_best_dcal"]),
                     reference_energy_reproduced=sum(1 for r in diff if r["ref_dcal_ours"] == r["ref_dcal_published"]),
                     any_unpinned_entry_involved=sum(1 for r in diff if r["ref_touches_unpinned"] or r["best_unp"]))
-    json.dump(out, open(os.path.join(ROOT, "profiles", "r02_unpinned_lookups.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", "r04_unpinned_lookups.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 
