@@ -302,7 +302,10 @@ int class_cfg(int K, int maxL, ClsCfg out[NGEN], bool nofft1 = false, bool nofft
     // positions - exact direct correlation on multi-word bit masks, lag values in a per-workgroup HBM scratch - with an LDS plan
     // sized for 4096 positions: ~50 KiB, so a CU holds two or three workgroups of it (four wavefronts per SIMD) instead of one.
     // Same integer pair counts, same fp64 values (tests/test_gpu_parity.py::test_gpu_fft_and_direct_correlation_agree).
-    static const int c3_direct = getenv("RAFFT_C3_DIRECT") ? atoi(getenv("RAFFT_C3_DIRECT")) : 0;
+    // (measured on the configs[3] shard: 202 -> 177 ms per call, the class itself 93 -> 66 ms - its regions cost 330 kcycles each at
+    //  three workgroups per CU against 182 at one; the benchmark set, whose two 23S sequences are all it has of such regions, is
+    //  unchanged.  RAFFT_C3_DIRECT=0: the FFT plan; read at every call, tests switch it.)
+    const int c3_direct = getenv("RAFFT_C3_DIRECT") ? atoi(getenv("RAFFT_C3_DIRECT")) : 1;
     if (c3_direct && direct3_ok && !longseq) {
         const int Kmax = std::max(1, std::min(K, MAX_P - 1)), nmax = MAX_P / 2, Pd = 2048;
         // (256 threads: at the 168 VGPRs the kernel needs without spilling a SIMD holds three wavefronts - three 256-thread

@@ -536,12 +536,26 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
             for (int k = tid; k < P; k += NT) {
                 double v = -INFINITY;
                 if (k < m) {
+                    // Only the words that hold cells of this diagonal - positions ip with 0 <= k - ip < n - are visited (half of them on
+                    // average: the lags near either end have short diagonals), and the 64-bit window of the reversed masks slides: every
+                    // step loads ONE new word per mask and reuses the high word of the step before (mask_window would load two and
+                    // range-check both).  Same bits, same counts.
                     const int sft = n - 1 - k;
+                    const int ip_lo = k > n - 1 ? k - (n - 1) : 0, ip_hi = k < n - 1 ? k : n - 1;
+                    const int w0 = ip_lo >> 6, w1 = ip_hi >> 6;
+                    const int start = (w0 << 6) + sft;                 // first bit of the window of word w0 (negative: bits before the string are zeros)
+                    int q = start >> 6;                                 // (arithmetic shift: floor)
+                    const int bsh = start & 63;
+                    const unsigned long long *RU = R + 3 * W, *RC = R + 1 * W;
+                    unsigned long long loU = (q >= 0 && q < W) ? RU[q] : 0ULL, loC = (q >= 0 && q < W) ? RC[q] : 0ULL;
                     int cAU = 0, cGC = 0, cGU = 0;
-                    for (int w = 0; w < W; w++) {
-                        const unsigned long long xU = mask_window(R + 3 * W, W, (w << 6) + sft), xC = mask_window(R + 1 * W, W, (w << 6) + sft);
+                    for (int w = w0; w <= w1; w++, q++) {
+                        const bool in = q + 1 >= 0 && q + 1 < W;
+                        const unsigned long long hiU = in ? RU[q + 1] : 0ULL, hiC = in ? RC[q + 1] : 0ULL;
+                        const unsigned long long xU = bsh ? (loU >> bsh) | (hiU << (64 - bsh)) : loU, xC = bsh ? (loC >> bsh) | (hiC << (64 - bsh)) : loC;
                         const unsigned long long fA = F[0 * W + w], fG = F[2 * W + w];
                         cAU += __popcll(fA & xU); cGC += __popcll(fG & xC); cGU += __popcll(fG & xU);
+                        loU = hiU; loC = hiC;
                     }
                     const double raw = (2.0 * (double)cAU) * d.au + (2.0 * (double)cGC) * d.gc + (2.0 * (double)cGU) * d.gu;
                     const int nk = k < m - 1 - k ? k : m - 1 - k;

@@ -183,6 +183,14 @@ def test_gpu_fft_and_direct_correlation_agree(monkeypatch, node_records):
         runs[lim] = [as_lists(t) for _, t in rafft_amd.fold_batch(longer, 100, 6, 1000, traj=True)]
     monkeypatch.delenv("RAFFT_DIRECT_N")
     assert runs["0"] == runs["1024"] == runs["4096"]
+    # regions of 1025-4096 positions: by default the FFT-free kernel (direct correlation, lag values in HBM, three workgroups per CU),
+    # with RAFFT_C3_DIRECT=0 the LDS FFT plan (one workgroup per CU)
+    big = longer[3:] + ["".join(rng.choice(list("ACGU"), 2600))]
+    d3 = [as_lists(t) for _, t in rafft_amd.fold_batch(big, 100, 4, 1000, traj=True)]
+    monkeypatch.setenv("RAFFT_C3_DIRECT", "0")
+    f3 = [as_lists(t) for _, t in rafft_amd.fold_batch(big, 100, 4, 1000, traj=True)]
+    monkeypatch.delenv("RAFFT_C3_DIRECT")
+    assert d3 == f3
     _, o = oracle.fold(longer[2], 100, 6, 1000, traj=True)
     assert runs["1024"][2] == as_lists(o)
 

@@ -10,11 +10,13 @@ of wave cycles spent active / parked (s_waitcnt) / issue-stalled.
 Lanes per vector instruction (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU / 4: thread-cycles tick per quad-cycle of a wave64 instruction) and
 LDS bank-conflict cycles come from a fifth pass when present.
 
-usage: python tools/pmc_summary.py gpurun_out/r03_prof profiles r03 [commit]"""
+usage: python tools/pmc_summary.py gpurun_out/r04_prof profiles r04      (run in the build container after tools/profile_r04.sh on the GPU box:
+       the commit comes from git, the digest of rafft_amd/csrc from the tree that ran; a `cfg4` sub-directory - the configs[3] shard,
+       3 calls of tools/ab_cfg4.py - becomes profiles/<tag>_cfg4_*)"""
 import collections, csv, json, os, shutil, sys
 
 N_CU, SIMD_PER_CU = 256, 4
-N_BATCHES = 4          # bench.py --steps 3 --warmup 1 in every PMC pass
+N_BATCHES = 4          # bench.py --steps 3 --warmup 1 in every PMC pass (3 for the configs[3] shard: tools/ab_cfg4.py folds it three times)
 
 
 def counters(dirname):
@@ -33,10 +35,25 @@ def counters(dirname):
     return tot, {k: len(v) for k, v in disp.items()}, dur
 
 
-def main(src, dst, tag, *rest):
+def head_commit():
+    import subprocess
+    try:
+        return subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip() or None
+    except OSError:
+        return None
+
+
+def main(src, dst, tag, n_batches=N_BATCHES, digest=None, workload="BASELINE configs[2], bench.py --steps 3 --warmup 1 --no-extras with synchronous calls (BENCH_DEPTH=1, BENCH_PREWARM_S=0)"):
+    global N_BATCHES
+    N_BATCHES = n_batches
     shutil.copy(os.path.join(src, "trace", "t_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
-    bench = json.load(open(os.path.join(src, "trace_bench.json")))
-    json.dump(bench, open(os.path.join(dst, f"{tag}_trace_bench.json"), "w"), indent=1)
+    if os.path.exists(os.path.join(src, "cu_share.json")):
+        shutil.copy(os.path.join(src, "cu_share.json"), os.path.join(dst, f"{tag}_cu_share.json"))
+    if os.path.exists(os.path.join(src, "trace_bench.json")):
+        bench = json.load(open(os.path.join(src, "trace_bench.json")))
+        json.dump(bench, open(os.path.join(dst, f"{tag}_trace_bench.json"), "w"), indent=1)
+    if digest is None and os.path.exists(os.path.join(src, "csrc_digest.txt")):
+        digest = open(os.path.join(src, "csrc_digest.txt")).read().strip()
     fe, nf, _ = counters(os.path.join(src, "pmc_fetch"))
     wr, nw, _ = counters(os.path.join(src, "pmc_write"))
     sq, ns, dur = counters(os.path.join(src, "pmc_sq"))
@@ -89,9 +106,10 @@ def main(src, dst, tag, *rest):
                     "mean_waves_resident_per_simd": round(4.0 * c["SQ_WAVE_CYCLES"] / slots, 3)}
     ex = next((k for k in issue if k.startswith("void expand_kernel<64")), None)
     out = {"source": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_* | SQ_* second set | lanes + LDS conflicts), each in its own run, "
-                     "bench.py --steps 3 --warmup 1 --no-extras with synchronous calls (BENCH_DEPTH=1, BENCH_PREWARM_S=0); tools/profile_%s.sh" % tag,
+                     "%s; tools/profile_%s.sh" % (workload, tag.split("_")[0]),
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE halving, MI355X_MICROARCH.md)",
-           "commit": sys.argv[4] if len(sys.argv) > 4 else None,
+           "commit": head_commit(), "csrc_digest": digest, "batches_profiled": n_batches,
+           "whole_batch_hbm_bytes": sum(v["hbm_bytes_per_batch"] for v in kernels.values()),
            "clock_hz_used": clk, "kernels": kernels, "issue": issue, "lanes_and_lds": lanes,
            "issue_roofline": dict(kernel=ex, **{k: issue[ex][k] for k in ("issue_frac", "valu_busy_frac_at_2_cycles_per_wave64_op", "pipe_busy_frac_measured",
                                                                              "wave_cycle_shares", "mean_waves_resident_per_simd")}) if ex else None}
@@ -104,4 +122,15 @@ def main(src, dst, tag, *rest):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    src, dst, tag = sys.argv[1:4]
+    main(src, dst, tag)
+    c4 = os.path.join(src, "cfg4")
+    if os.path.exists(os.path.join(c4, "pmc_fetch", "p_counter_collection.csv")):
+        dg = open(os.path.join(src, "csrc_digest.txt")).read().strip() if os.path.exists(os.path.join(src, "csrc_digest.txt")) else None
+        print("---- configs[3] shard")
+        main(c4, dst, tag + "_cfg4", 3, dg, "BASELINE configs[3], one GPU's LPT shard (2048 sequences, L 100..3000, ms=200), 3 calls of tools/ab_cfg4.py")
+        for name in ("trace_run.log",):
+            if os.path.exists(os.path.join(c4, name)):
+                shutil.copy(os.path.join(c4, name), os.path.join(dst, f"{tag}_cfg4_{name}"))
+    if os.path.exists(os.path.join(src, "bench_cfg4_n1.json")) and os.path.getsize(os.path.join(src, "bench_cfg4_n1.json")):
+        shutil.copy(os.path.join(src, "bench_cfg4_n1.json"), os.path.join(dst, f"{tag}_bench_cfg4_n1.json"))
