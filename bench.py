@@ -528,7 +528,12 @@ def main():
             "memoization": {"region_instances": agg.get("n_node_instances", 0) // args.steps,      # (structure, region) pairs
                             "regions_created": agg.get("n_nodes_created", 0) // args.steps,      # records written: first pick of a (parent region, candidate, side)
                             "regions_aliased": agg.get("n_nodes_aliased", 0) // args.steps,      # ... that turned out to be a known loop (another path)
-                            "regions_expanded": agg.get("n_node_expansions", 0) // args.steps},
+                            "regions_expanded": agg.get("n_node_expansions", 0) // args.steps,
+                            # children the combine step accepted (each one a probe + an insert in its sequence's `seen` set, rafft.py:196-200)
+                            "children_accepted": agg.get("n_children", 0) // args.steps, "structures_materialized": agg.get("n_structs", 0) // args.steps,
+                            # built-in tables: stem energies evaluated / involving a rule or model value / kept candidates that do
+                            "dE_evaluations": agg.get("n_dE_evals", 0) // args.steps, "dE_with_guessed_entry": agg.get("n_dE_guessed", 0) // args.steps,
+                            "kept_candidates_with_guessed_entry": agg.get("n_kept_guessed", 0) // args.steps},
             "allocations_in_timed_region": timed_allocs,
             "cpu_baseline": cpu,
             "parity_vs_cpu": parity,

@@ -78,17 +78,18 @@ typedef struct {
  * time of the call, and stay 0 otherwise.  RAFFT_SPANS=0 switches ms_expand off as well. */
 typedef struct {
     double ms_total;          /* wall time of the call, host side */
-    double ms_expand;         /* sum of expand_kernel<64,false> durations (regions with FFT size P <= 512;
-                                 the dominant kernel; HIP events on its own stream) */
+    double ms_expand;         /* sum of the durations of the dominant kernel, expand_kernel<64,true,16,0,1>: regions of 33..256 positions
+                                 with up to 128 branches, sixteen one-wavefront teams per workgroup (HIP events on its own stream) */
     double ms_expand_c1;      /* expand_small_kernel<16|32>: regions of up to 32 positions whose every lag is searched, teams of 16 / 32 lanes */
-    double ms_expand_c2;      /* expand_kernel<256,false> (512 < P <= 2048), runs concurrently */
-    double ms_expand_c3;      /* expand_kernel<512,false> (P > 2048), runs concurrently */
+    double ms_expand_c2;      /* expand_kernel<256,...>: regions of up to 1024 positions that do not fit the one-wavefront class; runs concurrently */
+    double ms_expand_c3;      /* regions of 1025..4096 positions (expand_kernel<256,false,1,2,3>: direct correlation, lag values in HBM; the LDS FFT
+                                 plan expand_kernel<512,...> with RAFFT_C3_DIRECT=0) and the class for regions beyond 4096 positions; concurrently */
     double ms_expand_wall;    /* fork->join wall time of the concurrent expand launches of every step */
     double ms_beam;           /* sum of beam-step kernel durations */
     double ms_materialize;    /* sum of materialize kernel durations */
     double ms_output;         /* output formatting kernel */
-    int64_t n_expand_launches; /* launches of the dominant kernel, expand_kernel<64,false> (steps with few new structures
-                                 send their regions to one of the wide kernels instead) */
+    int64_t n_expand_launches; /* launches of the dominant kernel (steps with few new structures send their regions to one of the
+                                 wide kernels instead) */
     int64_t n_steps;          /* folding steps executed (max over sequences) */
     int64_t n_node_expansions;/* regions really expanded (identical loops are expanded once) */
     int64_t n_nodes_created;  /* region records written: one per (parent region, candidate, side) that a beam member picked, whoever picked it first */

@@ -442,7 +442,10 @@ Caps plan_caps(size_t S, size_t sumL, const rafft_params &p, double est)
     c.db = std::max<size_t>(c.db, sumL + (size_t)NSHARD * (16 * (size_t)avgL + 4096));
     c.br = std::max<size_t>(c.br, (size_t)NSHARD * 8192);
     c.work = c.nd;
-    c.looptab = 1024; while (c.looptab < 2 * c.nd) c.looptab <<= 1;
+    // (the loop table holds the regions CREATED - one per child slot that a beam member picked, ~0.4 of the (structure, region) pairs
+    //  `nd` is planned for: a power of two >= nd keeps it at most half full; it is zero-filled for every wave, and a full table is an
+    //  overflow like any other - the wave is folded again with doubled arenas)
+    c.looptab = 1024; while (c.looptab < c.nd) c.looptab <<= 1;
     c.ch_cap = p.max_branch + p.max_stack + 8;
     int need = p.max_branch + 2 * p.max_stack + 8;
     // keys of one step: children + old beam; only the max_stack selected ones are sorted (padded to a power of two)

@@ -146,6 +146,73 @@ def test_gpu_cfg4_real_lpt_shard_ms200():
     assert not bad, (len(bad), [len(seqs[k]) for k in bad[:10]])
 
 
+def _cfg4_set():
+    """BASELINE configs[3]: 16 384 random sequences, L ~ U[100, 3000] (default_rng(3000): lengths first, then the bases of
+    every sequence in turn) and their LPT shards over 8 GPUs"""
+    rng = np.random.default_rng(3000)
+    lens = rng.integers(100, 3001, size=16384)
+    seqs = ["".join("ACGU"[c] for c in rng.choice(4, int(n))) for n in lens]
+    return seqs, sharding.lpt_shards([int(x) for x in lens], 8)
+
+
+def test_gpu_cfg4_all_eight_shards_ms200():
+    """BASELINE configs[3] whole: every one of the eight LPT shards (2048 sequences each, ms=200) folded on this GPU.  On all 16 384
+    results: beam sorted by energy, no structure twice, and the energy of EVERY final structure (3.2 M of them) re-evaluated from its
+    dot-bracket by the whole-structure kernel (balanced, canonical pairs only, exact dcal - a checksum of the incrementally summed dE
+    over every folding step).  Against the oracle: the full final beam of a stratified sample that includes members of 1000-3000 nt
+    (two per 400-nt length band, from different shards) - the size classes the headline workload barely touches."""
+    import ctypes as C
+    from rafft_amd import _native as N
+    seqs, shards = _cfg4_set()
+    assert sorted(i for sh in shards for i in sh) == list(range(16384)) and all(len(sh) == 2048 for sh in shards)
+    # the oracle sample first (worker processes, while the GPU folds): by length band, members of different shards
+    shard_of = {i: k for k, sh in enumerate(shards) for i in sh}
+    sample = []
+    for b, lo in enumerate((100, 500, 900, 1300, 1700, 2100, 2500, 2800)):
+        cand = [i for i in range(16384) if lo <= len(seqs[i]) < lo + 200]
+        sample += [next(i for i in cand if shard_of[i] == k) for k in (b, (3 * b + 5) % 8)]
+    assert max(len(seqs[i]) for i in sample) >= 2800 and len({shard_of[i] for i in sample}) >= 6
+    import threading
+    want = {}
+    th = threading.Thread(target=lambda: want.update(zip(sample, fold_many([(seqs[i], 100, 200, 1000, False) for i in sample]))))
+    th.start()
+    lib = N.lib()
+    n_struct = 0
+    got_sample = {}
+    for k, sh in enumerate(shards):
+        mine = [seqs[i] for i in sh]
+        res = rafft_amd.fold_batch(mine, 100, 200, 1000)
+        assert rafft_amd.last_stats()["n_regrows"] <= 1, (k, rafft_amd.last_stats())
+        enc = [s.encode() for s in mine]
+        seq_addr, db_addr, dcal_all = [], [], []
+        for j, s in enumerate(mine):
+            L, sizes, rows, dcal = res.raw(j)
+            assert L == len(s) and sizes == [len(dcal)] and 1 <= len(dcal) <= 200
+            assert (np.diff(dcal) >= 0).all()                                       # sorted by energy (rafft.py:207)
+            assert len({r.tobytes() for r in rows}) == len(rows)                       # `seen` dedupe (rafft.py:196-200)
+            base = rows.ctypes.data
+            db_addr.append(base + np.arange(len(dcal), dtype=np.uint64) * np.uint64(L + 1))
+            seq_addr.append(np.full(len(dcal), C.cast(C.c_char_p(enc[j]), C.c_void_p).value, dtype=np.uint64))
+            dcal_all.append(np.array(dcal))
+            if sh[j] in want or sh[j] in sample:
+                got_sample[sh[j]] = beam_key(res[j])
+        seq_addr, db_addr, dcal_all = np.concatenate(seq_addr), np.concatenate(db_addr), np.concatenate(dcal_all)
+        n_struct += len(dcal_all)
+        step = 150000                          # bounded host/device buffers per evaluation call
+        for a in range(0, len(dcal_all), step):
+            n = min(step, len(dcal_all) - a)
+            sa, da = np.ascontiguousarray(seq_addr[a:a + n]), np.ascontiguousarray(db_addr[a:a + n])
+            out, st = (C.c_int * n)(), (C.c_int * n)()
+            N.check(lib.rafft_eval_structures(n, (C.c_char_p * n).from_buffer(sa), (C.c_char_p * n).from_buffer(da), out, st))
+            assert not np.frombuffer(st, dtype=np.int32).any(), k
+            assert (np.frombuffer(out, dtype=np.int32) == dcal_all[a:a + n]).all(), k
+        del res
+    assert n_struct > 3_000_000
+    th.join()
+    bad = [(i, len(seqs[i])) for i in sample if got_sample[i] != want[i]]
+    assert not bad, bad
+
+
 def test_gpu_cfg5_streamed_graph_text_and_sidecar(tmp_path):
     """BASELINE configs[4] through the CLI: one 400-nt sequence, beam 1000, `--traj` text and binary side-car streamed
     from the flat result buffers - equal to the oracle's trajectory formatted the reference's way, and
