@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libraffthip.so")
+LIB_PATH = os.environ.get("RAFFT_LIB") or os.path.join(_HERE, "libraffthip.so")      # (RAFFT_LIB: another build of the library, for A/B measurements)
 
 OK, ERR_BAD_CHAR, ERR_EMPTY, ERR_TOO_LONG, ERR_TEMP, ERR_CAPACITY, ERR_PARAM, ERR_HIP, ERR_STRUCT, ERR_NO_DEVICE = range(10)
 

@@ -1355,7 +1355,12 @@ static void scheduler_main()
     // waves in flight: two (typically the long-tail wave of one batch beside a bulk wave) - more only split the work
     // into smaller, less efficient waves (measured with 6-12 batches in flight: 2 waves 9.5-9.9 ms per benchmark batch, 3-4
     // waves 10.1-10.3 ms) and multiply the HBM held by workspaces
-    const int max_waves = std::max(1, std::min(getenv("RAFFT_MAX_WAVES") ? atoi(getenv("RAFFT_MAX_WAVES")) : 2, MAX_PIPES));
+    // (round 4: THREE bulk waves.  A kernel trace of the pipelined loop with two - tools/concurrency.py - shows an expand kernel in flight
+    //  for 70 % of the wall time; for the rest only a beam step or the small latency-bound kernels of the tails are.  A third wave fills
+    //  part of that: steady state over 80 benchmark batches 367-377 k -> 384-388 k sequences/s with 15 in flight, a 20-step bench run
+    //  366 -> 373 k; four waves of four batches 372-375 k - smaller waves, more launches.  Round 2 measured the opposite with waves of
+    //  one or two batches and twice the kernel time per batch.)
+    const int max_waves = std::max(1, std::min(getenv("RAFFT_MAX_WAVES") ? atoi(getenv("RAFFT_MAX_WAVES")) : 3, MAX_PIPES));
     // a member batch is finished when its last job is: finalise it
     auto release = [&](Job &job, int rc, const std::string &err) {
         for (auto &m : job.members) {

@@ -295,3 +295,22 @@ __device__ __forceinline__ int br_lower(const uint32_t *br, int nbr, int x)
     }
     return lo;
 }
+
+// The same for four positions at once, in lockstep: the trip count depends on nbr alone (uniform over the wavefront), every step
+// loads the four probes together - four dependent chains of LDS round trips become one.  (a = number of branches whose 5' end lies
+// before x: all elements below index a are smaller; steps run from the largest power of two <= nbr down to 1.)
+__device__ __forceinline__ void br_lower4(const uint32_t *br, int nbr, int x0, int x1, int x2, int x3, int &r0, int &r1, int &r2, int &r3)
+{
+    int a = 0, b = 0, c = 0, e = 0;
+    int step = nbr > 0 ? 1 << (31 - __clz(nbr)) : 0;
+    for (; step > 0; step >>= 1) {
+        const int ia = a + step, ib = b + step, ic = c + step, ie = e + step;
+        const int va = ia <= nbr ? (int)(br[ia - 1] & 0xffffu) : 0x7fffffff, vb = ib <= nbr ? (int)(br[ib - 1] & 0xffffu) : 0x7fffffff;
+        const int vc = ic <= nbr ? (int)(br[ic - 1] & 0xffffu) : 0x7fffffff, ve = ie <= nbr ? (int)(br[ie - 1] & 0xffffu) : 0x7fffffff;
+        if (va < x0) a = ia;
+        if (vb < x1) b = ib;
+        if (vc < x2) c = ic;
+        if (ve < x3) e = ie;
+    }
+    r0 = a; r1 = b; r2 = c; r3 = e;
+}

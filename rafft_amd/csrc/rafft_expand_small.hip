@@ -240,8 +240,8 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
                     int g = g_old;
                     const int mi = w_mi[s], mj = w_mj[s];
                     const int a0 = pos[mi], b0 = pos[mj], ao = pos[mi - nb + 1], bo = pos[mj + nb - 1];
-                    int lo = br_lower(brl, nbr, a0), hi = br_lower(brl, nbr, b0);
-                    const int lo_o = br_lower(brl, nbr, ao), hi_o = br_lower(brl, nbr, bo);
+                    int lo, hi, lo_o, hi_o;
+                    br_lower4(brl, nbr, a0, b0, ao, bo, lo, hi, lo_o, hi_o);
                     BrList outer{brl, 0, lo_o, hi_o, nbr, 1, ao, bo};
                     int e_new = loop_energy_pre(T, B, Sl, L, ci, cj, outer, pf, g);
                     BrList inner{brl, lo, hi, 0, 0, 0, 0, 0};
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
                     }
                     Cand cd;
                     cd.ddcal = w_dd[s]; cd.mi = (uint16_t)mi; cd.mj = (uint16_t)mj; cd.nb = (uint16_t)nb;
-                    cd.set_cuts(br_lower(brl, nbr, pos[mi]), br_lower(brl, nbr, pos[mj]), br_lower(brl, nbr, pos[mi - nb + 1]), br_lower(brl, nbr, pos[mj + nb - 1]));
+                    { int c0, c1, c2, c3; br_lower4(brl, nbr, pos[mi], pos[mj], pos[mi - nb + 1], pos[mj + nb - 1], c0, c1, c2, c3); cd.set_cuts(c0, c1, c2, c3); }
                     cd.h1 = h1; cd.h2 = h2;
                     d.cand[cbase + toff + rank] = cd;
                     d.cslot[cbase + toff + rank] = 0ULL;      // (both child slots: nobody has asked yet)

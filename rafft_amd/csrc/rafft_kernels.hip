@@ -311,7 +311,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
     if (gteam == 0 && tid == 0) d.c->n_mat = 0;                // the beam step that follows counts its new structures here
     const int shard = gteam & (NSHARD - 1);
     unsigned long long st_items = 0, st_n = 0, st_lags = 0, st_nbr = 0;   // per-block statistics
-    unsigned int st_eval = 0, st_guess = 0, st_kguess = 0;                // per wavefront: stem energies evaluated / involving a rule or model value / kept ones that do
+    if (tid < 3) misc[24 + tid] = 0;         // per team: stem energies evaluated / involving a rule or model value / kept ones that do
 
     // Work items are fetched FETCH at a time and candidate slots are reserved in slabs, so that the
     // two atomics with a returned value (a full L2 round trip each) are paid once per several regions.
@@ -948,8 +948,8 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                     int g = g_old;
                     const int mi = wmi[r], mj = wmj[r];
                     const int a0 = pos[mi], b0 = pos[mj], ao = pos[mi - nb + 1], bo = pos[mj + nb - 1];
-                    int lo = br_lower(brl, nbr, a0), hi = br_lower(brl, nbr, b0);
-                    const int lo_o = br_lower(brl, nbr, ao), hi_o = br_lower(brl, nbr, bo);
+                    int lo, hi, lo_o, hi_o;
+                    br_lower4(brl, nbr, a0, b0, ao, bo, lo, hi, lo_o, hi_o);
                     BrList outer{brl, 0, lo_o, hi_o, nbr, 1, ao, bo};
                     int e_new = loop_energy_pre(T, B, Sl, L, ci, cj, outer, pf, g);
                     BrList inner{brl, lo, hi, 0, 0, 0, 0, 0};
@@ -992,8 +992,10 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                 const int f = kf & 1;
                 ESYNC();                      // everyone has read keep[] of this slab
                 const unsigned long long bal = __ballot(f != 0);
-                if (T->lsb) {                 // (built-in tables: how many stem energies of this launch involved a rule / model value)
-                    st_eval += __popcll(__ballot((kf & 4) != 0)); st_guess += __popcll(__ballot((kf & 6) == 6)); st_kguess += __popcll(__ballot((kf & 3) == 3));
+                if (T->lsb) {                 // (built-in tables: how many stem energies of this launch involved a rule / model value -
+                    //  counted in the team's LDS, not in registers that would live across the whole region loop)
+                    const int ne = __popcll(__ballot((kf & 4) != 0)), ng = __popcll(__ballot((kf & 6) == 6)), nk = __popcll(__ballot((kf & 3) == 3));
+                    if (lane == 0) { atomicAdd(&misc[24], ne); if (ng) atomicAdd(&misc[25], ng); if (nk) atomicAdd(&misc[26], nk); }
                 }
                 int pre = __popcll(bal & ((1ULL << lane) - 1));
                 if (NT > 64) {
@@ -1072,7 +1074,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                 }
                 Cand cd;
                 cd.ddcal = my; cd.mi = (uint16_t)mi; cd.mj = (uint16_t)mj; cd.nb = (uint16_t)nb;
-                cd.set_cuts(br_lower(brl, nbr, pos[mi]), br_lower(brl, nbr, pos[mj]), br_lower(brl, nbr, pos[mi - nb + 1]), br_lower(brl, nbr, pos[mj + nb - 1]));
+                { int c0, c1, c2, c3; br_lower4(brl, nbr, pos[mi], pos[mj], pos[mi - nb + 1], pos[mj + nb - 1], c0, c1, c2, c3); cd.set_cuts(c0, c1, c2, c3); }
                 cd.h1 = h1; cd.h2 = h2;
                 if (!dry) { d.cand[cbase + rank] = cd; d.cslot[cbase + rank] = 0ULL; }   // (both child slots: nobody has asked yet)
                 if (dbg.kept) dbg.kept[rank] = r;
@@ -1108,11 +1110,11 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
         atomicAdd(&sl->lags, st_lags);
         atomicAdd(&sl->nbr, st_nbr);
     }
-    if ((threadIdx.x & 63) == 0 && st_eval) {       // (every wavefront of a wide team counted its own lanes)
-        Counters::StatLine *sl = &d.c->xstat[cls][(gteam + (threadIdx.x >> 6)) & (NSHARD - 1)];
-        atomicAdd(&sl->evals, (unsigned long long)st_eval);
-        if (st_guess) atomicAdd(&sl->guessed, (unsigned long long)st_guess);
-        if (st_kguess) atomicAdd(&sl->kept_guessed, (unsigned long long)st_kguess);
+    if (tid == 0 && misc[24]) {
+        Counters::StatLine *sl = &d.c->xstat[cls][gteam & (NSHARD - 1)];
+        atomicAdd(&sl->evals, (unsigned long long)(unsigned)misc[24]);
+        if (misc[25]) atomicAdd(&sl->guessed, (unsigned long long)(unsigned)misc[25]);
+        if (misc[26]) atomicAdd(&sl->kept_guessed, (unsigned long long)(unsigned)misc[26]);
     }
 }
 

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 BENCH_PREWARM_S=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python3 $R/bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 5 > $R/gpurun_out/${TAG}_trace_bench.json 2> $OUT/trace.err
 cp $OUT/t_kernel_stats.csv $R/gpurun_out/${TAG}_kernel_stats.csv
 python3 $R/tools/cu_share.py $OUT/t_kernel_trace.csv > $R/gpurun_out/${TAG}_cu_share.json || true
-rm -f $OUT/t_kernel_trace.csv $OUT/*.db
+python3 $R/tools/concurrency.py $OUT/t_kernel_trace.csv > $R/gpurun_out/${TAG}_concurrency.txt || true; rm -f $OUT/*.db
 python3 - <<PY
 import csv
 rows = list(csv.DictReader(open("$R/gpurun_out/${TAG}_kernel_stats.csv")))
