@@ -99,9 +99,22 @@ __device__ inline void select_smallest_inplace(unsigned long long *keys, int N, 
 {
     const int tid = threadIdx.x;
     if (K >= N) return;
+    // bytes in which no two keys differ need no pass (the keys of the beam step are (energy + bias) << 32 | generation order: of
+    // their eight bytes three or four vary) - one OR-reduction of key ^ keys[0] finds them
+    unsigned long long diff = 0;
+    const unsigned long long key0 = keys[0];
+    for (int i = tid; i < N; i += NT) diff |= keys[i] ^ key0;
+    for (int o = 32; o > 0; o >>= 1) diff |= __shfl_xor(diff, o, 64);
+    if (tid < 2) sh[26 + tid] = 0;
+    __syncthreads();
+    if ((tid & 63) == 0) { atomicOr((unsigned int *)&sh[26], (unsigned int)diff); atomicOr((unsigned int *)&sh[27], (unsigned int)(diff >> 32)); }
+    __syncthreads();
+    diff = ((unsigned long long)(unsigned int)sh[27] << 32) | (unsigned int)sh[26];
     unsigned long long prefix = 0;
     int kk = K;
-    for (int pass = 7; pass >= 0; pass--) {
+    bool take_le = false;              // every key of the threshold bin is wanted: nothing below that byte needs looking at
+    for (int pass = 7; pass >= 0 && !take_le; pass--) {
+        if (((diff >> (8 * pass)) & 255ULL) == 0) { prefix |= key0 & (255ULL << (8 * pass)); continue; }
         for (int i = tid; i < 256; i += NT) hist[i] = 0;
         __syncthreads();
         const int sh_hi = 8 * (pass + 1);
@@ -116,15 +129,18 @@ __device__ inline void select_smallest_inplace(unsigned long long *keys, int N, 
             const int b = base + tid;
             const int h = b < 256 ? hist[b] : 0;
             int tot, ex = block_exscan<NT>(h, sh, &tot);
-            if (b < 256 && run + ex < kk && kk <= run + ex + h) { sh[28] = b; sh[29] = kk - (run + ex); }
+            if (b < 256 && run + ex < kk && kk <= run + ex + h) { sh[28] = b; sh[29] = kk - (run + ex); sh[30] = h; }
             run += tot;
             __syncthreads();
         }
         prefix |= (unsigned long long)(unsigned)sh[28] << (8 * pass);
         kk = sh[29];
+        take_le = kk == sh[30];
         __syncthreads();
+        if (take_le) prefix |= (pass > 0) ? ((1ULL << (8 * pass)) - 1ULL) : 0ULL;      // (the largest key the bin can hold)
     }
-    // `prefix` is now the K-th smallest key: keep every key <= prefix (exactly K, keys are distinct)
+    // `prefix` is now the K-th smallest key (or, stopped early, an upper bound of the wanted bin that no unwanted key reaches):
+    // keep every key <= prefix - exactly K, keys are distinct
     int outn = 0;
     for (int base = 0; base < N; base += NT) {
         const int i = base + tid;
@@ -1242,7 +1258,9 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
     if (tid == 0) sh[26] = 0;                  // fill of the LDS region list
     __syncthreads();
     {
-        const int G = d.seq_len[sq] <= 800 ? 16 : 64;
+        // (round 4: 8 lanes for sequences of up to 300 nt - their structures have 3-5 regions - i.e. 32 members per pass of a
+        //  256-thread workgroup instead of 16: a beam of 50 takes two passes of the chain instead of four)
+        const int G = d.seq_len[sq] <= 300 ? 8 : d.seq_len[sq] <= 800 ? 16 : 64;
         const int gpw = 64 / G, gl = lane & (G - 1), grp = lane / G;
         const int nslots = (BS_NT / 64) * gpw;
         const unsigned long long gmask = G == 64 ? ~0ULL : ((1ULL << G) - 1ULL);
@@ -1608,6 +1626,20 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
         // only the max_stack best survive: select them exactly (radix select), then sort just those
         const int K = N < d.B ? N : d.B;
         select_smallest_inplace<BS_NT>(skey, N, K, rl_cnt, sh);
+        if (K <= RL_CAP) {
+            // order the selected keys by counting (round 4): the rank of a key is the number of smaller ones among the K (they are
+            // distinct), and it goes straight to its place - two barriers where the bitonic sort of 64 keys takes 21
+            unsigned long long *outk = rl_off;              // (the region list of the product walk is dead by now; RL_CAP entries)
+            for (int i = tid; i < K; i += BS_NT) {
+                const unsigned long long ki = skey[i];
+                int r = 0;
+                for (int j = 0; j < K; j++) r += skey[j] < ki ? 1 : 0;
+                outk[r] = ki;
+            }
+            __syncthreads();
+            for (int i = tid; i < K; i += BS_NT) skey[i] = outk[i];
+            __syncthreads();
+        } else {
         int M = 2; while (M < K) M <<= 1;
         for (int i = K + tid; i < M; i += BS_NT) skey[i] = ~0ULL;
         __syncthreads();
@@ -1623,6 +1655,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
                 }
                 __syncthreads();
             }
+        }
     }
     STAMP(3);
     const int nnew = N < d.B ? N : d.B;
