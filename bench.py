@@ -349,6 +349,14 @@ def main():
         mine.run(max(3, args.steps // 2), depth=1)
         barrier()
         extras["ms_per_call_sequential"] = round(allmax(time.perf_counter() - t1) / max(3, args.steps // 2) * 1e3, 3)
+        # the same through rafft_fold_submit + rafft_fold_wait, one at a time: what an asynchronous or Python caller with ONE batch pays
+        # (a lone submit lingers up to RAFFT_LINGER_US = 150 us for followers before its waves are admitted; rafft_fold_batch never does)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(max(3, args.steps // 2)):
+            mine.wait(mine.submit())
+        barrier()
+        extras["ms_per_call_submit_wait"] = round(allmax(time.perf_counter() - t1) / max(3, args.steps // 2) * 1e3, 3)
         if world > 1:
             # (a) strong scaling: ONE copy of the set LPT-sharded over the ranks, `world` times as many steps in flight so that a
             # rank's scheduler still merges its 1/N-sized shards into full waves (rounds 2 and 3 reported this as `value`)

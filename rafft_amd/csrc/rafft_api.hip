@@ -252,7 +252,7 @@ static int cls1_br() { return std::min(CLS1_BR, (8 * cls1_P() - 16) / 10 - 1); }
 // wavefronts leaves ~32 KiB of a CU's LDS - room for a workgroup of the small-region kernel beside it.
 // `nofft2`: the same for the 256-thread class when Dev::direct_n covers all of its regions (<= 1024 positions): 46 -> 39 KiB, four
 // workgroups per CU instead of three.
-int class_cfg(int K, int maxL, ClsCfg out[NGEN], bool nofft1 = false, bool nofft2 = false, bool direct3_ok = false)
+int class_cfg(int K, int maxL, ClsCfg out[NGEN + 1], bool nofft1 = false, bool nofft2 = false, bool direct3_ok = false)
 {
     // sequences longer than LDS_SEQ: classes 2 and 3 read the bases of a loop from HBM/L2 (no LDS copy), class 0 takes the
     // regions whose FFT would not fit
@@ -315,6 +315,7 @@ int class_cfg(int K, int maxL, ClsCfg out[NGEN], bool nofft1 = false, bool nofft
         ExpandLds l = expand_lds(Pd, 0, nmax, MAX_BR, Kmax, false, 1, false, 256);
         if (fits && l.total <= 80 * 1024) {
             const int per_cu = std::max(1, std::min(3, (160 * 1024) / l.total));
+            out[NGEN] = out[3];          // the FFT plan stays for the steps with few such regions (launch_expand_cls)
             out[3] = {256, Pd, 0, nmax, MAX_BR, Kmax, l.total, g.n_cu * per_cu, false, 1, false, true};
         }
     }
@@ -335,7 +336,7 @@ int launch_expand(const Dev &d, int cls, const ClsCfg &cf, unsigned n_teams, hip
     return 0;
 }
 
-int launch_expand_cls(const Dev &d, int cls, const ClsCfg cf[NGEN], unsigned n_blocks, hipStream_t st, bool dry = false)
+int launch_expand_cls(const Dev &d, int cls, const ClsCfg cf[NGEN + 1], unsigned n_blocks, hipStream_t st, bool dry = false)
 {
     if (cls >= NGEN) {        // small regions: teams of 16 / 32 lanes, four wavefronts per workgroup (n_blocks = workgroups)
         const int arg = cls | ((getenv("RAFFT_SMALL_DIAG") ? atoi(getenv("RAFFT_SMALL_DIAG")) : 0) << 8);
@@ -369,8 +370,16 @@ int launch_expand_cls(const Dev &d, int cls, const ClsCfg cf[NGEN], unsigned n_b
         if (prod && !cf[2].tab) return launch_expand<256, false, 1, 0, 1>(d, 2 | nf, cf[2], n_blocks, st);
         return cf[2].tab ? launch_expand<256, true>(d, 2 | nf, cf[2], n_blocks, st) : launch_expand<256, false>(d, 2 | nf, cf[2], n_blocks, st);
     }
-    if (cf[3].direct3 && nodiag) return launch_expand<256, false, 1, 2, 3>(d, 3, cf[3], n_blocks, st);
-    if (cf[3].direct3) return launch_expand<256, false, 1, 2>(d, 3, cf[3], n_blocks, st);
+    if (cf[3].direct3) {
+        // Two kernels share the class's work list; the length of the list decides ON THE DEVICE which of them works (the other one's
+        // workgroups leave at once): up to Dev::c3_switch regions - every region has a CU to itself either way - the FFT plan, whose
+        // region takes 76 us (182 kcycles) against 137 us without the FFT buffers; beyond that the FFT-free kernel, three workgroups
+        // per CU.  (With the FFT-free kernel alone one synchronous call on the benchmark batch took 11.5 ms instead of 10.0: its
+        // long-tail wave expands a handful of such regions per step, 24 steps in a row.)
+        if (int rc = nodiag ? launch_expand<256, false, 1, 2, 3>(d, 3 | 0x8000, cf[3], n_blocks, st) : launch_expand<256, false, 1, 2>(d, 3 | 0x8000, cf[3], n_blocks, st)) return rc;
+        const unsigned nb_fft = std::min<unsigned>(n_blocks, (unsigned)cf[NGEN].grid);
+        return nodiag ? launch_expand<512, false, 1, 0, 2>(d, 3 | 0x4000, cf[NGEN], nb_fft, st) : launch_expand<512, false>(d, 3 | 0x4000, cf[NGEN], nb_fft, st);
+    }
     if (nodiag && !cf[3].tab) return launch_expand<512, false, 1, 0, 2>(d, 3, cf[3], n_blocks, st);
     return cf[3].tab ? launch_expand<512, true>(d, 3, cf[3], n_blocks, st) : launch_expand<512, false>(d, 3, cf[3], n_blocks, st);
 }
@@ -561,7 +570,7 @@ struct Wave {
     bool longseq = false;         // a sequence longer than LDS_SEQ: its loops' bases are read from HBM, regions beyond 4096 positions exist
     unsigned dedupe_per_cu = 1024 / DEDUPE_NT;
     std::vector<int> off, len;
-    ClsCfg cf[NGEN];
+    ClsCfg cf[NGEN + 1];          // (cf[NGEN]: the FFT plan of class 3 beside its FFT-free kernel)
     Caps c;
     Dev d;
     Counters hc;
@@ -731,6 +740,7 @@ int Wave::setup()
         d.big_keyv = (double *)g.big.p;
     }
     d.cls1_P = cls1_P(); d.cls1_br = cf[1].brmax;
+    d.c3_switch = getenv("RAFFT_C3_SWITCH") ? atoi(getenv("RAFFT_C3_SWITCH")) : ::g.n_cu;
     d.cand_slab = getenv("RAFFT_SLAB") ? std::max(16, atoi(getenv("RAFFT_SLAB"))) : 64;
     d.fetch_bulk = getenv("RAFFT_FETCH") ? std::max(1, atoi(getenv("RAFFT_FETCH"))) : 4;
     d.taper_pct = getenv("RAFFT_TAPER") ? std::max(0, std::min(100, atoi(getenv("RAFFT_TAPER")))) : 25;

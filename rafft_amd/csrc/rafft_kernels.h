@@ -133,6 +133,7 @@ struct Dev {
     int cand_slab;                           // candidate slots an expand wavefront reserves at a time (one returning atomic each)
                                  // sm_n5 to class 5 (teams of 32); 0 = class unused (see node_class)
     int cls1_P, cls1_br;         // limits of the one-wavefront expand class (FFT size, branches): they set its LDS per wavefront
+    int c3_switch;               // class 3: up to this many regions in a step the FFT plan works, beyond it the FFT-free kernel (launch_expand_cls)
     double min_nrj, gc, au, gu;
     int *beam, *beam_n, *done, *nsteps;
     // children of the current step

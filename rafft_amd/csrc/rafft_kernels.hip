@@ -325,6 +325,8 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
     }
     const unsigned n_items = d.c->n_work[cls].v;
     if (gteam == 0 && tid == 0) d.c->n_mat = 0;                // the beam step that follows counts its new structures here
+    // (class 3 is served by two kernels on one work list: the list's length says which of them works - launch_expand_cls)
+    if (((cls_arg & 0x4000) && n_items > (unsigned)d.c3_switch) || ((cls_arg & 0x8000) && n_items <= (unsigned)d.c3_switch)) return;
     const int shard = gteam & (NSHARD - 1);
     unsigned long long st_items = 0, st_n = 0, st_lags = 0, st_nbr = 0;   // per-block statistics
     if (tid < 3) misc[24 + tid] = 0;         // per team: stem energies evaluated / involving a rule or model value / kept ones that do
