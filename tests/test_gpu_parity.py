@@ -221,6 +221,18 @@ def test_gpu_small_region_kernel_is_interchangeable(monkeypatch, node_records):
         assert t == as_lists(o), len(s)
     st = rafft_amd.last_stats()
     assert st["n_node_expansions"] > 0
+    # a loop with few unpaired positions and MANY branches (n <= 16, 17..32 helices): with equal limits ("16,16") the 32-lane class is
+    # off and such a region must take the general kernel - it used to be routed to the class that is never launched and was dropped
+    hp = "GGGGAAAACCCC"
+    seq = "GA" + hp * 10 + "AC" + hp * 10 + "GU"
+    db = ".." + "((((....))))" * 10 + ".." + "((((....))))" * 10 + ".."
+    pos = [0, 1, 122, 123, 244, 245]
+    for lim in ("16,16", "16,32", "0,0"):
+        monkeypatch.setenv("RAFFT_SMALL", lim)
+        g = R.expand_node(seq, db, pos, 100, 0, 0.0)
+        o = oracle.expand_node(seq, db, pos, 100, 0, 0.0)
+        assert g["lag"] == o["lag"] and g["ddcal"] == o["ddcal"] and g["kept"] == o["kept"] and len(o["kept"]) > 0, lim
+    monkeypatch.delenv("RAFFT_SMALL")
 
 
 def test_gpu_beam_region_lists_not_resident(monkeypatch):
