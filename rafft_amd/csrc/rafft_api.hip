@@ -565,7 +565,7 @@ struct Wave {
     Batch &bt;                                      // the first of them: carries the wave's timing spans and statistics
     std::vector<Span> &spans;
     const SeamIn *seam;
-    size_t S = 0, sumL = 0, B = 0, bs_lds[2] = {0, 0}, mat_lds = RAFFT_MAX_LEN;
+    size_t S = 0, sumL = 0, B = 0, bs_lds[2] = {0, 0}, mat_lds = RAFFT_MAX_LEN, mat_row = RAFFT_MAX_LEN;
     double reserve = 1.0;         // buffers are allocated for a wave this many times bigger (merged batches to come)
     bool longseq = false;         // a sequence longer than LDS_SEQ: its loops' bases are read from HBM, regions beyond 4096 positions exist
     unsigned dedupe_per_cu = 1024 / DEDUPE_NT;
@@ -821,6 +821,7 @@ int Wave::setup()
         bs_lds[v] = std::max((size_t)c.sort_cap * 8, 24 * nt) + RL_CAP * 12 + B * sizeof(ParentInfo) + (B + 1) * 8 + ((B + 3) & ~(size_t)3) * 4 + 128;
     }
     mat_lds = 20 * (size_t)d.max_prod + (((size_t)maxL + 15) & ~(size_t)15);
+    mat_row = ((size_t)maxL + 15) & ~(size_t)15;
     if (const char *e = getenv("RAFFT_DEDUPE_PER_CU")) dedupe_per_cu = (unsigned)std::max(1, atoi(e));
     n_active = (unsigned)S;
     ms_setup = since(tw0);
@@ -931,7 +932,12 @@ int Wave::after_beam()
     {
         Span sp{next_event(), next_event(), 2};
         SPAN_REC(sp.a, st, sp.kind);
-        if (d.prof_e == nullptr) hipLaunchKernelGGL(materialize_kernel<true>, dim3(hc.n_mat), dim3(MAT_NT), mat_lds, st, d);
+        // (four structures per wavefront, teams of 16 lanes, when the short productive-region lists are in use and four rows fit the LDS
+        //  budget of a latency-bound kernel - materialize_team_kernel; RAFFT_MAT4=0: one structure per wavefront)
+        static const bool mat4_on = !(getenv("RAFFT_MAT4") && atoi(getenv("RAFFT_MAT4")) == 0);
+        if (mat4_on && d.prof_e == nullptr && d.max_prod <= MAT4_PROD && mat_row <= 2048)
+            hipLaunchKernelGGL(materialize_team_kernel, dim3((hc.n_mat + MAT4_TEAMS - 1) / MAT4_TEAMS), dim3(64), (size_t)MAT4_TEAMS * (20 * MAT4_PROD + mat_row), st, d, (int)hc.n_mat, (int)mat_row);
+        else if (d.prof_e == nullptr) hipLaunchKernelGGL(materialize_kernel<true>, dim3(hc.n_mat), dim3(MAT_NT), mat_lds, st, d);
         else hipLaunchKernelGGL(materialize_kernel<false>, dim3(hc.n_mat), dim3(MAT_NT), mat_lds, st, d);
         HIPCHK(hipGetLastError());
         // tail of the batch: so few new structures that their regions fit one wave of workgroups of the widest class

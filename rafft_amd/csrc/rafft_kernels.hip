@@ -1999,6 +1999,214 @@ __global__ __launch_bounds__(MAT_NT, RAFFT_MAT_WAVES) void materialize_kernel(De
 #undef MSTAMP
 }
 
+// The same with TEAMS of 16 lanes: four new beam members per wavefront (round 4).  materialize_kernel is a chain of four dependent
+// round trips per structure (record -> parent's lists and row -> slot claim / region headers / candidates -> stem positions and
+// arena allocation -> writes) in which a lane stands for one productive region of the parent - three to five of them on the benchmark
+// set - so a wavefront per structure keeps 60 lanes idle through the chain, and what a CU holds of such wavefronts (20, by registers)
+// bounds the structures in flight.  With four structures per wavefront the same CU holds four times as many.  Used when the
+// productive-region lists are the short ones (max_prod <= MAT4_PROD) and the rows fit (host: Wave::after_beam); identical results -
+// the arenas are bump allocated, so only the PLACES of records and lists differ from the one-structure form.
+#define MAT4_TL 16
+#define MAT4_TEAMS (64 / MAT4_TL)
+#define MAT4_PROD 64
+__global__ __launch_bounds__(64, RAFFT_MAT_WAVES) void materialize_team_kernel(Dev d, int n_mat, int row_cap)
+{
+    extern __shared__ __align__(16) uint8_t mat_dyn[];
+    const int tid = threadIdx.x, team = tid / MAT4_TL, tl = tid % MAT4_TL;
+    // dynamic LDS per team: the productive-region lists (MAT4_PROD entries each), then the dot-bracket staging row (row_cap bytes)
+    uint8_t *tbase = mat_dyn + (size_t)team * (20 * MAT4_PROD + (size_t)row_cap);
+    unsigned long long *prod_off = (unsigned long long *)tbase;
+    int *prod_node = (int *)(prod_off + MAT4_PROD);
+    int *prod_cnt = prod_node + MAT4_PROD;
+    int *sel = prod_cnt + MAT4_PROD;
+    uint8_t *sdb = (uint8_t *)(sel + MAT4_PROD);
+    // per-tile descriptors (one lane per productive region; index = lane of the wavefront) and the flat-copy prefix sums of every team
+    __shared__ unsigned long long k_srcpos[64], k_srcbr[64];
+    __shared__ int k_mi[64], k_mj[64], k_nb[64], k_lo0[64], k_loo[64], k_hio[64], k_newbr[64];
+    __shared__ int ps_[MAT4_TEAMS][2 * MAT4_TL + 1], bs_[MAT4_TEAMS][2 * MAT4_TL + 1], ns_[MAT4_TEAMS][MAT4_TL + 1];
+    __shared__ unsigned long long sh64_[MAT4_TEAMS][5];
+    int *ps = ps_[team], *bs = bs_[team], *ns = ns_[team];
+    const int tb = team * MAT4_TL;                       // first lane of my team
+    const unsigned long long tmask = ((1ULL << MAT4_TL) - 1ULL) << tb;
+    const int mat_i = blockIdx.x * MAT4_TEAMS + team;
+    const bool live = mat_i < n_mat;
+    MatRec rec;
+    rec.sid = 0; rec.sq = 0; rec.L = 0; rec.dcal = 0; rec.nprod = 0; rec.combo = 0; rec.prod = 0; rec.pdb = 0;
+    if (live) rec = d.mat[mat_i];
+    const int sid = rec.sid, sq = rec.sq, L = rec.L, my_dcal = rec.dcal;
+    const uint64_t soff = live ? (uint64_t)d.seq_off[sq] : 0;
+    const int pmask = d.pos_packed ? 0x0FFF : 0xFFFF;
+    int mprod = rec.nprod;
+    if (mprod > MAT4_PROD) mprod = MAT4_PROD;
+    {
+        const ProdEnt *pl = d.prod + rec.prod;             // the parent's productive regions (beam_step prepass)
+        for (int k = tl; k < mprod; k += MAT4_TL) { const ProdEnt pe = pl[k]; prod_node[k] = pe.node; prod_cnt[k] = (int)pe.cnt; prod_off[k] = pe.off; sel[k] = 0; }
+    }
+    const uint8_t *pdb = d.db + rec.pdb;                  // the parent's dot-bracket row (rafft/rafft.py:97,127-128)
+    for (int x = tl; x < L; x += MAT4_TL) sdb[x] = pdb[x];
+    wave_sync();
+    if (tl == 0) {       // digits of the combo, last region fastest; high digits of a small index stay 0
+        unsigned long long idx = rec.combo;
+        for (int k = mprod - 1; k >= 0 && idx; k--) {
+            const unsigned int c = (unsigned int)prod_cnt[k];
+            if (idx < (1ULL << 24)) {
+                const unsigned int v = (unsigned int)idx;
+                unsigned int q = (unsigned int)((float)v * __frcp_rn((float)c));       // off by one at most
+                int r = (int)(v - q * c);
+                if (r < 0) { q--; r += (int)c; } else if (r >= (int)c) { q++; r -= (int)c; }
+                sel[k] = r; idx = q;
+            } else { const unsigned long long q = idx / c; sel[k] = (int)(idx - q * c); idx = q; }
+        }
+    }
+    wave_sync();
+    // pass 1: sizes and slot claims (see materialize_kernel)
+    const int TILE = d.mat_tile < MAT4_TL ? d.mat_tile : MAT4_TL;
+    const bool one_tile = mprod <= TILE;
+    const bool memo = d.memo != 0;
+    MatDesc md;
+    md.flags = 0; md.win = 0; md.nnod = 0; md.npos_in = md.npos_out = md.nbr_in = md.nbr_out = 0; md.nb = 0; md.cidx = 0;
+    int tot_nodes = 0, tot_new = 0, tot_pos = 0, tot_br = 0;
+    for (int base = 0; base < mprod; base += TILE) {
+        const int k = base + tl;
+        int nnod = 0, nnew = 0, npos = 0, nbrr = 0;
+        if (k < mprod && tl < TILE) {
+            const unsigned long long cidx = prod_off[k] + (unsigned long long)sel[k];
+            unsigned long long old = 0;
+            if (memo) old = atomicOr(&d.cslot[cidx], 0x8000000080000000ULL);
+            md = mat_describe(d, prod_node[k], cidx);
+            int win = md.flags;
+            if (memo) win &= ((old >> 31) & 1ULL ? 0 : 1) | ((old >> 63) & 1ULL ? 0 : 2);
+            md.win = win;
+            if (!one_tile) sel[k] |= win << 28;
+            nnod = md.nnod; nnew = (win & 1) + (win >> 1);
+            npos = ((win & 1) ? md.npos_in : 0) + ((win & 2) ? md.npos_out : 0);
+            nbrr = ((win & 1) ? md.nbr_in : 0) + ((win & 2) ? md.nbr_out : 0);
+        }
+        for (int o = MAT4_TL / 2; o > 0; o >>= 1) {
+            nnod += __shfl_xor(nnod, o, MAT4_TL); nnew += __shfl_xor(nnew, o, MAT4_TL); npos += __shfl_xor(npos, o, MAT4_TL); nbrr += __shfl_xor(nbrr, o, MAT4_TL);
+        }
+        tot_nodes += nnod; tot_new += nnew; tot_pos += npos; tot_br += nbrr;
+    }
+    bool ok = live;
+    if (tl < 5 && live) {
+        // bump allocation from one of NSHARD sub-arenas; one lane per arena
+        const int shd = mat_i & (NSHARD - 1);
+        unsigned long long *ctr = tl == 0 ? &d.c->node[shd].v : tl == 1 ? &d.c->pos[shd].v : tl == 2 ? &d.c->db[shd].v : tl == 3 ? &d.c->br[shd].v : &d.c->nlist[shd].v;
+        const unsigned long long want = tl == 0 ? (unsigned long long)tot_new : tl == 1 ? (unsigned long long)tot_pos
+                                      : tl == 2 ? (unsigned long long)L : tl == 3 ? (unsigned long long)tot_br : (unsigned long long)tot_nodes;
+        const unsigned long long cap = tl == 0 || tl == 4 ? d.nd_shard_cap : tl == 1 ? d.pos_shard_cap : tl == 2 ? d.db_shard_cap : d.br_shard_cap;
+        const unsigned long long b0 = want ? atomicAdd(ctr, want) : 0ULL;
+        const bool bad = b0 + want > cap;
+        if (bad) atomicOr(&d.c->overflow, tl == 0 || tl == 4 ? OVF_NODE : tl == 1 ? OVF_POS : tl == 2 ? OVF_DB : OVF_BR);
+        const unsigned long long origin = tl == 0 || tl == 4 ? d.nd_base : tl == 1 ? d.pos_base : tl == 2 ? d.db_base : 0ULL;
+        sh64_[team][tl] = origin + (unsigned long long)shd * cap + b0;
+        ok = !bad;
+    }
+    // (every lane of the team learns whether all five allocations fit)
+    ok = ((__ballot(!ok) & tmask) == 0ULL) && live;
+    wave_sync();
+    if (!ok) { if (tl == 0 && live) { d.st[sid].nnodes = 0; d.st[sid].node0 = 0; d.st[sid].db = 0; } }
+    const unsigned long long nbase = sh64_[team][0], pbase = sh64_[team][1], tbase_db = sh64_[team][2], bbase = sh64_[team][3], lbase = sh64_[team][4];
+
+    // pass 2: per tile: descriptors -> LDS, prefix sums, node-list entries, records and flat copies of the regions created here
+    int run_nodes = 0, run_new = 0, run_pos = 0, run_br = 0;
+    const int mp2 = ok ? mprod : 0;
+    for (int base = 0; base < mp2; base += TILE) {
+        const int k = base + tl;
+        const int kt = mp2 - base < TILE ? mp2 - base : TILE;
+        if (!one_tile) {
+            md.flags = 0; md.win = 0; md.nnod = 0; md.npos_in = md.npos_out = md.nbr_in = md.nbr_out = 0; md.nb = 0;
+            if (k < mp2 && tl < TILE) { md = mat_describe(d, prod_node[k], prod_off[k] + (unsigned long long)(sel[k] & 0x0FFFFFFF)); md.win = (sel[k] >> 28) & 3; }
+        }
+        const bool act = k < mp2 && tl < TILE;
+        const int cp_in = act && (md.win & 1) ? md.npos_in : 0, cp_out = act && (md.win & 2) ? md.npos_out : 0;
+        const int cb_in = act && (md.win & 1) ? md.nbr_in : 0, cb_out = act && (md.win & 2) ? md.nbr_out : 0;
+        int xn = act ? md.nnod : 0, xw = act ? (md.win & 1) + (md.win >> 1) : 0, xp = cp_in + cp_out, xb = cb_in + cb_out, xs = act ? md.nb : 0;
+        const int vn = xn, vw = xw, vp = xp, vb = xb, vs = xs;
+        for (int o = 1; o < MAT4_TL; o <<= 1) {
+            const int yn = __shfl_up(xn, o, MAT4_TL), yw = __shfl_up(xw, o, MAT4_TL), yp = __shfl_up(xp, o, MAT4_TL), yb = __shfl_up(xb, o, MAT4_TL), ys = __shfl_up(xs, o, MAT4_TL);
+            if (tl >= o) { xn += yn; xw += yw; xp += yp; xb += yb; xs += ys; }
+        }
+        const int tn = __shfl(xn, MAT4_TL - 1, MAT4_TL), tw = __shfl(xw, MAT4_TL - 1, MAT4_TL), tp = __shfl(xp, MAT4_TL - 1, MAT4_TL),
+                  tbr = __shfl(xb, MAT4_TL - 1, MAT4_TL), ts = __shfl(xs, MAT4_TL - 1, MAT4_TL);
+        const int p0 = xp - vp, b0 = xb - vb;          // exclusive
+        ps[2 * tl] = p0; ps[2 * tl + 1] = p0 + cp_in;
+        bs[2 * tl] = b0; bs[2 * tl + 1] = b0 + cb_in;
+        ns[tl] = xs - vs;
+        if (tl == 0) { ps[2 * MAT4_TL] = tp; bs[2 * MAT4_TL] = tbr; ns[MAT4_TL] = ts; }
+        if (act) {
+            k_srcpos[tid] = md.srcpos; k_srcbr[tid] = md.srcbr;
+            k_mi[tid] = md.mi; k_mj[tid] = md.mj; k_nb[tid] = md.nb; k_lo0[tid] = md.lo0; k_loo[tid] = md.loo; k_hio[tid] = md.hio;
+            k_newbr[tid] = (int)md.newbr;
+            int nid = (int)(nbase + run_new + (xw - vw));
+            unsigned long long le = lbase + run_nodes + (xn - vn);
+            const unsigned long long poff = pbase + run_pos + p0, boff = bbase + run_br + b0;
+            const int slot0 = (int)(2 * md.cidx);
+            if (md.flags & 1) {
+                if (md.win & 1) {
+                    d.nd[nid].seq = sq; d.nd[nid].pdcal = my_dcal; d.nd[nid].pos = poff; d.nd[nid].n = md.npos_in;
+                    d.nd[nid].L = L; d.nd[nid].soff = soff;
+                    d.nd[nid].ci = md.a0; d.nd[nid].cj = md.b0; d.nd[nid].br = boff; d.nd[nid].nbr = md.nbr_in;
+                    d.nd[nid].ncand = -1; d.nd[nid].cand = 0;
+                    if (memo) { d.nd_slot[nid] = (uint32_t)slot0; ((uint32_t *)d.cslot)[slot0] = (uint32_t)(nid + 1) | 0x80000000u; }
+                    d.nlist[le] = memo ? -(slot0 + 1) : nid;
+                    nid++;
+                } else d.nlist[le] = -(slot0 + 1);
+                le++;
+            }
+            if (md.flags & 2) {
+                if (md.win & 2) {
+                    d.nd[nid].seq = sq; d.nd[nid].pdcal = my_dcal; d.nd[nid].pos = poff + cp_in; d.nd[nid].n = md.npos_out;
+                    d.nd[nid].L = L; d.nd[nid].soff = soff;
+                    d.nd[nid].ci = md.ci; d.nd[nid].cj = md.cj; d.nd[nid].br = boff + cb_in; d.nd[nid].nbr = md.nbr_out;
+                    d.nd[nid].ncand = -1; d.nd[nid].cand = 0;
+                    if (memo) { d.nd_slot[nid] = (uint32_t)(slot0 + 1); ((uint32_t *)d.cslot)[slot0 + 1] = (uint32_t)(nid + 1) | 0x80000000u; }
+                    d.nlist[le] = memo ? -(slot0 + 2) : nid;
+                } else d.nlist[le] = -(slot0 + 2);
+            }
+        }
+        wave_sync();
+        // unpaired positions of the regions created here (descriptor kk of my team sits at lane tb + kk)
+        for (int f = tl; f < tp; f += MAT4_TL) {
+            int lo = 0, hi = 2 * kt - 1;                 // last slot starting at or before f (empty slots share starts)
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (ps[mid] <= f) lo = mid; else hi = mid - 1; }
+            const int kk = tb + (lo >> 1), off = f - ps[lo];
+            const uint16_t *pp = d.pos + k_srcpos[kk];
+            int src;
+            if (!(lo & 1)) src = k_mi[kk] + 1 + off;
+            else { const int left = k_mi[kk] - k_nb[kk] + 1; src = off < left ? off : k_mj[kk] + k_nb[kk] + (off - left); }
+            d.pos[pbase + run_pos + f] = pp[src];
+        }
+        for (int f = tl; f < tbr; f += MAT4_TL) {         // their branch helices
+            int lo = 0, hi = 2 * kt - 1;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (bs[mid] <= f) lo = mid; else hi = mid - 1; }
+            const int kk = tb + (lo >> 1), off = f - bs[lo];
+            const uint32_t *bb = d.br + k_srcbr[kk];
+            uint32_t v;
+            if (!(lo & 1)) v = bb[k_lo0[kk] + off];
+            else {
+                const int loo = k_loo[kk];
+                v = off < loo ? bb[off] : off == loo ? (uint32_t)k_newbr[kk] : bb[k_hio[kk] + (off - loo - 1)];
+            }
+            d.br[bbase + run_br + f] = v;
+        }
+        for (int f = tl; f < ts; f += MAT4_TL) {          // the stems in the dot-bracket row
+            int lo = 0, hi = kt - 1;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (ns[mid] <= f) lo = mid; else hi = mid - 1; }
+            const int t = f - ns[lo];
+            const uint16_t *pp = d.pos + k_srcpos[tb + lo];
+            sdb[pp[k_mi[tb + lo] - t] & pmask] = '('; sdb[pp[k_mj[tb + lo] + t] & pmask] = ')';
+        }
+        run_nodes += tn; run_new += tw; run_pos += tp; run_br += tbr;
+        wave_sync();
+    }
+    if (ok) {
+        uint8_t *odb = d.db + tbase_db;
+        for (int x = tl; x < L; x += MAT4_TL) odb[x] = sdb[x];
+        if (tl == 0) { d.st[sid].node0 = (int)lbase; d.st[sid].nnodes = tot_nodes; d.st[sid].db = tbase_db; }
+    }
+}
+
 // ------------------------------------------------------------ dedupe kernel
 
 __device__ inline bool same_loop(const Dev &d, int a, int b)
