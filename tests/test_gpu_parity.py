@@ -191,6 +191,12 @@ def test_gpu_fft_and_direct_correlation_agree(monkeypatch, node_records):
     f3 = [as_lists(t) for _, t in rafft_amd.fold_batch(big, 100, 4, 1000, traj=True)]
     monkeypatch.delenv("RAFFT_C3_DIRECT")
     assert d3 == f3
+    # (by default both kernels are launched on the class's work list and its length decides on the device which one works:
+    #  RAFFT_C3_SWITCH = 0 -> always the FFT-free kernel, huge -> always the FFT plan, 2 -> they alternate from step to step here)
+    for sw in ("0", "1000000", "2"):
+        monkeypatch.setenv("RAFFT_C3_SWITCH", sw)
+        assert [as_lists(t) for _, t in rafft_amd.fold_batch(big, 100, 4, 1000, traj=True)] == d3, sw
+    monkeypatch.delenv("RAFFT_C3_SWITCH")
     _, o = oracle.fold(longer[2], 100, 6, 1000, traj=True)
     assert runs["1024"][2] == as_lists(o)
 
