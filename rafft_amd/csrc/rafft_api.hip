@@ -64,13 +64,13 @@ struct Workspace {
     void *hot = nullptr;                 // pinned, 1 KiB
     // named device buffers (grow-only)
     Buf codes, seq_off, seq_len, beam, beam_n, done, nsteps, ch_parent, ch_combo, ch_dcal, ch_h, seen, seen_off,
-        seen_cap, seen_cnt, st, prod, nd, nlist, nd_slot, cslot, pos, br, db, cand, looptab, trec, tsid,
+        seen_cap, seen_cnt, st, prod, nd, nlist, nd_slot, cslot, pos, br, sp, cand, looptab, trec, tsid,
         work0, work1, work2, work3, work4, work5, mat, counters,
         row_sid, row_off, out_db, out_dcal, row_off2, out_db2, out_dcal2, dbg, big;
     void release_buffers()
     {
         for (Buf *b : {&codes, &seq_off, &seq_len, &beam, &beam_n, &done, &nsteps, &ch_parent, &ch_combo, &ch_dcal, &ch_h, &seen,
-                       &seen_off, &seen_cap, &seen_cnt, &st, &prod, &nd, &nlist, &nd_slot, &cslot, &pos, &br, &db, &cand, &looptab, &trec, &tsid,
+                       &seen_off, &seen_cap, &seen_cnt, &st, &prod, &nd, &nlist, &nd_slot, &cslot, &pos, &br, &sp, &cand, &looptab, &trec, &tsid,
                        &work0, &work1, &work2, &work3, &work4, &work5, &mat, &counters, &row_sid, &row_off, &out_db, &out_dcal, &row_off2, &out_db2,
                        &out_dcal2, &dbg, &big})
             if (b->p) { hipError_t e_ = hipFree(b->p); (void)e_; b->p = nullptr; b->cap = 0; }
@@ -79,7 +79,7 @@ struct Workspace {
     {
         size_t t = 0;
         for (const Buf *b : {&codes, &seq_off, &seq_len, &beam, &beam_n, &done, &nsteps, &ch_parent, &ch_combo, &ch_dcal, &ch_h, &seen,
-                             &seen_off, &seen_cap, &seen_cnt, &st, &prod, &nd, &nlist, &nd_slot, &cslot, &pos, &br, &db, &cand, &looptab, &trec, &tsid,
+                             &seen_off, &seen_cap, &seen_cnt, &st, &prod, &nd, &nlist, &nd_slot, &cslot, &pos, &br, &sp, &cand, &looptab, &trec, &tsid,
                              &work0, &work1, &work2, &work3, &work4, &work5, &mat, &counters, &row_sid, &row_off, &out_db, &out_dcal, &row_off2, &out_db2,
                              &out_dcal2, &dbg, &big})
             t += b->cap;
@@ -412,7 +412,7 @@ struct BaseCodeTable {
 static const BaseCodeTable kBaseCode;
 
 struct Caps {
-    size_t st, nd, pos, br, db, cand, seen, trec, tsid, work, mat, looptab;
+    size_t st, nd, pos, br, sp, cand, seen, trec, tsid, work, mat, looptab;
     int ch_cap, sort_cap;
     size_t bytes;
 };
@@ -421,7 +421,8 @@ Caps plan_caps(size_t S, size_t sumL, const rafft_params &p, double est)
 {
     // Arena sizes from measured usage on the BASELINE workloads (benchmark set, L 28..2968, ms 50;
     // random L 100..3000, ms 200): per surviving structure about 2 + L/100 regions, 0.6 L region
-    // positions, one branch per region, ~5 candidates per region, L dot-bracket bytes (structures of
+    // positions, one branch per region, ~5 candidates per region, the pairs a structure adds to its parent's
+    // (one stem in every productive region - measured on L 100..3000: 30 pairs per structure, 0.02 L; structures of
     // long sequences are over-represented: they fold for more steps).  Factors below carry ~1.5x slack;
     // an overflow is detected on the device and the wave is re-run with doubled arenas.
     Caps c;
@@ -433,7 +434,7 @@ Caps plan_caps(size_t S, size_t sumL, const rafft_params &p, double est)
     c.nd = (size_t)std::min((double)c.st * nodes_per, 2.0e9) + 64;
     c.pos = (size_t)((double)sumL + (double)(c.st - S) * avgL * 0.9) + 4096;
     c.br = c.nd * 3 + 4096;
-    c.db = (size_t)((double)sumL + (double)(c.st - S) * avgL * 1.5) + 4096;
+    c.sp = (size_t)((double)(c.st - S) * (avgL * 0.05 + 24.0)) + 4096;
     c.cand = std::max<size_t>(c.nd * (size_t)std::min(std::max(p.nb_mode, 1), 8) + 4096, (size_t)NSHARD * 16384);
     // accepted children per sequence ~ steps * min(max_branch, ...); regions double and old ones are dropped
     // (measured, ms 50, max_branch 1000, regions abandoned by rehashing included: the benchmark set's bulk uses 4.6 x est x
@@ -448,7 +449,7 @@ Caps plan_caps(size_t S, size_t sumL, const rafft_params &p, double est)
     // whose few structures land on few shards, do not overflow a starved shard
     c.nd = std::max<size_t>(c.nd, S + (size_t)NSHARD * 2048);
     c.pos = std::max<size_t>(c.pos, sumL + (size_t)NSHARD * (16 * (size_t)avgL + 4096));
-    c.db = std::max<size_t>(c.db, sumL + (size_t)NSHARD * (16 * (size_t)avgL + 4096));
+    c.sp = std::max<size_t>(c.sp, (size_t)NSHARD * (2 * (size_t)avgL + 4096));
     c.br = std::max<size_t>(c.br, (size_t)NSHARD * 8192);
     c.work = c.nd;
     // (the loop table holds the regions CREATED - one per child slot that a beam member picked, ~0.4 of the (structure, region) pairs
@@ -460,7 +461,7 @@ Caps plan_caps(size_t S, size_t sumL, const rafft_params &p, double est)
     // keys of one step: children + old beam; only the max_stack selected ones are sorted (padded to a power of two)
     int m2 = 2; while (m2 < p.max_stack) m2 <<= 1;
     c.sort_cap = std::max((need + 1) & ~1, m2);
-    c.bytes = c.st * 128 + c.nd * (64 + 4 + 4 + 6 * 4 + 16) + c.pos * 2 + c.br * 4 + c.db + c.cand * (32 + 8) + c.seen * 16 +
+    c.bytes = c.st * 128 + c.nd * (64 + 4 + 4 + 6 * 4 + 16) + c.pos * 2 + c.br * 4 + c.sp * 4 + c.cand * (32 + 8) + c.seen * 16 +
               c.looptab * 8 + c.trec * 16 + c.tsid * 4 + c.mat * 48 + S * (size_t)c.ch_cap * 32 + S * B * 4;
     return c;
 }
@@ -702,7 +703,7 @@ int Wave::setup()
     ENS(seen, cr.seen * 16); ENS(seen_off, Sr * 8); ENS(seen_cap, Sr * 4); ENS(seen_cnt, Sr * 4);
     ENS(st, cr.st * sizeof(StRec)); ENS(prod, cr.nd * 16);
     ENS(nd, cr.nd * sizeof(NodeRec)); ENS(nlist, cr.nd * 4); ENS(nd_slot, cr.nd * 4); ENS(cslot, cr.cand * 8);
-    ENS(pos, cr.pos * 2); ENS(br, cr.br * 4); ENS(db, cr.db); ENS(cand, cr.cand * 32);
+    ENS(pos, cr.pos * 2); ENS(br, cr.br * 4); ENS(sp, cr.sp * 4); ENS(cand, cr.cand * 32);
     ENS(looptab, cr.looptab * 8);
     ENS(trec, cr.trec * 16); ENS(tsid, cr.tsid * 4);
     ENS(work0, cr.work * 4); ENS(work1, cr.work * 4); ENS(work2, cr.work * 4); ENS(work3, cr.work * 4); ENS(work4, cr.work * 4); ENS(work5, cr.work * 4);
@@ -768,7 +769,7 @@ int Wave::setup()
     d.nd = (NodeRec *)g.nd.p; d.nlist = (int *)g.nlist.p; d.nd_slot = (uint32_t *)g.nd_slot.p; d.cslot = (unsigned long long *)g.cslot.p;
     d.looptab = (unsigned long long *)g.looptab.p; d.looptab_cap = c.looptab;
     d.pos = (uint16_t *)g.pos.p; d.pos_cap = c.pos; d.br = (uint32_t *)g.br.p; d.br_cap = c.br;
-    d.db = (uint8_t *)g.db.p; d.db_cap = c.db;
+    d.sp = (uint32_t *)g.sp.p; d.sp_cap = c.sp;
     d.cand = (Cand *)g.cand.p; d.cand_cap = c.cand;
     d.trec = (int4 *)g.trec.p; d.trec_cap = (uint32_t)c.trec; d.tsid = (int *)g.tsid.p; d.tsid_cap = c.tsid;
     d.work[0] = (int *)g.work0.p; d.work[1] = (int *)g.work1.p; d.work[2] = (int *)g.work2.p; d.work[3] = (int *)g.work3.p;
@@ -777,7 +778,7 @@ int Wave::setup()
     d.c = (Counters *)g.counters.p;
     d.nd_base = S; d.nd_shard_cap = (c.nd - S) / NSHARD;
     d.pos_base = sumL; d.pos_shard_cap = (c.pos - sumL) / NSHARD;
-    d.db_base = sumL; d.db_shard_cap = (c.db - sumL) / NSHARD;
+    d.sp_shard_cap = c.sp / NSHARD;
     d.br_shard_cap = c.br / NSHARD; d.cand_shard_cap = c.cand / NSHARD;
     if (seam) d.dbg = seam->dbg;
     if (const char *rp = getenv("RAFFT_REP")) d.rep = atoi(rp);
@@ -820,7 +821,7 @@ int Wave::setup()
         const size_t nt = v ? 1024 : 256;
         bs_lds[v] = std::max((size_t)c.sort_cap * 8, 24 * nt) + RL_CAP * 12 + B * sizeof(ParentInfo) + (B + 1) * 8 + ((B + 3) & ~(size_t)3) * 4 + 128;
     }
-    mat_lds = 20 * (size_t)d.max_prod + (((size_t)maxL + 15) & ~(size_t)15);
+    mat_lds = 20 * (size_t)d.max_prod;
     mat_row = ((size_t)maxL + 15) & ~(size_t)15;
     if (const char *e = getenv("RAFFT_DEDUPE_PER_CU")) dedupe_per_cu = (unsigned)std::max(1, atoi(e));
     n_active = (unsigned)S;
@@ -932,11 +933,11 @@ int Wave::after_beam()
     {
         Span sp{next_event(), next_event(), 2};
         SPAN_REC(sp.a, st, sp.kind);
-        // (four structures per wavefront, teams of 16 lanes, when the short productive-region lists are in use and four rows fit the LDS
-        //  budget of a latency-bound kernel - materialize_team_kernel; RAFFT_MAT4=0: one structure per wavefront)
+        // (four structures per wavefront, teams of 16 lanes, when the short productive-region lists are in use -
+        //  materialize_team_kernel; RAFFT_MAT4=0: one structure per wavefront)
         static const bool mat4_on = !(getenv("RAFFT_MAT4") && atoi(getenv("RAFFT_MAT4")) == 0);
-        if (mat4_on && d.prof_e == nullptr && d.max_prod <= MAT4_PROD && mat_row <= 2048)
-            hipLaunchKernelGGL(materialize_team_kernel, dim3((hc.n_mat + MAT4_TEAMS - 1) / MAT4_TEAMS), dim3(64), (size_t)MAT4_TEAMS * (20 * MAT4_PROD + mat_row), st, d, (int)hc.n_mat, (int)mat_row);
+        if (mat4_on && d.prof_e == nullptr && d.max_prod <= MAT4_PROD)
+            hipLaunchKernelGGL(materialize_team_kernel, dim3((hc.n_mat + MAT4_TEAMS - 1) / MAT4_TEAMS), dim3(64), 0, st, d, (int)hc.n_mat);
         else if (d.prof_e == nullptr) hipLaunchKernelGGL(materialize_kernel<true>, dim3(hc.n_mat), dim3(MAT_NT), mat_lds, st, d);
         else hipLaunchKernelGGL(materialize_kernel<false>, dim3(hc.n_mat), dim3(MAT_NT), mat_lds, st, d);
         HIPCHK(hipGetLastError());
@@ -1004,7 +1005,7 @@ int Wave::emit_rows(size_t first, size_t count, bool early, double *t_gather)
     Span sp{next_event(), next_event(), 3};
     SPAN_REC(sp.a, st, sp.kind);
     unsigned grid = (unsigned)std::min<size_t>(nrows, 65536);
-    hipLaunchKernelGGL(output_kernel, dim3(grid), dim3(64), 0, st, d, (int)nrows, (int)recs.size(), (const OutRec *)b_rec.p,
+    hipLaunchKernelGGL(output_kernel, dim3(grid), dim3(64), mat_row, st, d, (int)nrows, (int)recs.size(), (const OutRec *)b_rec.p,
                        (char *)b_db.p, (int *)b_dc.p);
     HIPCHK(hipGetLastError());
     SPAN_REC(sp.b, st, sp.kind);
@@ -1197,11 +1198,11 @@ int Wave::finish_done_body()
     }
     if (getenv("RAFFT_TRACE")) {
         auto mx = [&](const ShardCtr *sc) { unsigned long long m = 0, t = 0; for (int i = 0; i < NSHARD; i++) { m = std::max(m, sc[i].v); t += sc[i].v; } return std::make_pair(m, t); };
-        auto nd = mx(hc.node), po = mx(hc.pos), br = mx(hc.br), db = mx(hc.db), ca = mx(hc.cand), pr = mx(hc.prod);
+        auto nd = mx(hc.node), po = mx(hc.pos), br = mx(hc.br), spr = mx(hc.sp), ca = mx(hc.cand), pr = mx(hc.prod);
         fprintf(stderr, "[rafft] max productive regions per structure: %u (limit %d)\n", hc.max_nprod, d.max_prod);
-        fprintf(stderr, "[rafft] arenas used/cap (max shard | total): st %llu/%zu  nd %llu/%llu|%llu  pos %llu/%llu|%llu  br %llu/%llu|%llu  db %llu/%llu  cand %llu/%llu|%llu  prod %llu/%llu  seen %llu/%zu  est %.1f\n",
+        fprintf(stderr, "[rafft] arenas used/cap (max shard | total): st %llu/%zu  nd %llu/%llu|%llu  pos %llu/%llu|%llu  br %llu/%llu|%llu  sp %llu/%llu|%llu  cand %llu/%llu|%llu  prod %llu/%llu  seen %llu/%zu  est %.1f\n",
                 hc.n_struct, c.st, nd.first, (unsigned long long)d.nd_shard_cap, nd.second, po.first, (unsigned long long)d.pos_shard_cap, po.second,
-                br.first, (unsigned long long)d.br_shard_cap, br.second, db.first, (unsigned long long)d.db_shard_cap,
+                br.first, (unsigned long long)d.br_shard_cap, br.second, spr.first, (unsigned long long)d.sp_shard_cap, spr.second,
                 ca.first, (unsigned long long)d.cand_shard_cap, ca.second, pr.first, (unsigned long long)d.prod_shard_cap, hc.seen_top, c.seen, est);
     }
     if (getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] host time inside issue_step %.3f ms, inside after_beam (incl. nested issue_step and this tail) %.3f ms\n", ms_issue, ms_after);

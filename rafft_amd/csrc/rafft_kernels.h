@@ -4,8 +4,9 @@
 // arenas, monotonic inside a batch so no kernel ever frees):
 //   codes[sum L]        uint8 base codes (N=0 A=1 C=2 G=3 U=4)
 //   struct table st[]   one 128-byte row per beam survivor: energy (dcal), 128-bit pair-set hash,
-//                       dot-bracket row offset, node range, product cursor, lineage
-//   db arena            dot-bracket bytes of every survivor (L per structure)
+//                       its stem pairs, node range, product cursor, lineage
+//   sp arena            the pairs a survivor ADDED to its parent's (uint32 i | j << 16): a structure is its lineage's
+//                       lists; dot-bracket rows only exist in the result buffers (output_kernel walks the lineage)
 //   node table nd[]     one 64-byte row per unpaired region.  A region is exactly one loop of
 //                       the structure: closing pair (ci,cj) (ci<0: exterior loop), the
 //                       ordered unpaired positions `pos` and the ordered branch helices
@@ -59,9 +60,9 @@ struct ShardCtr { unsigned long long v; unsigned long long pad[7]; };   // one 6
 // structure row: one beam survivor (see the file header)
 struct alignas(128) StRec {
     int32_t seq, dcal, node0, nnodes, parent, nprod;   // sequence, energy, region range, lineage, productive regions
-    int32_t c0d, pad;                                  // energy of its combo 0 (kept for resumed product walks)
+    int32_t c0d, nsp;                                  // energy of its combo 0 (kept for resumed product walks); pairs it added to its parent's
     uint64_t h1, h2;                                   // 128-bit pair-set hash
-    uint64_t db, cursor, combo, total, prod;           // dot-bracket row, product cursor, combo it came from, product size, productive-region list
+    uint64_t sp, cursor, combo, total, prod;           // its added pairs (sp arena), product cursor, combo it came from, product size, productive-region list
     uint64_t c0h1, c0h2;                               // hash of its combo 0
     uint64_t pad2[3];
 };
@@ -76,7 +77,7 @@ static_assert(sizeof(NodeRec) == 64, "NodeRec must be one cache line");
 
 struct ProdEnt { uint32_t cnt; int32_t node; uint64_t off; };   // one productive region of a structure
 // one new beam member to materialize: everything materialize_kernel needs to start, in one 48-byte read
-struct alignas(16) MatRec { int32_t sid, sq, L, dcal, nprod, pad; uint64_t combo, prod, pdb; };
+struct alignas(16) MatRec { int32_t sid, sq, L, dcal, nprod, pad; uint64_t combo, prod, pad2; };
 
 struct Counters {
     // hot part: read back by the host once per folding step.  Every counter that the kernels of a step add to with a RETURNING atomic
@@ -95,7 +96,7 @@ struct Counters {
     unsigned long long n_expand, sum_n, sum_lags, n_children, sum_struct_len, n_alias, sum_nbr;
     unsigned long long cls_items[NCLS], cls_sum_n[NCLS], cls_sum_lags[NCLS];   // per size class
     // sharded bump pointers of the arenas filled by materialize / expand
-    ShardCtr node[NSHARD], pos[NSHARD], br[NSHARD], db[NSHARD], cand[NSHARD], node_prev[NSHARD], prod[NSHARD];
+    ShardCtr node[NSHARD], pos[NSHARD], br[NSHARD], sp[NSHARD], cand[NSHARD], node_prev[NSHARD], prod[NSHARD];
     ShardCtr nlist[NSHARD];      // node-list entries (one per region of a structure; `node` counts the regions CREATED)
     // statistics the kernels add to once per wavefront / workgroup: one 64-byte line per (size class, shard), summed by the
     // host at the end of the wave.  (As single counters they were a same-address atomic storm at the end of every expand
@@ -110,7 +111,7 @@ struct Counters {
     struct StatLine { unsigned long long items, n, lags, nbr, alias, children, struct_len, evals, guessed, kept_guessed, pad[6]; } xstat[NCLS][NSHARD];
 };
 
-enum { OVF_STRUCT = 1, OVF_NODE = 2, OVF_POS = 4, OVF_DB = 8, OVF_CAND = 16, OVF_SEEN = 32,
+enum { OVF_STRUCT = 1, OVF_NODE = 2, OVF_POS = 4, OVF_SP = 8, OVF_CAND = 16, OVF_SEEN = 32,
        OVF_TRAJ = 64, OVF_WORK = 128, OVF_PROD = 256, OVF_SORT = 512, OVF_BR = 1024, OVF_LOOPTAB = 2048, OVF_PRODLIST = 4096 };
 
 struct DebugOut {       // kernel-level seam (rafft_expand_node); null in production
@@ -148,7 +149,7 @@ struct Dev {
     ProdEnt *prod; uint64_t prod_shard_cap;
     // nodes
     uint32_t nd_cap;
-    uint64_t nd_base, nd_shard_cap, pos_base, pos_shard_cap, br_shard_cap, db_base, db_shard_cap, cand_shard_cap;
+    uint64_t nd_base, nd_shard_cap, pos_base, pos_shard_cap, br_shard_cap, sp_shard_cap, cand_shard_cap;
     NodeRec *nd;                 // one 64-byte record per region (one cache line: header reads and writes are one transaction)
     int *nlist;                  // node lists of the structures (st.node0, st.nnodes): region id, or -(child slot + 1) (see the file header)
     unsigned long long *cslot;   // child slots, one word per candidate: inner | outer << 32; a half is 0 (nobody has asked yet), bit 31 alone
@@ -161,7 +162,7 @@ struct Dev {
     int pos_packed;              // no sequence beyond 4096 nt: an entry of `pos` is position | base code << 12 (the code rides along:
                                  // expanding a region reads it with the position instead of through a dependent second load)
     uint32_t *br; uint64_t br_cap;
-    uint8_t *db; uint64_t db_cap;
+    uint32_t *sp; uint64_t sp_cap;       // stem pairs added by every structure (i | j << 16)
     Cand *cand; uint64_t cand_cap;
     // trajectory records: (seq, step, count, offset into tsid)
     int4 *trec; uint32_t trec_cap;

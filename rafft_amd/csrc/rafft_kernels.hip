@@ -1181,9 +1181,8 @@ struct ParentInfo {         // filled by the parallel prepass, one entry per bea
     int sid, nprod;         // structure id; productive regions
     unsigned long long prod;              // productive-region list (global)
     int rl0, nrl;           // this member's regions with >= 2 candidates in the LDS list (rl0 < 0: not resident)
-    unsigned long long db;                // its dot-bracket row (handed to materialize_kernel with every child)
 };
-static_assert(sizeof(ParentInfo) == 72, "ParentInfo layout");
+static_assert(sizeof(ParentInfo) == 64, "ParentInfo layout");
 
 __device__ __forceinline__ unsigned long long sat_mul(unsigned long long a, unsigned long long b)
 {
@@ -1271,7 +1270,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
             const int b = b0 + wv * gpw + grp;
             if (b >= nbeam) continue;
             const int sid = oldbeam[b];
-            const unsigned long long cur0 = d.st[sid].cursor, tot0 = d.st[sid].total, dboff = d.st[sid].db;
+            const unsigned long long cur0 = d.st[sid].cursor, tot0 = d.st[sid].total;
             if (tot0 && cur0 >= tot0) { if (gl == 0) pinfo[b].flag = 1; continue; }
             const bool resumed = tot0 && cur0 > 0;
             unsigned long long pbase = 0, tot = 1, h1 = 0, h2 = 0;
@@ -1352,7 +1351,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
             }
             if (gl == 0) {
                 ParentInfo pi;
-                pi.sid = sid; pi.prod = pbase; pi.nprod = wpos; pi.rl0 = nm == 0 ? 0 : rl0; pi.nrl = nm; pi.db = dboff;
+                pi.sid = sid; pi.prod = pbase; pi.nprod = wpos; pi.rl0 = nm == 0 ? 0 : rl0; pi.nrl = nm;
                 if (resumed) {
                     pi.flag = 2; pi.total = tot0; pi.cur = cur0;
                     pi.h1 = d.st[sid].c0h1; pi.h2 = d.st[sid].c0h2; pi.dcal0 = d.st[sid].c0d;
@@ -1722,7 +1721,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
                     const ParentInfo &pp_ = pinfo[d.ch_parent[c]];
                     MatRec mr;
                     mr.sid = sid; mr.sq = sq; mr.L = d.seq_len[sq]; mr.dcal = d.ch_dcal[c]; mr.nprod = pp_.nprod; mr.pad = 0;
-                    mr.combo = d.ch_combo[c]; mr.prod = pp_.prod; mr.pdb = pp_.db;
+                    mr.combo = d.ch_combo[c]; mr.prod = pp_.prod; mr.pad2 = 0;
                     d.mat[mbase + run + ex] = mr;
                 }
                 beam[i] = sid;
@@ -1784,18 +1783,17 @@ __device__ inline MatDesc mat_describe(const Dev &d, int pn, unsigned long long 
 #ifndef RAFFT_MAT_WAVES
 #define RAFFT_MAT_WAVES 1
 #endif
-// (dynamic LDS: the dot-bracket staging row, sized for the longest sequence of the wave - a latency-bound kernel of
-//  one-wavefront workgroups lives on the number of them a CU holds)
+// (dynamic LDS: the productive-region lists only - a structure is stored as the pairs it adds to its parent's, no dot-bracket row is
+//  staged or written here; a latency-bound kernel of one-wavefront workgroups lives on the number of them a CU holds)
 template <bool PROD>      // (PROD: the phase stamps of RAFFT_TRACE=3 compiled out - see expand_kernel)
 __global__ __launch_bounds__(MAT_NT, RAFFT_MAT_WAVES) void materialize_kernel(Dev d)
 {
     extern __shared__ __align__(16) uint8_t mat_dyn[];
-    // dynamic LDS: the productive-region lists (d.max_prod entries each), then the dot-bracket staging row
+    // dynamic LDS: the productive-region lists (d.max_prod entries each)
     unsigned long long *prod_off = (unsigned long long *)mat_dyn;
     int *prod_node = (int *)(prod_off + d.max_prod);
     int *prod_cnt = prod_node + d.max_prod;
     int *sel = prod_cnt + d.max_prod;
-    uint8_t *sdb = (uint8_t *)(sel + d.max_prod);
     // per-tile descriptors (one lane per productive region) and the flat-copy prefix sums (two slots per region)
     __shared__ unsigned long long k_srcpos[64], k_srcbr[64];
     __shared__ int k_mi[64], k_mj[64], k_nb[64], k_lo0[64], k_loo[64], k_hio[64], k_newbr[64];
@@ -1817,9 +1815,6 @@ __global__ __launch_bounds__(MAT_NT, RAFFT_MAT_WAVES) void materialize_kernel(De
         const ProdEnt *pl = d.prod + rec.prod;             // the parent's productive regions (beam_step prepass)
         for (int k = tid; k < mprod; k += MAT_NT) { const ProdEnt pe = pl[k]; prod_node[k] = pe.node; prod_cnt[k] = (int)pe.cnt; prod_off[k] = pe.off; sel[k] = 0; }
     }
-    // the parent's dot-bracket row (rafft/rafft.py:97,127-128); the stems are marked below
-    const uint8_t *pdb = d.db + rec.pdb;
-    for (int x = tid; x < L; x += MAT_NT) sdb[x] = pdb[x];
     __syncthreads();
     if (tid == 0) {      // digits of the combo, last region fastest; high digits of a small index stay 0
         unsigned long long idx = rec.combo;
@@ -1835,7 +1830,7 @@ __global__ __launch_bounds__(MAT_NT, RAFFT_MAT_WAVES) void materialize_kernel(De
         }
     }
     __syncthreads();
-    MSTAMP(0);   // header, productive-region list, parent row, combo digits
+    MSTAMP(0);   // header, productive-region list, combo digits
 
     // pass 1: sizes, and who creates what.  A child region is a function of (parent region, candidate, side) alone
     // (rafft/rafft.py:127-152, rafft/utils.py:141-152): the beam member whose compare-and-swap finds the slot empty creates it, everybody
@@ -1848,10 +1843,10 @@ __global__ __launch_bounds__(MAT_NT, RAFFT_MAT_WAVES) void materialize_kernel(De
     const bool memo = d.memo != 0;
     MatDesc md;
     md.flags = 0; md.win = 0; md.nnod = 0; md.npos_in = md.npos_out = md.nbr_in = md.nbr_out = 0; md.nb = 0; md.cidx = 0;
-    int tot_nodes = 0, tot_new = 0, tot_pos = 0, tot_br = 0;
+    int tot_nodes = 0, tot_new = 0, tot_pos = 0, tot_br = 0, tot_sp = 0;
     for (int base = 0; base < mprod; base += TILE) {
         const int k = base + tid;
-        int nnod = 0, nnew = 0, npos = 0, nbrr = 0;
+        int nnod = 0, nnew = 0, npos = 0, nbrr = 0, nsp = 0;
         if (k < mprod && tid < TILE) {
             // the claim of both child slots of the chosen candidate: ONE returning atomic, issued before anything else is loaded (its
             // round trip runs beside those of the region header, the candidate and the positions).  A slot word is inner | outer << 32;
@@ -1865,38 +1860,39 @@ __global__ __launch_bounds__(MAT_NT, RAFFT_MAT_WAVES) void materialize_kernel(De
             if (memo) win &= ((old >> 31) & 1ULL ? 0 : 1) | ((old >> 63) & 1ULL ? 0 : 2);
             md.win = win;
             if (!one_tile) sel[k] |= win << 28;
-            nnod = md.nnod; nnew = (win & 1) + (win >> 1);
+            nnod = md.nnod; nnew = (win & 1) + (win >> 1); nsp = md.nb;
             npos = ((win & 1) ? md.npos_in : 0) + ((win & 2) ? md.npos_out : 0);
             nbrr = ((win & 1) ? md.nbr_in : 0) + ((win & 2) ? md.nbr_out : 0);
         }
         for (int o = 32; o > 0; o >>= 1) {
             nnod += __shfl_xor(nnod, o, 64); nnew += __shfl_xor(nnew, o, 64); npos += __shfl_xor(npos, o, 64); nbrr += __shfl_xor(nbrr, o, 64);
+            nsp += __shfl_xor(nsp, o, 64);
         }
-        tot_nodes += nnod; tot_new += nnew; tot_pos += npos; tot_br += nbrr;
+        tot_nodes += nnod; tot_new += nnew; tot_pos += npos; tot_br += nbrr; tot_sp += nsp;
     }
     MSTAMP(1);   // pass 1
     if (tid < 5) {
         // bump allocation from one of NSHARD sub-arenas (spreads the same-address atomics); one lane per arena
         const int shd = blockIdx.x & (NSHARD - 1);
-        unsigned long long *ctr = tid == 0 ? &d.c->node[shd].v : tid == 1 ? &d.c->pos[shd].v : tid == 2 ? &d.c->db[shd].v : tid == 3 ? &d.c->br[shd].v : &d.c->nlist[shd].v;
+        unsigned long long *ctr = tid == 0 ? &d.c->node[shd].v : tid == 1 ? &d.c->pos[shd].v : tid == 2 ? &d.c->sp[shd].v : tid == 3 ? &d.c->br[shd].v : &d.c->nlist[shd].v;
         const unsigned long long want = tid == 0 ? (unsigned long long)tot_new : tid == 1 ? (unsigned long long)tot_pos
-                                      : tid == 2 ? (unsigned long long)L : tid == 3 ? (unsigned long long)tot_br : (unsigned long long)tot_nodes;
-        const unsigned long long cap = tid == 0 || tid == 4 ? d.nd_shard_cap : tid == 1 ? d.pos_shard_cap : tid == 2 ? d.db_shard_cap : d.br_shard_cap;
+                                      : tid == 2 ? (unsigned long long)tot_sp : tid == 3 ? (unsigned long long)tot_br : (unsigned long long)tot_nodes;
+        const unsigned long long cap = tid == 0 || tid == 4 ? d.nd_shard_cap : tid == 1 ? d.pos_shard_cap : tid == 2 ? d.sp_shard_cap : d.br_shard_cap;
         const unsigned long long b0 = want ? atomicAdd(ctr, want) : 0ULL;
         const bool bad = b0 + want > cap;
-        if (bad) atomicOr(&d.c->overflow, tid == 0 || tid == 4 ? OVF_NODE : tid == 1 ? OVF_POS : tid == 2 ? OVF_DB : OVF_BR);
-        const unsigned long long origin = tid == 0 || tid == 4 ? d.nd_base : tid == 1 ? d.pos_base : tid == 2 ? d.db_base : 0ULL;
+        if (bad) atomicOr(&d.c->overflow, tid == 0 || tid == 4 ? OVF_NODE : tid == 1 ? OVF_POS : tid == 2 ? OVF_SP : OVF_BR);
+        const unsigned long long origin = tid == 0 || tid == 4 ? d.nd_base : tid == 1 ? d.pos_base : 0ULL;
         sh64[tid] = origin + (unsigned long long)shd * cap + b0;
         const unsigned long long anybad = __ballot(bad);
         if (tid == 0) shi[0] = anybad ? 0 : 1;
     }
     __syncthreads();
-    if (!shi[0]) { if (tid == 0) { d.st[sid].nnodes = 0; d.st[sid].node0 = 0; d.st[sid].db = 0; } return; }
-    const unsigned long long nbase = sh64[0], pbase = sh64[1], tbase = sh64[2], bbase = sh64[3], lbase = sh64[4];
+    if (!shi[0]) { if (tid == 0) { d.st[sid].nnodes = 0; d.st[sid].node0 = 0; d.st[sid].sp = 0; d.st[sid].nsp = 0; } return; }
+    const unsigned long long nbase = sh64[0], pbase = sh64[1], sbase = sh64[2], bbase = sh64[3], lbase = sh64[4];
     MSTAMP(2);   // allocation
 
     // pass 2: per tile: descriptors -> LDS, prefix sums, node-list entries, records and flat copies of the regions created here
-    int run_nodes = 0, run_new = 0, run_pos = 0, run_br = 0;
+    int run_nodes = 0, run_new = 0, run_pos = 0, run_br = 0, run_sp = 0;
     for (int base = 0; base < mprod; base += TILE) {
         const int k = base + tid;
         const int kt = mprod - base < TILE ? mprod - base : TILE;
@@ -1979,47 +1975,42 @@ __global__ __launch_bounds__(MAT_NT, RAFFT_MAT_WAVES) void materialize_kernel(De
             }
             d.br[bbase + run_br + f] = v;
         }
-        // the stems in the dot-bracket row
+        // the pairs of the stems (rafft/rafft.py:97,127-128 marks them in the parent's dot-bracket row; here the row is implicit)
         for (int f = tid; f < ts; f += MAT_NT) {
             int lo = 0, hi = kt - 1;
             while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (ns[mid] <= f) lo = mid; else hi = mid - 1; }
             const int t = f - ns[lo];
             const uint16_t *pp = d.pos + k_srcpos[lo];
-            sdb[pp[k_mi[lo] - t] & pmask] = '('; sdb[pp[k_mj[lo] + t] & pmask] = ')';
+            d.sp[sbase + run_sp + f] = (uint32_t)(pp[k_mi[lo] - t] & pmask) | ((uint32_t)(pp[k_mj[lo] + t] & pmask) << 16);
         }
-        run_nodes += tn; run_new += tw; run_pos += tp; run_br += tb;
+        run_nodes += tn; run_new += tw; run_pos += tp; run_br += tb; run_sp += ts;
         __syncthreads();
         MSTAMP(5);   // region copies
     }
-    uint8_t *odb = d.db + tbase;
-    for (int x = tid; x < L; x += MAT_NT) odb[x] = sdb[x];
-    if (tid == 0) { d.st[sid].node0 = (int)lbase; d.st[sid].nnodes = tot_nodes; d.st[sid].db = tbase; }
-    MSTAMP(6);   // row out
+    if (tid == 0) { d.st[sid].node0 = (int)lbase; d.st[sid].nnodes = tot_nodes; d.st[sid].sp = sbase; d.st[sid].nsp = tot_sp; }
+    MSTAMP(6);   // structure record
     if (mprof) for (int k = 0; k < 7; k++) atomicAdd(&d.prof_e[k], macc[k]);
 #undef MSTAMP
 }
 
 // The same with TEAMS of 16 lanes: four new beam members per wavefront (round 4).  materialize_kernel is a chain of four dependent
-// round trips per structure (record -> parent's lists and row -> slot claim / region headers / candidates -> stem positions and
+// round trips per structure (record -> parent's lists -> slot claim / region headers / candidates -> stem positions and
 // arena allocation -> writes) in which a lane stands for one productive region of the parent - three to five of them on the benchmark
 // set - so a wavefront per structure keeps 60 lanes idle through the chain, and what a CU holds of such wavefronts (20, by registers)
 // bounds the structures in flight.  With four structures per wavefront the same CU holds four times as many.  Used when the
-// productive-region lists are the short ones (max_prod <= MAT4_PROD) and the rows fit (host: Wave::after_beam); identical results -
+// productive-region lists are the short ones (max_prod <= MAT4_PROD; host: Wave::after_beam); identical results -
 // the arenas are bump allocated, so only the PLACES of records and lists differ from the one-structure form.
 #define MAT4_TL 16
 #define MAT4_TEAMS (64 / MAT4_TL)
 #define MAT4_PROD 64
-__global__ __launch_bounds__(64, RAFFT_MAT_WAVES) void materialize_team_kernel(Dev d, int n_mat, int row_cap)
+__global__ __launch_bounds__(64, RAFFT_MAT_WAVES) void materialize_team_kernel(Dev d, int n_mat)
 {
-    extern __shared__ __align__(16) uint8_t mat_dyn[];
     const int tid = threadIdx.x, team = tid / MAT4_TL, tl = tid % MAT4_TL;
-    // dynamic LDS per team: the productive-region lists (MAT4_PROD entries each), then the dot-bracket staging row (row_cap bytes)
-    uint8_t *tbase = mat_dyn + (size_t)team * (20 * MAT4_PROD + (size_t)row_cap);
-    unsigned long long *prod_off = (unsigned long long *)tbase;
-    int *prod_node = (int *)(prod_off + MAT4_PROD);
-    int *prod_cnt = prod_node + MAT4_PROD;
-    int *sel = prod_cnt + MAT4_PROD;
-    uint8_t *sdb = (uint8_t *)(sel + MAT4_PROD);
+    // LDS per team: the productive-region lists (MAT4_PROD entries each)
+    __shared__ unsigned long long prod_off_[MAT4_TEAMS][MAT4_PROD];
+    __shared__ int prod_node_[MAT4_TEAMS][MAT4_PROD], prod_cnt_[MAT4_TEAMS][MAT4_PROD], sel_[MAT4_TEAMS][MAT4_PROD];
+    unsigned long long *prod_off = prod_off_[team];
+    int *prod_node = prod_node_[team], *prod_cnt = prod_cnt_[team], *sel = sel_[team];
     // per-tile descriptors (one lane per productive region; index = lane of the wavefront) and the flat-copy prefix sums of every team
     __shared__ unsigned long long k_srcpos[64], k_srcbr[64];
     __shared__ int k_mi[64], k_mj[64], k_nb[64], k_lo0[64], k_loo[64], k_hio[64], k_newbr[64];
@@ -2031,7 +2022,7 @@ __global__ __launch_bounds__(64, RAFFT_MAT_WAVES) void materialize_team_kernel(D
     const int mat_i = blockIdx.x * MAT4_TEAMS + team;
     const bool live = mat_i < n_mat;
     MatRec rec;
-    rec.sid = 0; rec.sq = 0; rec.L = 0; rec.dcal = 0; rec.nprod = 0; rec.combo = 0; rec.prod = 0; rec.pdb = 0;
+    rec.sid = 0; rec.sq = 0; rec.L = 0; rec.dcal = 0; rec.nprod = 0; rec.combo = 0; rec.prod = 0; rec.pad2 = 0;
     if (live) rec = d.mat[mat_i];
     const int sid = rec.sid, sq = rec.sq, L = rec.L, my_dcal = rec.dcal;
     const uint64_t soff = live ? (uint64_t)d.seq_off[sq] : 0;
@@ -2042,8 +2033,6 @@ __global__ __launch_bounds__(64, RAFFT_MAT_WAVES) void materialize_team_kernel(D
         const ProdEnt *pl = d.prod + rec.prod;             // the parent's productive regions (beam_step prepass)
         for (int k = tl; k < mprod; k += MAT4_TL) { const ProdEnt pe = pl[k]; prod_node[k] = pe.node; prod_cnt[k] = (int)pe.cnt; prod_off[k] = pe.off; sel[k] = 0; }
     }
-    const uint8_t *pdb = d.db + rec.pdb;                  // the parent's dot-bracket row (rafft/rafft.py:97,127-128)
-    for (int x = tl; x < L; x += MAT4_TL) sdb[x] = pdb[x];
     wave_sync();
     if (tl == 0) {       // digits of the combo, last region fastest; high digits of a small index stay 0
         unsigned long long idx = rec.combo;
@@ -2065,10 +2054,10 @@ __global__ __launch_bounds__(64, RAFFT_MAT_WAVES) void materialize_team_kernel(D
     const bool memo = d.memo != 0;
     MatDesc md;
     md.flags = 0; md.win = 0; md.nnod = 0; md.npos_in = md.npos_out = md.nbr_in = md.nbr_out = 0; md.nb = 0; md.cidx = 0;
-    int tot_nodes = 0, tot_new = 0, tot_pos = 0, tot_br = 0;
+    int tot_nodes = 0, tot_new = 0, tot_pos = 0, tot_br = 0, tot_sp = 0;
     for (int base = 0; base < mprod; base += TILE) {
         const int k = base + tl;
-        int nnod = 0, nnew = 0, npos = 0, nbrr = 0;
+        int nnod = 0, nnew = 0, npos = 0, nbrr = 0, nsp = 0;
         if (k < mprod && tl < TILE) {
             const unsigned long long cidx = prod_off[k] + (unsigned long long)sel[k];
             unsigned long long old = 0;
@@ -2078,38 +2067,39 @@ __global__ __launch_bounds__(64, RAFFT_MAT_WAVES) void materialize_team_kernel(D
             if (memo) win &= ((old >> 31) & 1ULL ? 0 : 1) | ((old >> 63) & 1ULL ? 0 : 2);
             md.win = win;
             if (!one_tile) sel[k] |= win << 28;
-            nnod = md.nnod; nnew = (win & 1) + (win >> 1);
+            nnod = md.nnod; nnew = (win & 1) + (win >> 1); nsp = md.nb;
             npos = ((win & 1) ? md.npos_in : 0) + ((win & 2) ? md.npos_out : 0);
             nbrr = ((win & 1) ? md.nbr_in : 0) + ((win & 2) ? md.nbr_out : 0);
         }
         for (int o = MAT4_TL / 2; o > 0; o >>= 1) {
             nnod += __shfl_xor(nnod, o, MAT4_TL); nnew += __shfl_xor(nnew, o, MAT4_TL); npos += __shfl_xor(npos, o, MAT4_TL); nbrr += __shfl_xor(nbrr, o, MAT4_TL);
+            nsp += __shfl_xor(nsp, o, MAT4_TL);
         }
-        tot_nodes += nnod; tot_new += nnew; tot_pos += npos; tot_br += nbrr;
+        tot_nodes += nnod; tot_new += nnew; tot_pos += npos; tot_br += nbrr; tot_sp += nsp;
     }
     bool ok = live;
     if (tl < 5 && live) {
         // bump allocation from one of NSHARD sub-arenas; one lane per arena
         const int shd = mat_i & (NSHARD - 1);
-        unsigned long long *ctr = tl == 0 ? &d.c->node[shd].v : tl == 1 ? &d.c->pos[shd].v : tl == 2 ? &d.c->db[shd].v : tl == 3 ? &d.c->br[shd].v : &d.c->nlist[shd].v;
+        unsigned long long *ctr = tl == 0 ? &d.c->node[shd].v : tl == 1 ? &d.c->pos[shd].v : tl == 2 ? &d.c->sp[shd].v : tl == 3 ? &d.c->br[shd].v : &d.c->nlist[shd].v;
         const unsigned long long want = tl == 0 ? (unsigned long long)tot_new : tl == 1 ? (unsigned long long)tot_pos
-                                      : tl == 2 ? (unsigned long long)L : tl == 3 ? (unsigned long long)tot_br : (unsigned long long)tot_nodes;
-        const unsigned long long cap = tl == 0 || tl == 4 ? d.nd_shard_cap : tl == 1 ? d.pos_shard_cap : tl == 2 ? d.db_shard_cap : d.br_shard_cap;
+                                      : tl == 2 ? (unsigned long long)tot_sp : tl == 3 ? (unsigned long long)tot_br : (unsigned long long)tot_nodes;
+        const unsigned long long cap = tl == 0 || tl == 4 ? d.nd_shard_cap : tl == 1 ? d.pos_shard_cap : tl == 2 ? d.sp_shard_cap : d.br_shard_cap;
         const unsigned long long b0 = want ? atomicAdd(ctr, want) : 0ULL;
         const bool bad = b0 + want > cap;
-        if (bad) atomicOr(&d.c->overflow, tl == 0 || tl == 4 ? OVF_NODE : tl == 1 ? OVF_POS : tl == 2 ? OVF_DB : OVF_BR);
-        const unsigned long long origin = tl == 0 || tl == 4 ? d.nd_base : tl == 1 ? d.pos_base : tl == 2 ? d.db_base : 0ULL;
+        if (bad) atomicOr(&d.c->overflow, tl == 0 || tl == 4 ? OVF_NODE : tl == 1 ? OVF_POS : tl == 2 ? OVF_SP : OVF_BR);
+        const unsigned long long origin = tl == 0 || tl == 4 ? d.nd_base : tl == 1 ? d.pos_base : 0ULL;
         sh64_[team][tl] = origin + (unsigned long long)shd * cap + b0;
         ok = !bad;
     }
     // (every lane of the team learns whether all five allocations fit)
     ok = ((__ballot(!ok) & tmask) == 0ULL) && live;
     wave_sync();
-    if (!ok) { if (tl == 0 && live) { d.st[sid].nnodes = 0; d.st[sid].node0 = 0; d.st[sid].db = 0; } }
-    const unsigned long long nbase = sh64_[team][0], pbase = sh64_[team][1], tbase_db = sh64_[team][2], bbase = sh64_[team][3], lbase = sh64_[team][4];
+    if (!ok) { if (tl == 0 && live) { d.st[sid].nnodes = 0; d.st[sid].node0 = 0; d.st[sid].sp = 0; d.st[sid].nsp = 0; } }
+    const unsigned long long nbase = sh64_[team][0], pbase = sh64_[team][1], sbase = sh64_[team][2], bbase = sh64_[team][3], lbase = sh64_[team][4];
 
     // pass 2: per tile: descriptors -> LDS, prefix sums, node-list entries, records and flat copies of the regions created here
-    int run_nodes = 0, run_new = 0, run_pos = 0, run_br = 0;
+    int run_nodes = 0, run_new = 0, run_pos = 0, run_br = 0, run_sp = 0;
     const int mp2 = ok ? mprod : 0;
     for (int base = 0; base < mp2; base += TILE) {
         const int k = base + tl;
@@ -2190,21 +2180,17 @@ __global__ __launch_bounds__(64, RAFFT_MAT_WAVES) void materialize_team_kernel(D
             }
             d.br[bbase + run_br + f] = v;
         }
-        for (int f = tl; f < ts; f += MAT4_TL) {          // the stems in the dot-bracket row
+        for (int f = tl; f < ts; f += MAT4_TL) {          // the pairs of the stems
             int lo = 0, hi = kt - 1;
             while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (ns[mid] <= f) lo = mid; else hi = mid - 1; }
             const int t = f - ns[lo];
             const uint16_t *pp = d.pos + k_srcpos[tb + lo];
-            sdb[pp[k_mi[tb + lo] - t] & pmask] = '('; sdb[pp[k_mj[tb + lo] + t] & pmask] = ')';
+            d.sp[sbase + run_sp + f] = (uint32_t)(pp[k_mi[tb + lo] - t] & pmask) | ((uint32_t)(pp[k_mj[tb + lo] + t] & pmask) << 16);
         }
-        run_nodes += tn; run_new += tw; run_pos += tp; run_br += tbr;
+        run_nodes += tn; run_new += tw; run_pos += tp; run_br += tbr; run_sp += ts;
         wave_sync();
     }
-    if (ok) {
-        uint8_t *odb = d.db + tbase_db;
-        for (int x = tl; x < L; x += MAT4_TL) odb[x] = sdb[x];
-        if (tl == 0) { d.st[sid].node0 = (int)lbase; d.st[sid].nnodes = tot_nodes; d.st[sid].db = tbase_db; }
-    }
+    if (ok && tl == 0) { d.st[sid].node0 = (int)lbase; d.st[sid].nnodes = tot_nodes; d.st[sid].sp = sbase; d.st[sid].nsp = tot_sp; }
 }
 
 // ------------------------------------------------------------ dedupe kernel
@@ -2318,14 +2304,11 @@ __global__ void init_roots_kernel(Dev d)
     const int L = d.seq_len[sq];
     // structure sq / node sq are the unfolded structure and its single region (rafft.py:224-231)
     const unsigned long long off = (unsigned long long)d.seq_off[sq];
-    for (int x = tid; x < L; x += blockDim.x) {
-        d.db[off + x] = '.';
-        d.pos[off + x] = (uint16_t)(d.pos_packed ? x | (d.codes[off + x] << 12) : x);
-    }
+    for (int x = tid; x < L; x += blockDim.x) d.pos[off + x] = (uint16_t)(d.pos_packed ? x | (d.codes[off + x] << 12) : x);
 
     if (tid == 0) {
         d.st[sq].seq = sq; d.st[sq].dcal = 0; d.st[sq].h1 = 0; d.st[sq].h2 = 0;
-        d.st[sq].db = off; d.st[sq].node0 = sq; d.st[sq].nnodes = L > 0 ? 1 : 0; d.st[sq].cursor = 0; d.st[sq].total = 0;
+        d.st[sq].sp = 0; d.st[sq].nsp = 0; d.st[sq].node0 = sq; d.st[sq].nnodes = L > 0 ? 1 : 0; d.st[sq].cursor = 0; d.st[sq].total = 0;
         d.st[sq].parent = -1; d.st[sq].combo = 0;
         d.nd[sq].seq = sq; d.nd[sq].pdcal = 0; d.nd[sq].pos = off; d.nd[sq].n = L; d.nd[sq].ci = -1; d.nd[sq].cj = L;
         d.nd[sq].L = L; d.nd[sq].soff = off;
@@ -2347,8 +2330,12 @@ __global__ void init_roots_kernel(Dev d)
 // One record = the beam of one sequence at one step (all of them with traj, the last one otherwise); its rows
 // go out back to back, `off` bytes into the result buffer, row numbers from `row0`.
 struct OutRec { long long off; int row0, w, cnt, L; };
+// The dot-bracket rows are made HERE: a structure is stored as the pairs it added to its parent's (materialize kernels), so a row is
+// the unfolded one (rafft.py:224-231) with the stems of the whole lineage marked (rafft/rafft.py:97,127-128) - built in LDS (dynamic,
+// the longest sequence of the wave) and written out once.
 __global__ void output_kernel(Dev d, int nrows, int nrec, const OutRec *recs, char *out_db, int *out_dcal)
 {
+    extern __shared__ __align__(16) uint8_t out_row[];
     for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
         int lo = 0, hi = nrec - 1;                      // record holding row r
         while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (recs[mid].row0 <= r) lo = mid; else hi = mid - 1; }
@@ -2356,10 +2343,18 @@ __global__ void output_kernel(Dev d, int nrows, int nrec, const OutRec *recs, ch
         const int k = r - rc.row0;
         const int sid = d.tsid[rc.w + k];
         const int L = rc.L;
-        const uint8_t *db = d.db + d.st[sid].db;
+        for (int x = threadIdx.x; x < L; x += blockDim.x) out_row[x] = '.';
+        __syncthreads();
+        for (int s = sid; s >= 0; s = d.st[s].parent) {          // (the unfolded structure has parent -1 and no pairs)
+            const uint32_t *pl = d.sp + d.st[s].sp;
+            const int np = d.st[s].nsp;
+            for (int x = threadIdx.x; x < np; x += blockDim.x) { const uint32_t u = pl[x]; out_row[u & 0xFFFFu] = '('; out_row[u >> 16] = ')'; }
+        }
+        __syncthreads();
         char *o = out_db + rc.off + (long long)k * (L + 1);
-        for (int x = threadIdx.x; x < L; x += blockDim.x) o[x] = (char)db[x];
+        for (int x = threadIdx.x; x < L; x += blockDim.x) o[x] = (char)out_row[x];
         if (threadIdx.x == 0) { o[L] = 0; out_dcal[r] = d.st[sid].dcal; }
+        __syncthreads();
     }
 }
 
