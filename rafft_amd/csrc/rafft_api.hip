@@ -415,6 +415,7 @@ struct Caps {
     size_t st, nd, pos, br, sp, cand, seen, trec, tsid, work, mat, looptab;
     int ch_cap, sort_cap;
     size_t bytes;
+    bool capped;      // a table hit the limit of its 31-bit ids: the job is folded in halves when it has more than one sequence
 };
 
 Caps plan_caps(size_t S, size_t sumL, const rafft_params &p, double est)
@@ -432,10 +433,16 @@ Caps plan_caps(size_t S, size_t sumL, const rafft_params &p, double est)
     c.st = (size_t)std::min(nstruct, 2.0e9) + 64;
     double nodes_per = avgL / 60.0 + 4.0;
     c.nd = (size_t)std::min((double)c.st * nodes_per, 2.0e9) + 64;
+    c.capped = nstruct > 2.0e9 || (double)c.st * nodes_per > 2.0e9;
     c.pos = (size_t)((double)sumL + (double)(c.st - S) * avgL * 0.9) + 4096;
     c.br = c.nd * 3 + 4096;
     c.sp = (size_t)((double)(c.st - S) * (avgL * 0.05 + 24.0)) + 4096;
     c.cand = std::max<size_t>(c.nd * (size_t)std::min(std::max(p.nb_mode, 1), 8) + 4096, (size_t)NSHARD * 16384);
+    // (a child slot is named by 2 x candidate + side in 31 bits - the node lists hold -(slot + 1), rafft_kernels.h - so a wave has
+    //  at most 2^30 candidate records; round 4's structure rows used to keep the byte budget of a wave below that by themselves)
+    size_t cand_limit = ((size_t)1 << 30) - 4096;
+    if (const char *e = getenv("RAFFT_TEST_CAND_LIMIT")) cand_limit = std::min<size_t>(cand_limit, std::max<size_t>((size_t)atoll(e), (size_t)NSHARD * 16384));   // (tests: the split path on small jobs)
+    if (c.cand > cand_limit) { c.cand = cand_limit; c.capped = true; }
     // accepted children per sequence ~ steps * min(max_branch, ...); regions double and old ones are dropped
     // (measured, ms 50, max_branch 1000, regions abandoned by rehashing included: the benchmark set's bulk uses 4.6 x est x
     //  (B + max_branch / 4) slots per sequence, its two 2.9-knt sequences 11.6 x.  A factor of 24 used to reserve 1 MB per
@@ -1198,12 +1205,12 @@ int Wave::finish_done_body()
     }
     if (getenv("RAFFT_TRACE")) {
         auto mx = [&](const ShardCtr *sc) { unsigned long long m = 0, t = 0; for (int i = 0; i < NSHARD; i++) { m = std::max(m, sc[i].v); t += sc[i].v; } return std::make_pair(m, t); };
-        auto nd = mx(hc.node), po = mx(hc.pos), br = mx(hc.br), spr = mx(hc.sp), ca = mx(hc.cand), pr = mx(hc.prod);
+        auto nd = mx(hc.node), po = mx(hc.pos), br = mx(hc.br), spr = mx(hc.sp), ca = mx(hc.cand), pr = mx(hc.prod), nl = mx(hc.nlist);
         fprintf(stderr, "[rafft] max productive regions per structure: %u (limit %d)\n", hc.max_nprod, d.max_prod);
-        fprintf(stderr, "[rafft] arenas used/cap (max shard | total): st %llu/%zu  nd %llu/%llu|%llu  pos %llu/%llu|%llu  br %llu/%llu|%llu  sp %llu/%llu|%llu  cand %llu/%llu|%llu  prod %llu/%llu  seen %llu/%zu  est %.1f\n",
+        fprintf(stderr, "[rafft] arenas used/cap (max shard | total): st %llu/%zu  nd %llu/%llu|%llu  pos %llu/%llu|%llu  br %llu/%llu|%llu  sp %llu/%llu|%llu  cand %llu/%llu|%llu  prod %llu/%llu|%llu  nlist %llu/%llu|%llu  seen %llu/%zu  est %.1f\n",
                 hc.n_struct, c.st, nd.first, (unsigned long long)d.nd_shard_cap, nd.second, po.first, (unsigned long long)d.pos_shard_cap, po.second,
                 br.first, (unsigned long long)d.br_shard_cap, br.second, spr.first, (unsigned long long)d.sp_shard_cap, spr.second,
-                ca.first, (unsigned long long)d.cand_shard_cap, ca.second, pr.first, (unsigned long long)d.prod_shard_cap, hc.seen_top, c.seen, est);
+                ca.first, (unsigned long long)d.cand_shard_cap, ca.second, pr.first, (unsigned long long)d.prod_shard_cap, pr.second, nl.first, (unsigned long long)d.nd_shard_cap, nl.second, hc.seen_top, c.seen, est);
     }
     if (getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] host time inside issue_step %.3f ms, inside after_beam (incl. nested issue_step and this tail) %.3f ms\n", ms_issue, ms_after);
     if (getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] wave S=%zu setup %.2f ms, loop %.2f ms (%d steps), tail %.2f ms (counters %.3f, records+gather %.3f, rows out %.3f incl. %.1f MB D2H)\n",
@@ -1572,7 +1579,7 @@ static void scheduler_main()
                 const size_t big_wave = (size_t)((double)g.hbm_total * big_wave_frac);
                 if (cc.bytes > big_wave)
                     for (int k = 0; k < MAX_PIPES; k++) if (slot[k].wave && slot[k].wave->c.bytes > big_wave) fits_now = false;
-                if ((cc.bytes > budget || (!fits_now && n_running == 0)) && job.seqs.size() > 1) {
+                if ((cc.bytes > budget || cc.capped || (!fits_now && n_running == 0)) && job.seqs.size() > 1) {
                     const size_t h = job.seqs.size() / 2;          // too big for one wave: two jobs, one after the other
                     Job a{std::vector<SeqIn>(job.seqs.begin(), job.seqs.begin() + h), job.est, job.depth, job.members, true, job.big_prod};
                     Job c{std::vector<SeqIn>(job.seqs.begin() + h, job.seqs.end()), job.est, job.depth, job.members, true, job.big_prod};

@@ -310,6 +310,24 @@ def test_gpu_large_nb_mode_on_long_sequences_vs_oracle():
             assert as_lists(traj) == as_lists(o), (len(s), nb_mode, ms)
 
 
+def test_gpu_job_whose_candidate_table_would_outgrow_its_31_bit_slot_ids_is_split(monkeypatch):
+    """a child slot is named by 2 x candidate + side in 31 bits (node lists hold -(slot + 1)): a job planned for more than 2^30
+    candidate records is folded in halves.  (Found the hard way: with the dot-bracket arena gone the byte budget of a wave stopped
+    keeping BASELINE configs[3] on one GPU below that - a negative slot, a memory fault.)  The hook lowers the limit to the 1 M
+    floor, so 200 sequences of 200 nt become eight waves; same beams."""
+    rng = np.random.default_rng(230)
+    seqs = ["".join(rng.choice(list("ACGU"), 200)) for _ in range(200)]
+    want = [[(x.str_struct, x.dcal) for x in r] for r in rafft_amd.fold_batch(seqs, 100, 50, 1000)]
+    launches_one = rafft_amd.last_stats()["n_expand_launches"]
+    monkeypatch.setenv("RAFFT_TEST_CAND_LIMIT", "1")
+    got = [[(x.str_struct, x.dcal) for x in r] for r in rafft_amd.fold_batch(seqs, 100, 50, 1000)]
+    st = rafft_amd.last_stats()
+    monkeypatch.delenv("RAFFT_TEST_CAND_LIMIT")
+    assert got == want
+    # (launches of the one-wavefront expand kernel, summed over the waves of the call)
+    assert st["n_expand_launches"] > 2 * launches_one and st["n_regrows"] == 0, (st["n_expand_launches"], launches_one)
+
+
 def test_gpu_more_productive_regions_than_the_short_lists_hold(monkeypatch):
     """a structure with more productive regions than materialize_kernel's short LDS lists hold (64; here the hook makes it 3)
     is no error: the wave is folded again with the long lists - same trajectories, one regrowth on record - and later waves
