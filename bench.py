@@ -17,7 +17,7 @@ N > 1: WEAK scaling, per-GPU work fixed: the global batch of a step is N copies 
        the reference's driver does with Pool(int(argv[1])), benchmark_results/bench_fft.py:17 - before anything touches
        the GPU, relays rank 0's line and fails if any rank does.
 
-Steps are issued through the library's asynchronous C-ABI (rafft_fold_submit / rafft_fold_wait) with up to fifteen batches
+Steps are issued through the library's asynchronous C-ABI (rafft_fold_submit / rafft_fold_wait) with up to twenty-one batches
 in flight - continuous batching: queued batches with identical parameters are folded as ONE wave by the library's
 scheduler (fewer, fuller kernel launches), and the nearly empty last folding steps of step k (only the longest sequences still fold)
 run beside the busy first steps of step k+1.  Every step is waited for, and its result freed, inside the timed
@@ -41,7 +41,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
-PIPELINE_DEPTH = int(os.environ.get("BENCH_DEPTH", "15"))   # batches in flight: three waves of up to five merged batches (profiling passes use 1)
+PIPELINE_DEPTH = int(os.environ.get("BENCH_DEPTH", "21"))   # batches in flight: three waves of up to seven merged batches (profiling passes use 1)
 
 
 def load_bench_sequences():
@@ -518,7 +518,7 @@ def main():
                        "parallelism": (f"LPT sequence shards x{world}, no collective" if world > 1 else "1 GPU"),
                        "batches_in_flight": DEPTH_RUN,
                        "scheduler": "queued batches with equal parameters are folded as ONE wave of up to "
-                                    + os.environ.get("RAFFT_MERGE_SEQS", "11500") + " sequences (5 steps of this workload), three waves at a time; "
+                                    + os.environ.get("RAFFT_MERGE_SEQS", "16384") + " sequences (7 steps of this workload), three waves at a time; "
                                     "ms_per_call_sequential is one synchronous call"},
             "roofline": {"bound": "hbm", "kernel": "expand_kernel<64,true,16> (regions of 33..256 positions, up to 128 branches; 16 one-wavefront teams per workgroup)", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),

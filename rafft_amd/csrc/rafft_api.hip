@@ -1278,11 +1278,12 @@ static unsigned admit_below()
 }
 // sequences one merged wave may hold (a wave of the whole benchmark set four times over folds 25 % faster per sequence
 // than the set alone: fewer, fuller launches; five times over - with ten batches in flight, so that two such waves run side by
-// side - another 4 % in round 3: 288 k sequences/s against 277-282 k over 30 steps; beyond that the arenas of a wave pass a tenth
-// of the HBM, where waves run one at a time)
+// side - another 4 % in round 3: 288 k sequences/s against 277-282 k over 30 steps; seven times over, three such waves side by side,
+// 432-444 k -> 461-464 k in round 4, tools/ab_waves2.sh; beyond that the arenas of a wave pass a tenth of the HBM, where waves run
+// one at a time)
 static size_t merge_cap()
 {
-    static const size_t v = getenv("RAFFT_MERGE_SEQS") ? (size_t)atol(getenv("RAFFT_MERGE_SEQS")) : 11500;
+    static const size_t v = getenv("RAFFT_MERGE_SEQS") ? (size_t)atol(getenv("RAFFT_MERGE_SEQS")) : 16384;
     return v;
 }
 
