@@ -426,13 +426,14 @@ def main():
         t_seq = (time.perf_counter() - t1) / 5
         t1 = time.perf_counter()
         q = []
-        for _ in range(6):
+        n_py = 2 * PIPELINE_DEPTH           # (as many batches in flight as the timed loop keeps, twice over)
+        for _ in range(n_py):
             q.append(rafft_amd.submit_batch(seqs, args.nb_mode, args.max_stack, args.max_branch))
             if len(q) >= PIPELINE_DEPTH:
                 q.pop(0).result()
         while q:
             q.pop(0).result()
-        t_pipe = (time.perf_counter() - t1) / 6
+        t_pipe = (time.perf_counter() - t1) / n_py
         py_api = {"fold_batch_ms": round(t_seq * 1e3, 3), "fold_batch_sequences_per_s": round(n / t_seq, 1),
                   "submit_batch_pipelined_sequences_per_s": round(n / t_pipe, 1), "first_structure": first[:24] + "..."}
     # informational, outside the timed region: the same call on a 4x larger batch (the set replicated 4 times in

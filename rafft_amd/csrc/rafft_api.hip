@@ -437,7 +437,14 @@ Caps plan_caps(size_t S, size_t sumL, const rafft_params &p, double est)
     c.pos = (size_t)((double)sumL + (double)(c.st - S) * avgL * 0.9) + 4096;
     c.br = c.nd * 3 + 4096;
     c.sp = (size_t)((double)(c.st - S) * (avgL * 0.05 + 24.0)) + 4096;
-    c.cand = std::max<size_t>(c.nd * (size_t)std::min(std::max(p.nb_mode, 1), 8) + 4096, (size_t)NSHARD * 16384);
+    c.cand = c.nd * (size_t)std::min(std::max(p.nb_mode, 1), 8) + 4096;
+    // (with memoization a region is created once per wave, whoever picks the stem that makes it: what a structure adds to the candidate
+    //  table stops growing with the regions it HAS.  Measured, tools/arena_probe.py, candidates per structure: 10-20 on the benchmark
+    //  set, 200-nt and 40-nt random sequences, ms 50 and 400; 15 on L 100..3000 at ms 200 - where the line above plans 238 -; 46 at
+    //  ms 1; 50 on G/C-only sequences of 600 nt; 59 and 95 on 2.9-knt and 8-knt sequences at ms 50 and 20)
+    const bool memo_on = p.min_nrj == 0.0 && !(getenv("RAFFT_NO_MEMO") && atoi(getenv("RAFFT_NO_MEMO")));
+    if (memo_on) c.cand = std::min(c.cand, (size_t)((double)c.st * (60.0 + avgL / 40.0)) + 4096);
+    c.cand = std::max<size_t>(c.cand, (size_t)NSHARD * 16384);
     // (a child slot is named by 2 x candidate + side in 31 bits - the node lists hold -(slot + 1), rafft_kernels.h - so a wave has
     //  at most 2^30 candidate records; round 4's structure rows used to keep the byte budget of a wave below that by themselves)
     size_t cand_limit = ((size_t)1 << 30) - 4096;
