@@ -302,6 +302,7 @@ def main():
     while time.perf_counter() - t_pre < float(os.environ.get("BENCH_PREWARM_S", "0.5")):
         mine.run(DEPTH_RUN, depth=DEPTH_RUN)
     mine.run(args.warmup, depth=DEPTH_RUN)
+    agg_untimed = dict(mine.agg)        # (pre-warm and warmup launches: with the timed ones they are what rocprofv3 averages over)
     mine.agg = {}
     barrier()
     if os.environ.get("RAFFT_TRACE_ALLOC"):
@@ -471,6 +472,10 @@ def main():
             # batches per wave, i.e. fewer and bigger launches: per launch LIKE `achieved` = bytes per batch / launches per step
             traffic = round(traffic_batch * args.steps / launches)
             traffic_src += "; per batch in the PMC run, divided by the launches per step of the timed loop"
+        # rocprofv3 --stats averages over EVERY launch of the process - warmup waves (W batches: a smaller wave than the timed loop's
+        # seven) included: the same average from the library's HIP events, to set beside profiles/*_kernel_stats.csv
+        launches_all = launches + agg_untimed.get("n_expand_launches", 0)
+        dur_all_ms = (agg.get("ms_expand", 0.0) + agg_untimed.get("ms_expand", 0.0)) / max(1, launches_all)
         dur_s = agg.get("ms_expand", 0.0) / 1e3 / launches
         bytes_per_launch = agg.get("alg_bytes_expand", 0) / launches
         achieved = bytes_per_launch / dur_s / 1e9 if dur_s > 0 else 0.0
@@ -526,6 +531,7 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          "alg_bytes_per_launch": round(bytes_per_launch, 1),
                          "mean_launch_ms": round(dur_s * 1e3, 4), "launches_per_step": launches / args.steps,
+                         "mean_launch_ms_all_launches": round(dur_all_ms, 4), "launches_incl_untimed": launches_all,
                          "issue_roofline": issue,
                          "traffic_age": (tj or {}).get("commit"),
                          # the PMC summary was measured on another build of rafft_amd/csrc than the one that just ran
