@@ -486,6 +486,7 @@ struct SeqIn { const char *s; int len; int idx; int bi; const uint8_t *c = nullp
 struct HostOut {   // owner of a rafft_result
     std::vector<rafft_seq_result> seq;
     std::vector<std::vector<int>> step_size, step_off;
+    std::vector<int> one_size, one_off;     // ... of a sequence with a single step (every sequence without --traj)
     std::vector<const char *> db_ptr;       // rows live in pinned chunks (one per wave): the D2H copy lands
     std::vector<const int *> dcal_ptr;      // directly in the memory the caller reads
     std::vector<std::shared_ptr<struct PinChunk>> chunks;   // a chunk may hold rows of several batches folded as one wave
@@ -938,12 +939,10 @@ int Wave::after_beam()
     if (hc.n_mat == 0) return finish();
     n_active = (unsigned)S - hc.n_done;
     last_mat = hc.n_mat;
-    // most sequences of the wave have finished: their rows leave now, beside the folding steps of the others
-    if (!p.traj && !seam && !harvested && S >= 256 && (size_t)hc.trec_n * 10 >= S * 7 && getenv("RAFFT_NO_HARVEST") == nullptr) {
-        if (int rc = emit_rows(0, (size_t)hc.trec_n, true, nullptr)) return rc;
-        harvested = (size_t)hc.trec_n;
-        if (getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] early harvest after step %d: %zu of %zu sequences\n", steps, harvested, S);
-    }
+    // most sequences of the wave have finished: their rows leave beside the folding steps of the others - once this step's kernels
+    // are queued (below): the host's share of it, a millisecond or two for a wave of 16 k sequences, is off the wave's own path
+    const bool harvest_now = !p.traj && !seam && !harvested && S >= 256 && (size_t)hc.trec_n * 10 >= S * 7 && getenv("RAFFT_NO_HARVEST") == nullptr;
+    const size_t harvest_n = (size_t)hc.trec_n;
     {
         Span sp{next_event(), next_event(), 2};
         SPAN_REC(sp.a, st, sp.kind);
@@ -974,7 +973,14 @@ int Wave::after_beam()
         HIPCHK(hipStreamSynchronize(st));
         fprintf(stderr, "[rafft] step %d: n_mat %u -> work %u %u %u %u | small %u %u\n", steps, hc.n_mat, h2.n_work[0].v, h2.n_work[1].v, h2.n_work[2].v, h2.n_work[3].v, h2.n_work[4].v, h2.n_work[5].v);
     }
-    return issue_step();
+    const int step_of_harvest = steps;
+    if (int rc = issue_step()) return rc;
+    if (harvest_now && !finished) {
+        if (int rc = emit_rows(0, harvest_n, true, nullptr)) return rc;
+        harvested = harvest_n;
+        if (getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] early harvest after step %d: %zu of %zu sequences\n", step_of_harvest, harvested, S);
+    }
+    return 0;
 }
 
 // Format the beams of trajectory records [first, first + count) as result rows on the device and copy them to a
@@ -987,8 +993,9 @@ int Wave::emit_rows(size_t first, size_t count, bool early, double *t_gather)
     Buf &b_rec = early ? g.row_off2 : g.row_off, &b_db = early ? g.out_db2 : g.out_db, &b_dc = early ? g.out_dcal2 : g.out_dcal;
     std::vector<int4> trec(count);
     if (count) HIPCHK(hipMemcpy(trec.data(), (const int4 *)g.trec.p + first, count * sizeof(int4), hipMemcpyDeviceToHost));
-    // records in (sequence, step) order; rows are laid out record after record
-    std::sort(trec.begin(), trec.end(), [](const int4 &a, const int4 &b) { return a.x != b.x ? a.x < b.x : a.y < b.y; });
+    // records in (sequence, step) order; rows are laid out record after record.  (Without --traj a sequence has ONE record: any order
+    // of the records will do, and sorting 16 k of them is a millisecond of the scheduler thread.)
+    if (p.traj) std::sort(trec.begin(), trec.end(), [](const int4 &a, const int4 &b) { return a.x != b.x ? a.x < b.x : a.y < b.y; });
     std::vector<OutRec> &recs = early ? early_recs : late_recs;     // (members: they outlive the asynchronous upload)
     recs.assign(trec.size(), OutRec{});
     long long tot_bytes = 0;
@@ -1035,11 +1042,14 @@ int Wave::emit_rows(size_t first, size_t count, bool early, double *t_gather)
         while (r1 < recs.size() && trec[r1].x == i) r1++;
         const int gi = seqs[i].idx;
         HostOut &out = out_of(i);
-        auto &ss = out.step_size[gi];
-        auto &so = out.step_off[gi];
-        ss.resize(r1 - r0); so.resize(r1 - r0);
         int o = 0;
-        for (size_t r = r0; r < r1; r++) { ss[r - r0] = recs[r].cnt; so[r - r0] = o; o += recs[r].cnt; }
+        if (r1 - r0 == 1) { out.one_size[gi] = o = recs[r0].cnt; out.one_off[gi] = 0; }      // (no heap allocation per sequence)
+        else {
+            auto &ss = out.step_size[gi];
+            auto &so = out.step_off[gi];
+            ss.resize(r1 - r0); so.resize(r1 - r0);
+            for (size_t r = r0; r < r1; r++) { ss[r - r0] = recs[r].cnt; so[r - r0] = o; o += recs[r].cnt; }
+        }
         out.dcal_ptr[gi] = all_dcal + recs[r0].row0;
         out.db_ptr[gi] = all_db + recs[r0].off;
         rafft_seq_result &sr = out.seq[gi];
@@ -1341,7 +1351,8 @@ static void finalize_batch(const std::shared_ptr<Batch> &bp)
         HostOut *ho = b.ho;
         for (int i = 0; i < b.n_seq; i++) {
             rafft_seq_result &sr = ho->seq[i];
-            sr.step_size = ho->step_size[i].data(); sr.step_off = ho->step_off[i].data();
+            const bool one = ho->step_size[i].empty();
+            sr.step_size = one ? &ho->one_size[i] : ho->step_size[i].data(); sr.step_off = one ? &ho->one_off[i] : ho->step_off[i].data();
             sr.db = ho->db_ptr[i]; sr.dcal = ho->dcal_ptr[i];
         }
         ho->res.n_seq = b.n_seq; ho->res.seq = ho->seq.data(); ho->res._owner = ho;
@@ -1745,7 +1756,7 @@ static int submit_locked(const rafft_params *p, int n_seq, const char *const *se
     Batch &b = *bp;
     b.p = *p; b.n_seq = n_seq; b.t0 = std::chrono::steady_clock::now();
     HostOut *ho = b.ho = new HostOut();
-    ho->seq.resize(n_seq); ho->step_size.resize(n_seq); ho->step_off.resize(n_seq);
+    ho->seq.resize(n_seq); ho->step_size.resize(n_seq); ho->step_off.resize(n_seq); ho->one_size.assign(n_seq, 0); ho->one_off.assign(n_seq, 0);
     ho->dcal_ptr.assign(n_seq, nullptr); ho->db_ptr.assign(n_seq, nullptr);
     // the sequences are copied: the caller's buffers may go away before rafft_fold_wait
     std::vector<int> L(n_seq);
@@ -2127,7 +2138,7 @@ int rafft_expand_node(const rafft_params *p, const char *seq, const char *db, co
     dbg.corval = (double *)b; b += 8 * K; dbg.score = (double *)b;
     std::vector<SeqIn> one{{seq, L, 0, 0}};
     HostOut ho;
-    ho.seq.resize(1); ho.step_size.resize(1); ho.step_off.resize(1); ho.dcal_ptr.assign(1, nullptr); ho.db_ptr.assign(1, nullptr);
+    ho.seq.resize(1); ho.step_size.resize(1); ho.step_off.resize(1); ho.one_size.assign(1, 0); ho.one_off.assign(1, 0); ho.dcal_ptr.assign(1, nullptr); ho.db_ptr.assign(1, nullptr);
     Batch bt;                                  // a private batch: the scheduler is idle (drained above) and g.mu is held
     bt.p = *p;
     bt.p.max_stack = std::max(1, bt.p.max_stack);
