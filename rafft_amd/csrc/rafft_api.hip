@@ -581,7 +581,7 @@ struct Wave {
     Batch &bt;                                      // the first of them: carries the wave's timing spans and statistics
     std::vector<Span> &spans;
     const SeamIn *seam;
-    size_t S = 0, sumL = 0, B = 0, bs_lds[2] = {0, 0}, mat_lds = RAFFT_MAX_LEN, mat_row = RAFFT_MAX_LEN;
+    size_t S = 0, sumL = 0, B = 0, bs_lds[2] = {0, 0}, mat_lds = RAFFT_MAX_LEN, out_row_lds = RAFFT_MAX_LEN;
     double reserve = 1.0;         // buffers are allocated for a wave this many times bigger (merged batches to come)
     bool longseq = false;         // a sequence longer than LDS_SEQ: its loops' bases are read from HBM, regions beyond 4096 positions exist
     unsigned dedupe_per_cu = 1024 / DEDUPE_NT;
@@ -837,7 +837,7 @@ int Wave::setup()
         bs_lds[v] = std::max((size_t)c.sort_cap * 8, 24 * nt) + RL_CAP * 12 + B * sizeof(ParentInfo) + (B + 1) * 8 + ((B + 3) & ~(size_t)3) * 4 + 128;
     }
     mat_lds = 20 * (size_t)d.max_prod;
-    mat_row = ((size_t)maxL + 15) & ~(size_t)15;
+    out_row_lds = ((size_t)maxL + 15) & ~(size_t)15;      // output_kernel builds a dot-bracket row in LDS: the longest sequence of the wave
     if (const char *e = getenv("RAFFT_DEDUPE_PER_CU")) dedupe_per_cu = (unsigned)std::max(1, atoi(e));
     n_active = (unsigned)S;
     ms_setup = since(tw0);
@@ -1026,7 +1026,7 @@ int Wave::emit_rows(size_t first, size_t count, bool early, double *t_gather)
     Span sp{next_event(), next_event(), 3};
     SPAN_REC(sp.a, st, sp.kind);
     unsigned grid = (unsigned)std::min<size_t>(nrows, 65536);
-    hipLaunchKernelGGL(output_kernel, dim3(grid), dim3(64), mat_row, st, d, (int)nrows, (int)recs.size(), (const OutRec *)b_rec.p,
+    hipLaunchKernelGGL(output_kernel, dim3(grid), dim3(64), out_row_lds, st, d, (int)nrows, (int)recs.size(), (const OutRec *)b_rec.p,
                        (char *)b_db.p, (int *)b_dc.p);
     HIPCHK(hipGetLastError());
     SPAN_REC(sp.b, st, sp.kind);
@@ -1600,6 +1600,10 @@ static void scheduler_main()
                     for (int k = 0; k < MAX_PIPES; k++) if (slot[k].wave && slot[k].wave->c.bytes > big_wave) fits_now = false;
                 if ((cc.bytes > budget || cc.capped || (!fits_now && n_running == 0)) && job.seqs.size() > 1) {
                     const size_t h = job.seqs.size() / 2;          // too big for one wave: two jobs, one after the other
+                    if (getenv("RAFFT_TRACE"))
+                        fprintf(stderr, "[rafft] job of %zu sequences folded in halves: plan %.1f GB (budget %.1f), this workspace holds %.1f GB, the others %.1f GB, %s%s\n",
+                                job.seqs.size(), (double)cc.bytes / 1e9, (double)budget / 1e9, (double)g.ws[w].bytes() / 1e9, (double)others / 1e9,
+                                cc.capped ? "a table at the limit of its ids, " : "", fits_now ? "fits" : "does not fit beside what is held");
                     Job a{std::vector<SeqIn>(job.seqs.begin(), job.seqs.begin() + h), job.est, job.depth, job.members, true, job.big_prod};
                     Job c{std::vector<SeqIn>(job.seqs.begin() + h, job.seqs.end()), job.est, job.depth, job.members, true, job.big_prod};
                     for (auto &m : job.members) m->pending++;      // one job became two (halves of a split are not merged again)
