@@ -25,7 +25,7 @@ enum {
     RAFFT_OK = 0,
     RAFFT_ERR_BAD_CHAR = 1,      /* reference: KeyError from prep_sequence, rafft/utils.py:73-80 */
     RAFFT_ERR_EMPTY = 2,         /* reference: numpy AxisError from flip(), rafft/utils.py:83 */
-    RAFFT_ERR_TOO_LONG = 3,      /* L > RAFFT_MAX_LEN (16-bit positions and the LDS plan of the biggest regions) */
+    RAFFT_ERR_TOO_LONG = 3,      /* L > RAFFT_MAX_LEN (the LDS plan of the biggest regions: 2 bytes per position; 16-bit pair tables) */
     RAFFT_ERR_TEMP = 4,          /* temp != 37 with the built-in 37 C tables (no enthalpies): load a parameter file first */
     RAFFT_ERR_CAPACITY = 5,      /* an HBM arena overflowed even after regrowth */
     RAFFT_ERR_PARAM = 6,         /* unsupported parameter combination (e.g. max_branch+2*max_stack too large) */
@@ -34,7 +34,7 @@ enum {
     RAFFT_ERR_NO_DEVICE = 9
 };
 
-#define RAFFT_MAX_LEN 16384
+#define RAFFT_MAX_LEN 32768
 
 /* Mirrors the argument list of rafft.fold(), rafft/rafft.py:219-221 (and
  * Glob_parms, rafft/utils.py:9-21). */

@@ -276,13 +276,16 @@ int class_cfg(int K, int maxL, ClsCfg out[NGEN + 1], bool nofft1 = false, bool n
     const int WPB[NGEN] = {1, wpb1, 1, 1};
     const bool TAB[NGEN] = {false, (tabm & 2) != 0 || WPB[1] > 1, (tabm & 4) != 0, false};    // (LDS tables come with LDS twiddles: FFT sizes <= CLS2_P only)
     for (int c = 0; c < NGEN; c++) {
-        int nmax = c == 0 ? BIG_N : P[c] / 2;
-        int Kmax = std::max(1, std::min(K, c == 0 ? 2 * BIG_N - 1 : P[c] - 1));
+        // (class 0 is planned for 16 384 positions unless a sequence of the wave is longer: the 64 KiB of 32 768 positions leave
+        //  its scratch room for nb_mode <= 106 only, where the plan for 16 384 takes ~400)
+        const int big_n = maxL > 16384 ? BIG_N : 16384;
+        int nmax = c == 0 ? big_n : P[c] / 2;
+        int Kmax = std::max(1, std::min(K, c == 0 ? 2 * big_n - 1 : P[c] - 1));
         const bool nf = (c == 1 && nofft1 && WPB[1] > 1) || (c == 2 && nofft2);
-        ExpandLds l = expand_lds(P[c], LM[c], nmax, BR[c], Kmax, TAB[c], WPB[c], nf, NT[c]);
+        ExpandLds l = expand_lds(P[c], LM[c], nmax, BR[c], Kmax, TAB[c], WPB[c], nf, NT[c], c != 0);      // (class 0: no LDS copy of the base codes - expand_kernel's CODE_LDS)
         // region A is time-shared: behind the fp64 lag values (8 P bytes) it must still hold the branch prefix sums
         // (10 bytes per branch), the select histogram and the window_slide scratch of this class
-        if (c == 0 && longseq && (80 * (BIG_N / 64) + 24 * 8 * std::max(Kmax, 1) + 4096 > 16 * P[c] || 10 * (BR[c] + 1) + 16 + 24 * Kmax + 2048 > 16 * P[c]))
+        if (c == 0 && longseq && (80 * (big_n / 64) + 24 * 8 * std::max(Kmax, 1) + 4096 > 16 * P[c] || 10 * (BR[c] + 1) + 16 + 24 * Kmax + 2048 > 16 * P[c]))
             return fail(RAFFT_ERR_PARAM, "nb_mode too large for the LDS scratch of the class for regions beyond 4096 positions");
         if (c >= 1 && (10 * (BR[c] + 1) + 16 > 8 * P[c] || 2 * P[c] + 1152 + 16 > 8 * P[c] || (NT[c] > 64 && NT[c] * 24 > 8 * P[c])))
             return fail(RAFFT_ERR_PARAM, "internal: expand LDS plan does not fit its size class");
@@ -747,7 +750,7 @@ int Wave::setup()
     d.max_prod = (longseq || big_prod) ? MAX_PROD_LONG : MAX_PROD;
     if (const char *e = getenv("RAFFT_TEST_MAX_PROD")) if (!big_prod && !longseq) d.max_prod = std::max(1, std::min(atoi(e), MAX_PROD));   // test hook: short lists overflow early
     if (longseq) {       // scratch of the class for regions beyond 4096 positions: lag values (fp64) + lag column, per workgroup
-        d.big_stride = (size_t)2 * BIG_N + (size_t)2 * BIG_N / 4;
+        d.big_stride = (size_t)2 * cf[0].nmax + (size_t)2 * cf[0].nmax / 4;
         if (int rc = ensure(g.big, (size_t)cf[0].grid * d.big_stride * 8)) return rc;
         d.big_keyv = (double *)g.big.p;
     } else if (cf[3].direct3) {      // ... and of class 3 when it runs without FFT buffers: FFT size 8192 at most
@@ -1925,7 +1928,7 @@ static int eval_structures_impl(int n, const char *const *seqs, const char *cons
     for (int i = 0; i < n; i++) {
         len[i] = (int)strlen(seqs[i]);
         off[i] = tot;
-        if ((int)strlen(dbs[i]) != len[i] || len[i] > 32767) { status[i] = RAFFT_ERR_STRUCT; len[i] = 0; }
+        if ((int)strlen(dbs[i]) != len[i] || len[i] > RAFFT_MAX_LEN) { status[i] = RAFFT_ERR_STRUCT; len[i] = 0; }      // (16-bit pair tables: positions 0..32767)
         tot += len[i];
     }
     std::vector<uint8_t> codes(tot + 16, 0);

@@ -9,7 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define RAFFT_MAX_LEN 16384
+#define RAFFT_MAX_LEN 32768
 
 // Small, hot tables (3.4 KB): copied into LDS by the expand kernel of the smallest size class.
 struct SmallT {

@@ -188,7 +188,7 @@ struct Dev {
 #define MAX_P 8192
 #define MAX_BR 1024        // branches of a loop, classes 1-3
 #define BIG_BR 4095        // ... of the class for the biggest regions (the 12-bit cut points of a candidate)
-#define BIG_N 16384        // positions of a region of that class = RAFFT_MAX_LEN
+#define BIG_N 32768        // positions of a region of that class = RAFFT_MAX_LEN
 #define LDS_SEQ 4096       // sequences up to this length have the bases of a loop staged in LDS by classes 2 and 3
 #define MAX_PROD 64        // productive regions per structure (sequences up to LDS_SEQ); a wave that meets more is folded again with the long lists
 #define MAX_PROD_LONG 1024 // ... for longer sequences
@@ -231,7 +231,10 @@ struct ExpandLds {
 };
 // `nofft`: the class never runs the FFT (every region is correlated by popcounts on bit masks): region A only holds the lag
 // values (8 P bytes) and what follows them in turn - bit masks, select histogram (at 9 P), branch prefix sums, sort keys.
-__host__ __device__ inline ExpandLds expand_lds(int Pmax, int Lmax, int nmax, int brmax, int Kmax, bool tab_lds, int wpb = 1, bool nofft = false, int nt = 512)
+// `code_lds`: the region's base codes are staged in LDS (nmax bytes) - every class but the one for regions beyond 4096 positions,
+// which reads them through the positions from HBM/L2 (its 32 768 positions alone take 64 KiB).
+__host__ __device__ inline ExpandLds expand_lds(int Pmax, int Lmax, int nmax, int brmax, int Kmax, bool tab_lds, int wpb = 1, bool nofft = false, int nt = 512,
+                                                bool code_lds = true)
 {
     ExpandLds l;
     auto al = [](int x) { return (x + 15) & ~15; };
@@ -243,7 +246,7 @@ __host__ __device__ inline ExpandLds expand_lds(int Pmax, int Lmax, int nmax, in
     }
     int o = l.szA;
     l.off_pos = o; o += al(2 * nmax + 2);
-    l.off_code = o; o += al(nmax);
+    l.off_code = o; if (code_lds) o += al(nmax);
     l.off_S = o; o += al(Lmax + 8);
     l.off_br = o; o += al(4 * brmax);
     // per-lag arrays (ranked lags, window_slide results, dE, kept list): 14 bytes per searched lag.  In the class with the

@@ -174,12 +174,14 @@ __device__ __forceinline__ unsigned long long mask_window(const unsigned long lo
 // Bit masks of a region: forward masks F[0..3] = positions holding A, C, G, U, F[4] = contiguity with the previous
 // position; R[] = the same strings reversed (bit j of R = bit n-1-j of F).  W words each.  One synchronisation inside
 // (the caller adds the one behind).
-template <int NT>
-__device__ inline void build_masks(unsigned long long *F, unsigned long long *R, int W, int n, const uint8_t *code, const uint16_t *pos, int tid)
+// (`code_at(t)`: the base code of the region's position t - an LDS array, or the sequence's codes read through `pos` for the class
+//  whose regions are too big for an LDS copy)
+template <int NT, class CodeAt>
+__device__ inline void build_masks(unsigned long long *F, unsigned long long *R, int W, int n, const CodeAt &code_at, const uint16_t *pos, int tid)
 {
     for (int wq = tid >> 6; wq < W; wq += NT / 64) {       // each wavefront ballots whole 64-bit words
         const int t = wq * 64 + (tid & 63);
-        const int c0 = t < n ? code[t] : 0;
+        const int c0 = t < n ? code_at(t) : 0;
         const unsigned long long bA = __ballot(c0 == 1), bC = __ballot(c0 == 2), bG = __ballot(c0 == 3), bU = __ballot(c0 == 4);
         const unsigned long long bg = __ballot(t >= 1 && t < n && (int)pos[t] - (int)pos[t > 0 ? t - 1 : 0] == 1);
         if ((tid & 63) == 0) { F[0 * W + wq] = bA; F[1 * W + wq] = bC; F[2 * W + wq] = bG; F[3 * W + wq] = bU; F[4 * W + wq] = bg; }
@@ -281,7 +283,10 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
     static_assert(LONGSEQ == 0 || NT > 64, "long sequences never reach the one-wavefront class");
     extern __shared__ __align__(16) unsigned char lds_all[];
     const bool nofft = PROD == 1 || (cls_arg & 0x2000) != 0;   // the host promises: no seam, no forced FFT, no negative weights, every region within Dev::direct_n
-    const ExpandLds lay = expand_lds(Pmax, Lmax, nmax, brmax, Kmax, TAB_LDS, WPB, nofft, NT);
+    // (the class for regions beyond 4096 positions - 512 threads, lag values in HBM - keeps no LDS copy of the base codes: 32 768
+    //  positions x 2 bytes are 64 KiB of its plan already; the FFT-free class for 1025-4096 positions, 256 threads, does)
+    constexpr bool CODE_LDS = !(LONGSEQ == 2 && NT == 512);
+    const ExpandLds lay = expand_lds(Pmax, Lmax, nmax, brmax, Kmax, TAB_LDS, WPB, nofft, NT, CODE_LDS);
     const int tid = threadIdx.x % NT;                 // position inside this region's team (a wavefront / the workgroup)
     const int team = threadIdx.x / NT;                // wavefront of the workgroup (0 when the workgroup is the team)
     const unsigned gteam = blockIdx.x * WPB + team, n_teams = gridDim.x * WPB;
@@ -378,6 +383,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
         const uint16_t *posg = d.pos + d.nd[nid].pos;
         const uint32_t *brg = d.br + d.nd[nid].br;
         const uint8_t *codes = d.codes + d.nd[nid].soff;
+        auto code_at = [&](int t) -> int { return CODE_LDS ? (int)code[t] : (int)codes[pos[t]]; };
         // (LDS copy of the bases: only the loop's span [sx0, sx1) is staged, at Sl_lds[x - sx0]; the pointer is shifted so
         //  that it still takes sequence positions - sx0 < 4096 never exceeds the offset of that area, the shifted pointer stays
         //  inside the LDS.  The address space is known at compile time either way.)
@@ -398,7 +404,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
         for (int t = tid; t < n; t += NT) {
             const int p = posg[t];
             if (d.pos_packed) { pos[t] = (uint16_t)(p & 0x0FFF); code[t] = (uint8_t)(p >> 12); }   // (Dev::pos_packed: no sequence beyond 4096 nt in this wave)
-            else { pos[t] = (uint16_t)p; code[t] = codes[p]; }
+            else { pos[t] = (uint16_t)p; if (CODE_LDS) code[t] = codes[p]; }
         }
         if (LONGSEQ == 0) {   // bases: only the span of this loop is ever looked at (closing pair, its neighbours inside, branches)
             for (int x = sx0 + tid; x < sx1; x += NT) Sl_lds[x - sx0] = codes[x];
@@ -548,7 +554,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
             const int W = (n + 63) >> 6;
             unsigned long long *F = (unsigned long long *)(lds + lay.offA + 8 * Pk);
             unsigned long long *R = F + 5 * W;
-            build_masks<NT>(F, R, W, n, code, pos, tid);
+            build_masks<NT>(F, R, W, n, code_at, pos, tid);
             ESYNC();
             // ... and the three pair counts of every lag: bit ip of window(R_x, sft + 64 w) = base x at position k - ip
             for (int k = tid; k < P; k += NT) {
@@ -773,7 +779,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
             parts = (WsPart *)(R + 5 * W);
             if (LONGSEQ != 2 && (!mw || inplace))   // (the direct correlation on multi-word masks has built them already - behind the lag values)
             for (int rep_ = 0; rep_ < 1 + ((rep >> 7) & 1); rep_++) {
-                build_masks<NT>(F, R, W, n, code, pos, tid);
+                build_masks<NT>(F, R, W, n, code_at, pos, tid);
                 ESYNC();
             }
             auto window = [&](const unsigned long long *X, int start) -> unsigned long long { return mask_window(X, W, start); };
@@ -881,12 +887,12 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                 const int a = (int)((long long)len2 * c / C), e = (int)((long long)len2 * (c + 1) / C);
                 const int ip0 = lagp < n ? 0 : lagp - n + 1, jp0 = lagp < n ? lagp : n - 1;   // cell i: (ip0+i, jp0-i)
                 int z = a;                                  // replay start: just after the last zero cell before `a`
-                while (z > 0 && wtab[code[ip0 + z - 1] * 5 + code[jp0 - (z - 1)]] != 0.0) z--;
+                while (z > 0 && wtab[code_at(ip0 + z - 1) * 5 + code_at(jp0 - (z - 1))] != 0.0) z--;
                 double prev = 0.0, mx_s = 0.0;
                 int tmp = 0, mx_nb = 0, mx_i = 0, mx_j = 0, any = 0;
                 for (int i = z; i < e; i++) {
                     const int ip = ip0 + i, jp = jp0 - i;
-                    double t = wtab[code[ip] * 5 + code[jp]];
+                    double t = wtab[code_at(ip) * 5 + code_at(jp)];
                     if (i > 0 && (int)pos[ip] - (int)pos[ip - 1] == 1 && (int)pos[jp + 1] - (int)pos[jp] == 1)
                         t = (prev + t) * t;
                     tmp = (t == 0.0) ? 0 : tmp + 1;

@@ -30,7 +30,7 @@ def _raise_like_reference(status, sequence):
     if status == N.ERR_EMPTY:
         raise np.exceptions.AxisError("axis 1 is out of bounds for array of dimension 1")  # utils.py:83
     if status == N.ERR_TOO_LONG:
-        raise ValueError("sequence longer than 16384 nt (RAFFT_MAX_LEN) is not supported")
+        raise ValueError("sequence longer than 32768 nt (RAFFT_MAX_LEN) is not supported")
     raise N.RafftError(status, "per-sequence failure")
 
 

@@ -1,4 +1,4 @@
-"""Sequences beyond 4096 nt (up to RAFFT_MAX_LEN = 16384): regions whose FFT would not fit the LDS are correlated by
+"""Sequences beyond 4096 nt (up to RAFFT_MAX_LEN = 32768): regions whose FFT would not fit the LDS are correlated by
 the exact direct form on multi-word bit masks with their lag values in HBM, and classes 2 and 3 read the bases of a loop
 from HBM instead of an LDS copy.  Full trajectories against the oracle."""
 import numpy as np
@@ -37,16 +37,38 @@ def test_gpu_sequences_beyond_4096_nt_vs_oracle():
 
 
 def test_gpu_maximum_length_and_beyond():
-    """RAFFT_MAX_LEN itself (the oracle needs minutes there: size-independent properties and the whole-structure
-    re-evaluation of every final structure by the other kernel), and one position more"""
+    """RAFFT_MAX_LEN itself (32 768: the oracle needs a quarter of an hour there - its fold is a committed fixture, below; here
+    size-independent properties and the whole-structure re-evaluation of every final structure by the other kernel), the 16 384 that
+    was the limit until round 4 (the class for the biggest regions is planned for 16 384 positions unless a sequence is longer), and
+    one position more than the maximum"""
     from test_gpu_scale import check_structures
-    rng = np.random.default_rng(16384)
-    s = "".join(rng.choice(list("ACGU"), 16384))
-    fin = rafft_amd.fold(s, 100, 4, 1000)
-    check_structures(s, fin, 4)
-    assert fin[0].dcal < -100000 and fin[0].str_struct.count("(") > 2000
-    e, st = R.eval_structures([s] * len(fin), [x.str_struct for x in fin])
-    assert not any(st) and e == [x.dcal for x in fin]
-    assert [(x.str_struct, x.dcal) for x in rafft_amd.fold(s, 100, 4, 1000)] == [(x.str_struct, x.dcal) for x in fin]
+    for L, min_pairs in ((16384, 2000), (32768, 4000)):
+        rng = np.random.default_rng(L)
+        s = "".join(rng.choice(list("ACGU"), L))
+        fin = rafft_amd.fold(s, 100, 4, 1000)
+        check_structures(s, fin, 4)
+        assert fin[0].dcal < -100000 and fin[0].str_struct.count("(") > min_pairs
+        e, st = R.eval_structures([s] * len(fin), [x.str_struct for x in fin])
+        assert not any(st) and e == [x.dcal for x in fin]
+        assert [(x.str_struct, x.dcal) for x in rafft_amd.fold(s, 100, 4, 1000)] == [(x.str_struct, x.dcal) for x in fin]
     with pytest.raises(ValueError):
         rafft_amd.fold(s + "A")
+
+
+@pytest.mark.parametrize("L", [17000, 32768])
+def test_gpu_sequences_beyond_16384_nt_vs_committed_oracle_folds(L):
+    """the oracle's fold of a random sequence of 17 000 nt (ms=3; 109 s of CPU) and of 32 768 nt (ms=1; a quarter of an hour), generated
+    once by tools/make_golden_verylong.py: final beam identical, and the energies and pair counts of every beam of the trajectory"""
+    import gzip, json, os
+    g = json.load(gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"fold_verylong_{L}.json.gz"), "rt"))
+    fin, traj = rafft_amd.fold(g["sequence"], g["nb_mode"], g["max_stack"], g["max_branch"], traj=True)
+    assert [[x.str_struct, x.dcal] for x in fin] == g["final"]
+    assert [[x.dcal for x in st] for st in traj] == g["traj_dcal"]
+    assert [[x.str_struct.count("(") for x in st] for st in traj] == g["traj_pairs"]
+    # in a batch with short sequences and another very long one (one wave, the plan for 32 768 positions)
+    rng = np.random.default_rng(5)
+    others = ["".join(rng.choice(list("ACGU"), n)) for n in (60, 900, 20000)]
+    res = rafft_amd.fold_batch([g["sequence"]] + others, g["nb_mode"], g["max_stack"], g["max_branch"])
+    assert [[x.str_struct, x.dcal] for x in res[0]] == g["final"]
+    for s, r in zip(others[:2], res[1:3]):
+        assert [(x.str_struct, x.dcal) for x in r] == [(x.str_struct, x.dcal) for x in oracle.fold(s, g["nb_mode"], g["max_stack"], g["max_branch"])]
