@@ -25,10 +25,24 @@ struct SmallT {
     // special hairpins (tri-, tetra-, hexaloops) in one open-addressing hash table: key = 3 bits per base of
     // the loop with its closing pair, tagged with the loop size in bits 28..; 0 = empty slot
     uint32_t sp_key[128]; int32_t sp_e[128];
+    // (round 5) 1024-bit filter in front of that table: bit (size class << 8 | 2-bit codes of the closing pair's 5' base, the first
+    // and the last base of the loop and the closing pair's 3' base) is set when some special loop of that size class has them; nine
+    // hairpins in ten are told "no special loop" by one look-up instead of building the key of up to eight bases and probing
+    uint32_t sp_filter[32];
+    // (round 5) stacking energy of a stem's pair t on its pair t-1 by the 2-bit codes (A C G U = 0..3) of the four bases:
+    // index = x5(t) | x5(t-1) << 2 | x3(t-1) << 4 | x3(t) << 6 - the order in which the bases of a contiguous stem come out of
+    // the packed strands (stem_stack_packed): stack[type(x5(t), x3(t))][rtype(type(x5(t-1), x3(t-1)))], 0 when either is no pair
+    int16_t stk4[256];
 };
 static_assert(sizeof(SmallT) % 16 == 0, "SmallT is copied to LDS in 16-byte pieces");
 __host__ __device__ inline uint32_t sp_tag(int size) { return (uint32_t)(size == 3 ? 1 : size == 4 ? 2 : 3) << 28; }
 __host__ __device__ inline uint32_t sp_slot(uint32_t tagged) { return (tagged * 2654435761u) >> 25; }
+// index into SmallT::sp_filter: size class (1: tri-, 2: tetra-, 3: hexaloops) and the base codes (N=0 A=1 .. U=4; 2 bits each, N
+// aliases U - a filter may say "maybe" too often, never "no" wrongly) of the closing pair (c5, c3) and of the loop's ends (l5, l3)
+__host__ __device__ inline uint32_t sp_filter_index(int size, int c5, int l5, int l3, int c3)
+{
+    return ((sp_tag(size) >> 28) << 8) | (uint32_t)((c5 + 3) & 3) | (uint32_t)((l5 + 3) & 3) << 2 | (uint32_t)((l3 + 3) & 3) << 4 | (uint32_t)((c3 + 3) & 3) << 6;
+}
 // Big, rarely hit tables stay in HBM/L2.
 struct BigT {
     int16_t int11[7][7][5][5];
@@ -65,61 +79,64 @@ __device__ inline int e_hairpin(const SmallT *T, const BigT *B, int size, int ty
 {
     int e = (size <= 30) ? T->hairpin[size] : T->hairpin[30] + B->logext[size];
     if (size < 3) return e;
+    const int l5 = S[ci + 1], l3 = S[cj - 1];
     if (size == 3 || size == 4 || size == 6) {
-        const uint32_t k = loop_key(S, ci, size + 2) | sp_tag(size);
-        for (uint32_t sl = sp_slot(k);; sl = (sl + 1) & 127u) {
-            const uint32_t kk = T->sp_key[sl];
-            if (kk == k) return T->sp_e[sl];
-            if (kk == 0) break;
+        const uint32_t fi = sp_filter_index(size, S[ci], l5, l3, S[cj]);
+        if ((T->sp_filter[fi >> 5] >> (fi & 31u)) & 1u) {      // (SmallT::sp_filter: some special loop of this size has these four bases)
+            const uint32_t k = loop_key(S, ci, size + 2) | sp_tag(size);
+            for (uint32_t sl = sp_slot(k);; sl = (sl + 1) & 127u) {
+                const uint32_t kk = T->sp_key[sl];
+                if (kk == k) return T->sp_e[sl];
+                if (kk == 0) break;
+            }
         }
         if (size == 3) return e + (type > 2 ? T->term_au : 0);
     }
-    return e + T->mmH[type][S[ci + 1]][S[cj - 1]];
+    return e + T->mmH[type][l5][l3];
 }
 
 // `g`: set when the value read is a rule / model value of the built-in tables (SmallT::lsb)
+// (round 5) Two paths instead of a decision tree with a body per kind of loop.  The lanes of a wavefront evaluate loops of every
+// kind at once, and a tree runs each of its bodies in turn for the lanes that took it: stack, bulge, 1 x n, 2 x 3 and the generic
+// interior loop are now ONE straight line (every table read unconditionally, the kind chooses by selection), the three tabulated
+// small loops (1 x 1, 2 x 1, 2 x 2; HBM / L2) one load whose address is selected.  Same values read, same sums.
 __device__ inline int e_intloop(const SmallT *T, const BigT *B, int n1, int n2, int type, int type2,
                                 int si1, int sj1, int sp1, int sq1, int &g)
 {
     const int lsb = T->lsb;
-#define RAFFT_TV(x) ([&](int v_) { g |= v_ & lsb; return v_ & ~lsb; }((int)(x)))
-    int nl = n1 > n2 ? n1 : n2, ns = n1 > n2 ? n2 : n1, e, u;
-    if (nl == 0) return T->stack[type][type2];
-    if (ns == 0) {
-        e = (nl <= 30) ? RAFFT_TV(T->bulge[nl]) : RAFFT_TV(T->bulge[30]) + B->logext[nl];
-        if (nl == 1) e += T->stack[type][type2];
-        else {
-            if (type > 2) e += T->term_au;
-            if (type2 > 2) e += T->term_au;
-        }
-        return e;
+    const int nl = n1 > n2 ? n1 : n2, ns = n1 > n2 ? n2 : n1, u = nl + ns;
+    if (ns >= 1 && nl <= 2) {
+        // int11[type][type2][si1][sj1] | int21[type][type2][si1][sq1][sj1] (n1 == 1), int21[type2][type][sq1][si1][sp1] (n2 == 1) |
+        // int22[type][type2][si1][sp1][sq1][sj1]
+        const bool c11 = nl == 1, c22 = ns == 2, sw = !c11 && !c22 && n1 != 1;
+        const int ta = sw ? type2 : type, tb = sw ? type : type2;
+        const int ia = sw ? sq1 : si1;
+        const int ib = c11 ? sj1 : c22 ? sp1 : (sw ? si1 : sq1);
+        const int ic = c22 ? sq1 : (sw ? sp1 : sj1);
+        const int i2 = ((ta * 7 + tb) * 5 + ia) * 5 + ib, i3 = i2 * 5 + ic, i4 = i3 * 5 + sj1;
+        static_assert(offsetof(BigT, int11) == 0 && offsetof(BigT, int21) == 2 * 1225 && offsetof(BigT, int22) == 2 * (1225 + 6125), "BigT layout");
+        const int off = c11 ? i2 : c22 ? 1225 + 6125 + i4 : 1225 + i3;
+        const int v = ((const int16_t *)B)[off];
+        g |= v & lsb;
+        return v & ~lsb;
     }
-    if (ns == 1) {
-        if (nl == 1) return RAFFT_TV(B->int11[type][type2][si1][sj1]);
-        if (nl == 2) {
-            if (n1 == 1) return RAFFT_TV(B->int21[type][type2][si1][sq1][sj1]);
-            return RAFFT_TV(B->int21[type2][type][sq1][si1][sp1]);
-        }
-        u = nl + 1;
-        e = (u <= 30) ? RAFFT_TV(T->interior[u]) : RAFFT_TV(T->interior[30]) + B->logext[u];
-        e += min(T->max_ninio, (nl - ns) * T->ninio);
-        e += RAFFT_TV(T->mm1n[type][si1][sj1]) + RAFFT_TV(T->mm1n[type2][sq1][sp1]);
-        return e;
-    }
-    if (ns == 2) {
-        if (nl == 2) return RAFFT_TV(B->int22[type][type2][si1][sp1][sq1][sj1]);
-        if (nl == 3) {
-            e = RAFFT_TV(T->interior[5]) + T->ninio;
-            e += RAFFT_TV(T->mm23[type][si1][sj1]) + RAFFT_TV(T->mm23[type2][sq1][sp1]);
-            return e;
-        }
-    }
-    u = nl + ns;
-    e = (u <= 30) ? RAFFT_TV(T->interior[u]) : RAFFT_TV(T->interior[30]) + B->logext[u];
-    e += min(T->max_ninio, (nl - ns) * T->ninio);
-    e += RAFFT_TV(T->mmI[type][si1][sj1]) + RAFFT_TV(T->mmI[type2][sq1][sp1]);
-    return e;
-#undef RAFFT_TV
+    static_assert(offsetof(SmallT, bulge) == offsetof(SmallT, hairpin) + 31 * 4 && offsetof(SmallT, interior) == offsetof(SmallT, hairpin) + 62 * 4, "SmallT layout");
+    static_assert(offsetof(SmallT, mmI) == offsetof(SmallT, mmH) + 350 && offsetof(SmallT, mm1n) == offsetof(SmallT, mmH) + 700 && offsetof(SmallT, mm23) == offsetof(SmallT, mmH) + 1050, "SmallT layout");
+    const int stk = T->stack[type][type2];
+    const bool bul = ns == 0, c23 = ns == 2 && nl == 3;
+    const int sz = ((const int32_t *)((const char *)T + offsetof(SmallT, hairpin)))[(bul ? 31 : 62) + (u < 30 ? u : 30)];   // bulge[min(u, 30)] | interior[min(u, 30)]
+    const int16_t *mm = (const int16_t *)((const char *)T + offsetof(SmallT, mmH)) + (ns == 1 ? 350 : c23 ? 525 : 175);    // mm1n | mm23 | mmI
+    const int m1 = mm[(type * 5 + si1) * 5 + sj1], m2 = mm[(type2 * 5 + sq1) * 5 + sp1];
+    const int nin0 = T->ninio, ninx = T->max_ninio, tau = T->term_au;
+    int e = sz & ~lsb;
+    if (u > 30) e += B->logext[u];
+    const int dn = (nl - ns) * nin0;
+    const int nin = c23 ? nin0 : (ninx < dn ? ninx : dn);
+    const int au = (type > 2 ? tau : 0) + (type2 > 2 ? tau : 0);
+    const int tail = bul ? (nl == 1 ? stk : au) : nin + (m1 & ~lsb) + (m2 & ~lsb);
+    const int gt = bul ? (sz & lsb) : ((sz | m1 | m2) & lsb);
+    g |= nl == 0 ? 0 : gt;
+    return nl == 0 ? stk : e + tail;
 }
 
 // si1/sj1 < 0: neighbour does not exist (sequence end)
@@ -201,11 +218,61 @@ __device__ __host__ inline uint64_t mix64(uint64_t z)
     z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
     return z ^ (z >> 31);
 }
-__device__ __host__ inline void pair_hash(int i, int j, uint64_t *h1, uint64_t *h2)
+__device__ __host__ inline void pair_mix(int i, int j, uint64_t *f1, uint64_t *f2)
 {
     uint64_t k = ((uint64_t)(uint32_t)i << 20) | (uint32_t)j;
-    *h1 = mix64(k);
-    *h2 = mix64(k ^ 0xa5a5a5a5deadbeefULL);
+    *f1 = mix64(k);
+    *f2 = mix64(k ^ 0xa5a5a5a5deadbeefULL);
+}
+// (round 5) The hash of ONE pair is F(i, j) - F(i - 1, j + 1), F = the two mixes above.  Along a run of stacked pairs
+// (i - t, j + t) the terms telescope: a contiguous stem of any length costs two evaluations of F - at its innermost pair and one
+// place beyond its outermost pair - where rounds 1-4 mixed every pair of it.  The sum over a pair SET is still a function of the set
+// alone (whatever stems it was assembled from: the partial sums telescope exactly, modulo 2^64), and two different sets differ in the
+// ends of their maximal diagonal runs, i.e. in which values of F enter with +1 and -1 - no weaker than the plain sum of mixes.
+__device__ __host__ inline void pair_hash(int i, int j, uint64_t *h1, uint64_t *h2)
+{
+    uint64_t a1, a2, b1, b2;
+    pair_mix(i, j, &a1, &a2);
+    pair_mix(i - 1, j + 1, &b1, &b2);
+    *h1 = a1 - b1; *h2 = a2 - b2;
+}
+// ... of the contiguous stem with innermost pair (a0, b0) and outermost pair (ao, bo) = (a0 - nb + 1, b0 + nb - 1)
+__device__ __host__ inline void stem_hash(int a0, int b0, int ao, int bo, uint64_t *h1, uint64_t *h2)
+{
+    uint64_t a1, a2, b1, b2;
+    pair_mix(a0, b0, &a1, &a2);
+    pair_mix(ao - 1, bo + 1, &b1, &b2);
+    *h1 = a1 - b1; *h2 = a2 - b2;
+}
+
+// ---- stacking energies of a contiguous stem from packed strands (round 5) ----
+// `P2`: the region's bases, 2 bits per position (A C G U = 0..3; N never pairs), 16 positions per word, one word of slack behind
+// the last.  The 5' strand of a stem whose innermost pair sits at region positions (mi, mj) is positions mi - nb + 1 .. mi, its
+// 3' strand mj .. mj + nb - 1: two 32-bit windows hold both for nb <= 16, and the stacking term of pair t on pair t - 1 is ONE
+// look-up in SmallT::stk4 by four 2-bit codes - where the loop used to read two positions, two bases and the stack table per pair.
+__device__ __forceinline__ uint32_t strand_window(const uint32_t *P2, int start)
+{
+    const int q = start >> 4;
+    return __builtin_amdgcn_alignbit(P2[q + 1], P2[q], (uint32_t)(start & 15) * 2u);
+}
+__device__ __forceinline__ int stem_stack_windows(const SmallT *T, uint32_t w5, uint32_t w3, int nb)
+{
+    int e = 0;
+    for (int t = 1; t < nb; t++) {
+        const uint32_t i5 = (w5 >> (2 * (nb - 1 - t))) & 15u;     // x5(t) | x5(t-1) << 2
+        const uint32_t i3 = (w3 >> (2 * (t - 1))) & 15u;          // x3(t-1) | x3(t) << 2
+        e += T->stk4[i5 | (i3 << 4)];
+    }
+    return e;
+}
+// one step of the OR-reduction over a row of 16 lanes (DPP row_shr): lane 15 of every row ends up with the OR of the row
+__device__ __forceinline__ uint32_t row16_or(uint32_t x)
+{
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);
+    return x;
 }
 
 // ---- loop energy from an explicit (virtual) branch list -------------------

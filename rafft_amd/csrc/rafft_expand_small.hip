@@ -30,7 +30,7 @@ template <int TL> struct SmLds {
 };
 // the per-team areas start behind a 4 KiB guard (the energy tables live in it): the window of bases is addressed by SEQUENCE
 // position through a pointer shifted back by the span's start (< 4096), which must stay inside the LDS
-#define SM_GUARD 4096
+#define SM_GUARD 4608
 static_assert(sizeof(SmallT) <= SM_GUARD, "energy tables must fit the guard area");
 #define SM_WG_WAVES 4
 template <int TL> constexpr int small_lds_bytes() { return SM_GUARD + SM_WG_WAVES * (64 / TL) * SmLds<TL>::per_team; }
@@ -136,6 +136,10 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
         }
         if (act && ci >= 0 && tl < 2) { const int x = tl ? cj : ci; Sw[x - sx0] = codes[x]; }
         // base masks of the strand (bit t = position t holds A / C / G / U), contiguity with the previous position
+        // the strand again, 2 bits per position, in a register pair of every lane (stem_stack_windows; n <= 32: one 64-bit word)
+        const uint32_t px_ = row16_or((uint32_t)((c + 3) & 3) << (2 * (tl & 15)));
+        const unsigned long long p2 = (unsigned long long)(uint32_t)__shfl((int)px_, tbase + 15, 64) |
+                                      (TL == 32 ? (unsigned long long)(uint32_t)__shfl((int)px_, tbase + 31, 64) << 32 : 0ULL);
         const unsigned long long bA = __ballot(c == 1), bC = __ballot(c == 2), bG = __ballot(c == 3), bU = __ballot(c == 4);
         const int pprev = __shfl_up(myp, 1, TL);
         const unsigned long long bg = __ballot(act && tl >= 1 && tl < n && myp - pprev == 1);
@@ -158,7 +162,9 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
                 const int len = k < n ? k + 1 : 2 * n - k - 1;
                 const int len2 = (len >> 1) + (len & 1);
                 const int ip0 = k < n ? 0 : k - n + 1, jp0 = k < n ? k : n - 1;
-                int lo = 0, hi = len2;                      // eligible cells (pos[jp]-pos[ip] > min_hp) form a prefix
+                // eligible cells (pos[jp]-pos[ip] > min_hp) form a prefix; those with jp - ip > min_hp are eligible without looking (expand_kernel)
+                const int csure = len - 1 - d.min_hp;
+                int lo = csure > 0 ? min((csure + 1) >> 1, len2) : 0, hi = len2;
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
                     if ((int)pos[jp0 - mid] - (int)pos[ip0 + mid] > d.min_hp) lo = mid + 1; else hi = mid;
@@ -246,6 +252,10 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
                     int e_new = loop_energy_pre(T, B, Sl, L, ci, cj, outer, pf, g);
                     BrList inner{brl, lo, hi, 0, 0, 0, 0, 0};
                     e_new += loop_energy_pre(T, B, Sl, L, a0, b0, inner, pf, g);
+                    // the stem itself: a contiguous one takes its stacking energies from the packed strand (expand_kernel)
+                    if (nb <= 16 && a0 - ao == nb - 1 && bo - b0 == nb - 1)
+                        e_new += stem_stack_windows(T, (uint32_t)(p2 >> (2 * (mi - nb + 1))), (uint32_t)(p2 >> (2 * mj)), nb);
+                    else {
                     int pa = a0, pb = b0, ty_in = pair_type(Sl[a0], Sl[b0]);
                     for (int t = 1; t < nb; t++) {
                         const int a = pos[mi - t], b = pos[mj + t];
@@ -259,6 +269,7 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
                             lo = lo2; hi = hi2;
                         }
                         pa = a; pb = b; ty_in = ty;
+                    }
                     }
                     const int ddc = e_new - e_old;
                     w_dd[s] = ddc;
@@ -349,15 +360,18 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
                             rank += ky < kx ? 1 : 0;
                     }
                     const int mi = w_mi[s], mj = w_mj[s], nb = w_nb[s];
+                    const int a0 = pos[mi], b0 = pos[mj], ao = pos[mi - nb + 1], bo = pos[mj + nb - 1];
                     uint64_t h1 = 0, h2 = 0;
-                    for (int t = 0; t < nb; t++) {
-                        uint64_t a, b;
-                        pair_hash(pos[mi - t], pos[mj + t], &a, &b);
-                        h1 += a; h2 += b;
-                    }
+                    if (a0 - ao == nb - 1 && bo - b0 == nb - 1) stem_hash(a0, b0, ao, bo, &h1, &h2);      // contiguous: the pair hashes telescope
+                    else
+                        for (int t = 0; t < nb; t++) {
+                            uint64_t a, b;
+                            pair_hash(pos[mi - t], pos[mj + t], &a, &b);
+                            h1 += a; h2 += b;
+                        }
                     Cand cd;
                     cd.ddcal = w_dd[s]; cd.mi = (uint16_t)mi; cd.mj = (uint16_t)mj; cd.nb = (uint16_t)nb;
-                    { int c0, c1, c2, c3; br_lower4(brl, nbr, pos[mi], pos[mj], pos[mi - nb + 1], pos[mj + nb - 1], c0, c1, c2, c3); cd.set_cuts(c0, c1, c2, c3); }
+                    { int c0, c1, c2, c3; br_lower4(brl, nbr, a0, b0, ao, bo, c0, c1, c2, c3); cd.set_cuts(c0, c1, c2, c3); }
                     cd.h1 = h1; cd.h2 = h2;
                     d.cand[cbase + toff + rank] = cd;
                     d.cslot[cbase + toff + rank] = 0ULL;      // (both child slots: nobody has asked yet)

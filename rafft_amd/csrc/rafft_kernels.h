@@ -224,7 +224,7 @@ __host__ __device__ inline int node_class(int n, int span, int nbr, int merge_cl
 // LDS layout of the expand kernel (bytes).  Region A is time-shared between the FFT
 // buffers and the sort keys; region B holds the loop itself.
 struct ExpandLds {
-    int offA, szA, off_pos, off_code, off_S, off_br, off_rk, off_nb, off_mi, off_mj, off_dd, off_keep, off_w, off_misc,
+    int offA, szA, off_pos, off_code, off_p2, off_S, off_br, off_rk, off_nb, off_mi, off_mj, off_dd, off_keep, off_w, off_misc,
         per_team,             // bytes of one team (wavefront or workgroup); a workgroup of `wpb` teams holds wpb of them ...
         off_tab, off_tw,      // ... followed by ONE shared area: energy tables, twiddles (offsets inside that area)
         total;
@@ -247,6 +247,7 @@ __host__ __device__ inline ExpandLds expand_lds(int Pmax, int Lmax, int nmax, in
     int o = l.szA;
     l.off_pos = o; o += al(2 * nmax + 2);
     l.off_code = o; if (code_lds) o += al(nmax);
+    l.off_p2 = o; if (code_lds) o += al(4 * ((nmax + 15) / 16 + 1));       // (round 5) the bases again, 2 bits per position (stem_stack_windows)
     l.off_S = o; o += al(Lmax + 8);
     l.off_br = o; o += al(4 * brmax);
     // per-lag arrays (ranked lags, window_slide results, dE, kept list): 14 bytes per searched lag.  In the class with the
@@ -264,7 +265,7 @@ __host__ __device__ inline ExpandLds expand_lds(int Pmax, int Lmax, int nmax, in
     l.off_mj = q; q += al(2 * Kmax);
     l.off_dd = q; q += al(4 * Kmax);
     l.off_keep = q; q += al(2 * Kmax);
-    l.off_w = o; o += al(25 * 8);
+    l.off_w = o; if (!nofft) o += al(25 * 8);      // (pair weights by base codes: only the cell-by-cell window_slide reads them - never in a class without FFT buffers)
     l.off_misc = o; o += 128;
     l.per_team = o;
     int sh = 0;

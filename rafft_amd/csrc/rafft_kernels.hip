@@ -312,6 +312,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
     }
     uint16_t *pos = (uint16_t *)(lds + lay.off_pos);
     uint8_t *code = lds + lay.off_code;
+    uint32_t *P2 = (uint32_t *)(lds + lay.off_p2);      // the bases again, 2 bits per position (stem_stack_windows); only with CODE_LDS
     uint8_t *Sl_lds = lds + lay.off_S;
     uint32_t *brl = (uint32_t *)(lds + lay.off_br);
     uint16_t *rk = (uint16_t *)(lds + lay.off_rk);
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
     double *wtab = (double *)(lds + lay.off_w);
     int *misc = (int *)(lds + lay.off_misc);
 
-    if (tid < 25) {
+    if (!nofft && tid < 25) {      // (a class without FFT buffers has no such table: expand_lds)
         int a = tid / 5, b = tid % 5;
         int tp = pair_type(a, b);
         wtab[tid] = (tp == 5 || tp == 6) ? d.au : (tp == 1 || tp == 2) ? d.gc : (tp == 3 || tp == 4) ? d.gu : 0.0;
@@ -401,11 +402,21 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
         const int Kp = d.K < m ? (d.K > 0 ? d.K : 0) : m;
 
         for (int rep_ = 0; rep_ < 1 + ((rep >> 4) & 1); rep_++) {
-        for (int t = tid; t < n; t += NT) {
-            const int p = posg[t];
-            if (d.pos_packed) { pos[t] = (uint16_t)(p & 0x0FFF); code[t] = (uint8_t)(p >> 12); }   // (Dev::pos_packed: no sequence beyond 4096 nt in this wave)
-            else { pos[t] = (uint16_t)p; if (CODE_LDS) code[t] = codes[p]; }
+        // (every lane of the team walks the loop, so that the rows of 16 lanes that pack the bases - 2 bits each, SmallT::stk4 - are whole)
+        for (int t0 = 0; t0 < n; t0 += NT) {
+            const int t = t0 + tid;
+            int c = 0;
+            if (t < n) {
+                const int p = posg[t];
+                if (d.pos_packed) { pos[t] = (uint16_t)(p & 0x0FFF); c = p >> 12; code[t] = (uint8_t)c; }   // (Dev::pos_packed: no sequence beyond 4096 nt in this wave)
+                else { pos[t] = (uint16_t)p; if (CODE_LDS) { c = codes[p]; code[t] = (uint8_t)c; } }
+            }
+            if (CODE_LDS) {
+                const uint32_t x = row16_or((uint32_t)((c + 3) & 3) << (2 * (t & 15)));
+                if ((t & 15) == 15 && t - 15 < n) P2[t >> 4] = x;
+            }
         }
+        if (CODE_LDS && tid == 0) P2[(n + 15) >> 4] = 0u;       // (the word of slack behind the last: strand_window reads two)
         if (LONGSEQ == 0) {   // bases: only the span of this loop is ever looked at (closing pair, its neighbours inside, branches)
             for (int x = sx0 + tid; x < sx1; x += NT) Sl_lds[x - sx0] = codes[x];
         }
@@ -790,7 +801,12 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                 const int len = lagp < n ? lagp + 1 : 2 * n - lagp - 1;
                 const int len2 = (len >> 1) + (len & 1);
                 const int ip0 = lagp < n ? 0 : lagp - n + 1, jp0 = lagp < n ? lagp : n - 1;
-                int lo = 0, hi = len2;                      // eligible cells (pos[jp]-pos[ip] > min_hp) form a prefix
+                // eligible cells (pos[jp]-pos[ip] > min_hp) form a prefix.  Positions are strictly increasing, so pos[jp] - pos[ip] >=
+                // jp - ip = len - 1 - 2 i: every cell with len - 1 - 2 i > min_hp is eligible without looking, and the search only
+                // covers the (min_hp + 3) / 2 cells that remain at the inner end of the half-diagonal (two steps for min_hp = 3
+                // where the search over all of it took log2(len / 2) dependent pairs of LDS reads)
+                const int csure = len - 1 - d.min_hp;
+                int lo = csure > 0 ? min((csure + 1) >> 1, len2) : 0, hi = len2;
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
                     if ((int)pos[jp0 - mid] - (int)pos[ip0 + mid] > d.min_hp) lo = mid + 1; else hi = mid;
@@ -978,6 +994,11 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                     int e_new = loop_energy_pre(T, B, Sl, L, ci, cj, outer, pf, g);
                     BrList inner{brl, lo, hi, 0, 0, 0, 0, 0};
                     e_new += loop_energy_pre(T, B, Sl, L, a0, b0, inner, pf, g);
+                    // the stem itself: a contiguous one (both strands without a gap - nearly all of them) of up to 16 pairs takes its
+                    // stacking energies from the packed strands, one look-up per pair (stem_stack_windows); the others pair by pair
+                    if (CODE_LDS && nb <= 16 && a0 - ao == nb - 1 && bo - b0 == nb - 1)
+                        e_new += stem_stack_windows(T, strand_window(P2, mi - nb + 1), strand_window(P2, mj), nb);
+                    else {
                     int pa = a0, pb = b0, ty_in = pair_type(Sl[a0], Sl[b0]);
                     for (int t = 1; t < nb; t++) {
                         const int a = pos[mi - t], b = pos[mj + t];
@@ -991,6 +1012,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                             lo = lo2; hi = hi2;
                         }
                         pa = a; pb = b; ty_in = ty;
+                    }
                     }
                     const int ddc = e_new - e_old;
                     dd[r] = ddc;
@@ -1090,15 +1112,18 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                 }
                 FSTAMP(14);  // (emit: sort keys, rank)
                 int mi = wmi[r], mj = wmj[r], nb = wnb[r];
+                const int a0 = pos[mi], b0 = pos[mj], ao = pos[mi - nb + 1], bo = pos[mj + nb - 1];
                 uint64_t h1 = 0, h2 = 0;
-                for (int t = 0; t < nb; t++) {
-                    uint64_t a, b;
-                    pair_hash(pos[mi - t], pos[mj + t], &a, &b);
-                    h1 += a; h2 += b;
-                }
+                if (a0 - ao == nb - 1 && bo - b0 == nb - 1) stem_hash(a0, b0, ao, bo, &h1, &h2);      // contiguous: the pair hashes telescope
+                else
+                    for (int t = 0; t < nb; t++) {
+                        uint64_t a, b;
+                        pair_hash(pos[mi - t], pos[mj + t], &a, &b);
+                        h1 += a; h2 += b;
+                    }
                 Cand cd;
                 cd.ddcal = my; cd.mi = (uint16_t)mi; cd.mj = (uint16_t)mj; cd.nb = (uint16_t)nb;
-                { int c0, c1, c2, c3; br_lower4(brl, nbr, pos[mi], pos[mj], pos[mi - nb + 1], pos[mj + nb - 1], c0, c1, c2, c3); cd.set_cuts(c0, c1, c2, c3); }
+                { int c0, c1, c2, c3; br_lower4(brl, nbr, a0, b0, ao, bo, c0, c1, c2, c3); cd.set_cuts(c0, c1, c2, c3); }
                 cd.h1 = h1; cd.h2 = h2;
                 if (!dry) { d.cand[cbase + rank] = cd; d.cslot[cbase + rank] = 0ULL; }   // (both child slots: nobody has asked yet)
                 if (dbg.kept) dbg.kept[rank] = r;

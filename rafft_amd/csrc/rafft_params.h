@@ -491,7 +491,17 @@ inline bool scaled_tables(const ParamSet &P, double temp, EnergyTables *h, std::
         uint32_t sl = sp_slot(k);
         while (h->s.sp_key[sl]) { if (h->s.sp_key[sl] == k) return; sl = (sl + 1) & 127u; }    // a sequence listed twice: the first entry wins (strstr)
         h->s.sp_key[sl] = k; h->s.sp_e[sl] = e;
+        // (the filter in front of the table: closing pair and the loop's two end bases, e_hairpin)
+        auto base = [&](int t) { return (int)((key >> (3 * t)) & 7u); };
+        const uint32_t fi = sp_filter_index(size, base(0), base(1), base(size), base(size + 1));
+        h->s.sp_filter[fi >> 5] |= 1u << (fi & 31u);
     };
+    // stacking energies by the packed bases of a contiguous stem (SmallT::stk4, stem_stack_packed)
+    for (int i = 0; i < 256; i++) {
+        const int x5t = (i & 3) + 1, x5p = ((i >> 2) & 3) + 1, x3p = ((i >> 4) & 3) + 1, x3t = ((i >> 6) & 3) + 1;
+        const int ty = pair_type(x5t, x3t), ty_in = pair_type(x5p, x3p);
+        h->s.stk4[i] = (ty && ty_in) ? h->s.stack[ty][rtype(ty_in)] : 0;
+    }
     for (const SpecialLoop &l : P.tri) put(loop_key_host(l.seq.c_str(), 5), 3, sc(l.e37, l.dH));
     for (const SpecialLoop &l : P.tetra) put(loop_key_host(l.seq.c_str(), 6), 4, sc(l.e37, l.dH));
     for (const SpecialLoop &l : P.hexa) put(loop_key_host(l.seq.c_str(), 8), 6, sc(l.e37, l.dH));
