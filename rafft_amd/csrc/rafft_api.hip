@@ -285,7 +285,7 @@ int class_cfg(int K, int maxL, ClsCfg out[NGEN + 1], bool nofft1 = false, bool n
         ExpandLds l = expand_lds(P[c], LM[c], nmax, BR[c], Kmax, TAB[c], WPB[c], nf, NT[c], c != 0);      // (class 0: no LDS copy of the base codes - expand_kernel's CODE_LDS)
         // region A is time-shared: behind the fp64 lag values (8 P bytes) it must still hold the branch prefix sums
         // (10 bytes per branch), the select histogram and the window_slide scratch of this class
-        if (c == 0 && longseq && (80 * (big_n / 64) + 24 * 8 * std::max(Kmax, 1) + 4096 > 16 * P[c] || 10 * (BR[c] + 1) + 16 + 24 * Kmax + 2048 > 16 * P[c]))
+        if (c == 0 && longseq && (8 * MASK_WORDS * (big_n / 64) + 24 * 8 * std::max(Kmax, 1) + 4096 > 16 * P[c] || 10 * (BR[c] + 1) + 16 + 24 * Kmax + 2048 > 16 * P[c]))
             return fail(RAFFT_ERR_PARAM, "nb_mode too large for the LDS scratch of the class for regions beyond 4096 positions");
         if (c >= 1 && (10 * (BR[c] + 1) + 16 > 8 * P[c] || 2 * P[c] + 1152 + 16 > 8 * P[c] || (NT[c] > 64 && NT[c] * 24 > 8 * P[c])))
             return fail(RAFFT_ERR_PARAM, "internal: expand LDS plan does not fit its size class");
@@ -314,7 +314,7 @@ int class_cfg(int K, int maxL, ClsCfg out[NGEN + 1], bool nofft1 = false, bool n
         // (256 threads: at the 168 VGPRs the kernel needs without spilling a SIMD holds three wavefronts - three 256-thread
         //  workgroups per CU; a 512-thread workgroup is two wavefronts per SIMD, and two of those would need 128 VGPRs: 44 spilled)
         const int Cc = std::max(1, std::min(8, 256 / std::max(Kmax, 1)));
-        const bool fits = 80 * (nmax / 64) + 24 * Cc * Kmax + 2048 + 64 <= 16 * Pd && 10 * (MAX_BR + 1) + 16 + 8 * Kmax + 2048 <= 16 * Pd;
+        const bool fits = 8 * MASK_WORDS * (nmax / 64) + 24 * Cc * Kmax + 2048 + 64 <= 16 * Pd && 10 * (MAX_BR + 1) + 16 + 8 * Kmax + 2048 <= 16 * Pd;
         ExpandLds l = expand_lds(Pd, 0, nmax, MAX_BR, Kmax, false, 1, false, 256);
         if (fits && l.total <= 80 * 1024) {
             const int per_cu = std::max(1, std::min(3, (160 * 1024) / l.total));

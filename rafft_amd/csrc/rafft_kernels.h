@@ -221,6 +221,10 @@ __host__ __device__ inline int node_class(int n, int span, int nbr, int merge_cl
     return 3;
 }
 
+// bit masks of a region (build_masks): 5 forward strings (A, C, G, U, contiguity with the previous position) and 5 reversed
+// ones, W = ceil(n / 64) words each
+#define MASK_F_WORDS 5
+#define MASK_WORDS 10
 // LDS layout of the expand kernel (bytes).  Region A is time-shared between the FFT
 // buffers and the sort keys; region B holds the loop itself.
 struct ExpandLds {
@@ -241,7 +245,7 @@ __host__ __device__ inline ExpandLds expand_lds(int Pmax, int Lmax, int nmax, in
     l.offA = 0;
     l.szA = al(16 * Pmax);
     if (nofft) {
-        const int need1 = 8 * Pmax + 80 * ((nmax + 63) / 64) + (nt > 64 && 24 * nt > 1152 ? 24 * nt : 1152) /* select histogram, later the partial results of chunked diagonals (wide classes) */, need2 = 8 * Pmax + 10 * (brmax + 1) + 16, need3 = 8 * Pmax + 8 * Kmax + 64;
+        const int need1 = 8 * Pmax + 8 * MASK_WORDS * ((nmax + 63) / 64) + 8 + (nt > 64 && 24 * nt > 1152 ? 24 * nt : 1152) /* select histogram, later the partial results of chunked diagonals (wide classes) */, need2 = 8 * Pmax + 10 * (brmax + 1) + 16, need3 = 8 * Pmax + 8 * Kmax + 64;
         l.szA = al(need1 > need2 ? (need1 > need3 ? need1 : need3) : (need2 > need3 ? need2 : need3));
     }
     int o = l.szA;

@@ -172,8 +172,9 @@ __device__ __forceinline__ unsigned long long mask_window(const unsigned long lo
 }
 
 // Bit masks of a region: forward masks F[0..3] = positions holding A, C, G, U, F[4] = contiguity with the previous
-// position; R[] = the same strings reversed (bit j of R = bit n-1-j of F).  W words each.  One synchronisation inside
-// (the caller adds the one behind).
+// position; R[0..3] = the base strings reversed (bit j of R = bit n-1-j of F), R[4] = "contiguous with the NEXT position" reversed
+// (bit j of R[4] = bit n-j of F[4]) - so that for the cell (ip, jp = lag - ip) of a diagonal all five reversed strings are read at
+// the same bit n - 1 - lag + ip.  W words each, F first, then R.  One synchronisation inside (the caller adds the one behind).
 // (`code_at(t)`: the base code of the region's position t - an LDS array, or the sequence's codes read through `pos` for the class
 //  whose regions are too big for an LDS copy)
 template <int NT, class CodeAt>
@@ -188,11 +189,12 @@ __device__ inline void build_masks(unsigned long long *F, unsigned long long *R,
     }
     if (NT == 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } else __syncthreads();
     // reverse the whole 64 W-bit string (word order and bit order), then shift the n live bits down:
-    // R bit j = T bit (j + 64 W - n) with T[w] = brev(F[W-1-w]); bits of F past n are zero
+    // R bit j = T bit (j + 64 W - n) with T[w] = brev(F[W-1-w]); bits of F past n are zero.  The contiguity string is shifted one
+    // bit less (bit j = F[4] bit n - j = T bit j + 64 W - n - 1; its bit 0 is F[4] bit n: zero)
     for (int idx = tid; idx < 5 * W; idx += NT) {
         const int which = idx / W, w = idx - which * W;
-        const int s0 = 64 * w + 64 * W - n, q = s0 >> 6, bsh = s0 & 63;
-        const unsigned long long lo = q < W ? __brevll(F[which * W + W - 1 - q]) : 0ULL;
+        const int s0 = 64 * w + 64 * W - n - (which == 4 ? 1 : 0), q = s0 >> 6, bsh = s0 & 63;      // (arithmetic shift: q = -1 for s0 = -1)
+        const unsigned long long lo = q >= 0 && q < W ? __brevll(F[which * W + W - 1 - q]) : 0ULL;
         const unsigned long long hi = q + 1 < W ? __brevll(F[which * W + W - 2 - q]) : 0ULL;
         R[which * W + w] = bsh ? (lo >> bsh) | (hi << (64 - bsh)) : lo;
     }
@@ -564,7 +566,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
             // base masks of the region (the same arrays window_slide uses below, built once here) ...
             const int W = (n + 63) >> 6;
             unsigned long long *F = (unsigned long long *)(lds + lay.offA + 8 * Pk);
-            unsigned long long *R = F + 5 * W;
+            unsigned long long *R = F + MASK_F_WORDS * W;
             build_masks<NT>(F, R, W, n, code_at, pos, tid);
             ESYNC();
             // ... and the three pair counts of every lag: bit ip of window(R_x, sft + 64 w) = base x at position k - ip
@@ -653,7 +655,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
         ESTAMP(3);   // lag values
         if (skip_lvl >= 3) continue;
         if (selected) {
-            int *hist = (int *)(lds + lay.offA + (LONGSEQ == 2 ? lay.szA - 2048 : nofft ? 8 * P + 80 * ((nmax + 63) >> 6) : 9 * P));      // 256 bins behind the lag values and the bit masks (8 P + 0.625 P at most); at region A's end when the masks of the biggest regions are already there
+            int *hist = (int *)(lds + lay.offA + (LONGSEQ == 2 ? lay.szA - 2048 : nofft ? 8 * P + 8 * MASK_WORDS * ((nmax + 63) >> 6) : 9 * P));      // 256 bins behind the lag values and the bit masks (8 P + 0.69 P at most); at region A's end when the masks of the biggest regions are already there
             int *shs = hist + 256;                                   // scan scratch [32]
             for (int rep_ = 0; rep_ < 1 + ((rep >> 1) & 1); rep_++) {
             auto ukey = [&](int i) -> unsigned long long {
@@ -781,19 +783,28 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
         // (negative weights or the forced-FFT test mode take the cell-by-cell form below)
         const bool ws_masks = PROD || (d.gc >= 0.0 && d.au >= 0.0 && d.gu >= 0.0 && !force_fft);
         if (ws_masks) {
-            // forward masks F[0..3] = A,C,G,U, F[4] = contiguity with the previous position; R[] = reversed strings.
+            // forward masks F[0..3] = A,C,G,U, F[4] = contiguity with the previous position; R[] = reversed strings (build_masks).
             // Region A: behind the lag values (8 P bytes) unless those were sorted in place and are dead; the
             // partial results of chunked diagonals follow the masks.
             const int W = (n + 63) >> 6;
             unsigned long long *F = (unsigned long long *)(lds + lay.offA + (inplace ? 0 : 8 * Pk));
-            unsigned long long *R = F + 5 * W;
+            unsigned long long *R = F + MASK_F_WORDS * W;
             parts = (WsPart *)(R + 5 * W);
             if (LONGSEQ != 2 && (!mw || inplace))   // (the direct correlation on multi-word masks has built them already - behind the lag values)
             for (int rep_ = 0; rep_ < 1 + ((rep >> 7) & 1); rep_++) {
                 build_masks<NT>(F, R, W, n, code_at, pos, tid);
                 ESYNC();
             }
-            auto window = [&](const unsigned long long *X, int start) -> unsigned long long { return mask_window(X, W, start); };
+            // (round 5) The cells of a diagonal are taken 32 at a time, counted from the diagonal's FIRST cell: chunk k holds the cells
+            // ip0 + 32 k .. of the forward strings and - the reversed strings all being read at bit n - 1 - lag + ip - the bits
+            // n - 1 - lag + ip0 + 32 k .. of the reversed ones; a window of 32 bits at any bit offset is two adjacent words and one
+            // v_alignbit.  Half a diagonal of a region of up to 64 positions is ONE chunk, and the loop over its pairing cells runs on
+            // 32-bit masks (rounds 1-4: 64-bit words aligned to the region, 64-bit shifts and tests per cell, windows assembled from
+            // range-checked loads: 38 % of the kernel's vector instructions, tools/pmc_phases.sh).  Bits read past a string's end are
+            // cells past the half-diagonal's eligible prefix: masked.
+            const uint32_t *F32 = (const uint32_t *)F, *R32 = (const uint32_t *)R;
+            const int W2 = 2 * W;
+            auto win = [](const uint32_t *X, int start) -> uint32_t { const int q_ = start >> 5; return __builtin_amdgcn_alignbit(X[q_ + 1], X[q_], (uint32_t)(start & 31)); };
             for (int rep_ = 0; rep_ < 1 + ((rep >> 2) & 1); rep_++) {
             for (int q = tid; q < Kp * C; q += NT) {
                 const int r = q / C, c = q - r * C;
@@ -812,70 +823,66 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                     if ((int)pos[jp0 - mid] - (int)pos[ip0 + mid] > d.min_hp) lo = mid + 1; else hi = mid;
                 }
                 const int lim = lo;
-                // this lane's share of the eligible cells [a, e), as positions ip
-                const int ipa = ip0 + (int)((long long)lim * c / C), ipe = ip0 + (int)((long long)lim * (c + 1) / C);
-                const int sft = n - 1 - lagp;                // bit ip of x? = base at position lagp - ip
-                // pairing cells of word w by pair type, and the contiguity mask
-                auto cells = [&](int w, unsigned long long &pGC, unsigned long long &pAU, unsigned long long &pGU, unsigned long long &cm) {
-                    const int wb = w << 6;
-                    const unsigned long long xA = window(R + 0 * W, wb + sft), xC = window(R + 1 * W, wb + sft),
-                                             xG = window(R + 2 * W, wb + sft), xU = window(R + 3 * W, wb + sft);
-                    const unsigned long long fA = F[0 * W + w], fC = F[1 * W + w], fG = F[2 * W + w], fU = F[3 * W + w];
-                    pGC = d.gc != 0.0 ? ((fG & xC) | (fC & xG)) : 0ULL;
-                    pAU = d.au != 0.0 ? ((fA & xU) | (fU & xA)) : 0ULL;
-                    pGU = d.gu != 0.0 ? ((fG & xU) | (fU & xG)) : 0ULL;
-                    cm = F[4 * W + w] & window(R + 4 * W, wb + sft - 1);   // contiguous with previous cell
-                    if (ip0 >= wb && ip0 < wb + 64) cm &= ~(1ULL << (ip0 - wb));          // never for the first cell
+                // this lane's share of the eligible cells [ca, ce), counted from the diagonal's first cell
+                const int ca = (int)((long long)lim * c / C), ce = (int)((long long)lim * (c + 1) / C);
+                const int rs0 = n - 1 - lagp + ip0;          // bit of the reversed strings that belongs to the first cell (>= 0)
+                // pairing cells of chunk k by pair type, and the cells contiguous with their predecessor
+                auto cells = [&](int k, uint32_t &pGC, uint32_t &pAU, uint32_t &pGU, uint32_t &cm) {
+                    const int cs = ip0 + 32 * k, rs = rs0 + 32 * k;
+                    const uint32_t fA = win(F32 + 0 * W2, cs), fC = win(F32 + 1 * W2, cs), fG = win(F32 + 2 * W2, cs), fU = win(F32 + 3 * W2, cs);
+                    const uint32_t xA = win(R32 + 0 * W2, rs), xC = win(R32 + 1 * W2, rs), xG = win(R32 + 2 * W2, rs), xU = win(R32 + 3 * W2, rs);
+                    pGC = d.gc != 0.0 ? ((fG & xC) | (fC & xG)) : 0u;
+                    pAU = d.au != 0.0 ? ((fA & xU) | (fU & xA)) : 0u;
+                    pGU = d.gu != 0.0 ? ((fG & xU) | (fU & xG)) : 0u;
+                    cm = win(F32 + 4 * W2, cs) & win(R32 + 4 * W2, rs);       // contiguous with the previous cell on both strands
+                    if (k == 0) cm &= ~1u;                                    // never for the first cell
                 };
-                auto span = [](int lo_, int hi_, int wb) -> unsigned long long {             // bits of cells [lo_, hi_) inside word wb
-                    unsigned long long m_ = ~0ULL;
-                    if (lo_ > wb) m_ &= ~0ULL << (lo_ - wb);
-                    if (hi_ < wb + 64) m_ &= (1ULL << (hi_ - wb)) - 1;
+                auto span = [](int lo_, int hi_, int cb) -> uint32_t {                       // bits of cells [lo_, hi_) inside the chunk that starts at cell cb
+                    uint32_t m_ = ~0u;
+                    if (lo_ > cb) m_ &= ~0u << (lo_ - cb);
+                    if (hi_ < cb + 32) m_ &= (1u << (hi_ - cb)) - 1u;
                     return m_;
                 };
                 double mx_s = 0.0, prev = 0.0;
-                int mx_nb = 0, mx_i = 0, mx_j = 0, last_ip = -2, runlen = 0;
-                bool found = false;
-                if (ipe > ipa) {
-                    int z = ipa;                             // replay start: first cell of the run of pairing cells ending at ipa - 1
-                    if (ipa > ip0) {
-                        for (int wz = (ipa - 1) >> 6;; wz--) {
-                            const int wb = wz << 6;
-                            unsigned long long pGC, pAU, pGU, cm;
-                            cells(wz, pGC, pAU, pGU, cm);
-                            const unsigned long long zeros = ~(pGC | pAU | pGU) & span(ip0, ipa, wb);
-                            if (zeros) { z = wb + 64 - __clzll((long long)zeros); break; }
-                            if (wb <= ip0) { z = ip0; break; }
+                int mx_nb = 0, mx_c = 0, last_c = -2, runlen = 0, mx_i = 0, mx_j = 0;
+                if (ce > ca) {
+                    int z = ca;                              // replay start: first cell of the run of pairing cells ending at ca - 1
+                    if (ca > 0) {
+                        for (int kz = (ca - 1) >> 5;; kz--) {
+                            const int cb = kz << 5;
+                            uint32_t pGC, pAU, pGU, cm;
+                            cells(kz, pGC, pAU, pGU, cm);
+                            const uint32_t zeros = ~(pGC | pAU | pGU) & span(0, ca, cb);
+                            if (zeros) { z = cb + 32 - __clz((int)zeros); break; }
+                            if (cb == 0) { z = 0; break; }
                         }
                     }
-                    for (int w = z >> 6; w <= (ipe - 1) >> 6; w++) {
-                        const int wb = w << 6;
-                        unsigned long long pGC, pAU, pGU, cm;
-                        cells(w, pGC, pAU, pGU, cm);
-                        const unsigned long long range = span(z, ipe, wb);
-                        pGC &= range; pAU &= range; pGU &= range;
-                        unsigned long long any = pGC | pAU | pGU;
+                    for (int k = z >> 5; k <= (ce - 1) >> 5; k++) {
+                        const int cb = k << 5;
+                        uint32_t pGC, pAU, pGU, cm;
+                        cells(k, pGC, pAU, pGU, cm);
+                        uint32_t any = (pGC | pAU | pGU) & span(z, ce, cb);
                         while (any) {
-                            const int bi = __ffsll((long long)any) - 1;
-                            any &= any - 1;
-                            const unsigned long long bit = 1ULL << bi;
-                            const int ip = wb + bi;
-                            const double w8 = (pGC & bit) ? d.gc : (pAU & bit) ? d.au : d.gu;
-                            if (ip != last_ip + 1) { prev = 0.0; runlen = 0; }   // previous cell was a zero cell
+                            const int bi = __ffs((int)any) - 1;
+                            any &= any - 1u;
+                            const int cc = cb + bi;
+                            const double w8 = ((pGC >> bi) & 1u) ? d.gc : ((pAU >> bi) & 1u) ? d.au : d.gu;
+                            if (cc != last_c + 1) { prev = 0.0; runlen = 0; }   // previous cell was a zero cell
                             double t = w8;
-                            if (cm & bit) t = (prev + w8) * w8;
+                            if ((cm >> bi) & 1u) t = (prev + w8) * w8;
                             runlen++;
-                            if (ip >= ipa && t >= mx_s) { mx_s = t; mx_nb = runlen; mx_i = ip; mx_j = lagp - ip; found = true; }
-                            prev = t; last_ip = ip;
+                            if ((C == 1 || cc >= ca) && t >= mx_s) { mx_s = t; mx_nb = runlen; mx_c = cc; }
+                            prev = t; last_c = cc;
                         }
                     }
-                    if (!found) { mx_i = ipe - 1; mx_j = lagp - (ipe - 1); }   // last eligible (zero) cell of the share, nb = 0
+                    if (mx_nb == 0) mx_c = ce - 1;           // no pairing cell in the share: its last eligible (zero) cell, nb = 0
+                    mx_i = ip0 + mx_c; mx_j = lagp - mx_i;
                 }
                 if (C == 1) {
                     wnb[r] = (uint16_t)mx_nb; wmi[r] = (uint16_t)mx_i; wmj[r] = (uint16_t)mx_j;
                     if (dbg.nb) { dbg.nb[r] = mx_nb; dbg.mi[r] = mx_i; dbg.mj[r] = mx_j; dbg.score[r] = mx_s; }
                 } else {
-                    WsPart wp; wp.score = mx_s; wp.nb = mx_nb; wp.mi = mx_i; wp.mj = mx_j; wp.any = ipe > ipa ? 1 : 0;
+                    WsPart wp; wp.score = mx_s; wp.nb = mx_nb; wp.mi = mx_i; wp.mj = mx_j; wp.any = ce > ca ? 1 : 0;
                     parts[q] = wp;
                 }
             }
