@@ -85,6 +85,7 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
     unsigned int st_eval = 0, st_guess = 0, st_kguess = 0;                   // stem energies evaluated / involving a rule or model value / kept ones that do (every lane its own)
     const unsigned FETCH = n_items > 4u * TPW * n_waves ? (unsigned)d.fetch_bulk : 1u;            // groups of TPW regions claimed per atomic
     unsigned fetch_base = 0, fetch_left = 0;                                  // uniform across the wavefront
+    const FetchPlan fplan = fetch_plan(d, n_items, FETCH * TPW, TPW);
     int fshard = (int)(gw & (NSHARD - 1));
     unsigned long long ffailed = 0;
     unsigned long long slab_base = 0; unsigned slab_left = 0;                 // lane 0 only: reserved candidate slots
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
         wave_sync();                                   // the previous regions' LDS use is over
         if (fetch_left == 0) {
             unsigned fcount = TPW;
-            fetch_base = fetch_chunk(d, cls, n_items, FETCH * TPW, TPW, fshard, ffailed, fcount);
+            fetch_base = fetch_chunk(d, cls, fplan, fshard, ffailed, fcount);
             if (fetch_base == ~0u) break;
             fetch_left = fcount / TPW;
         }
@@ -149,6 +150,8 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
         const uint32_t rA = __brev(mA) >> rs, rC = __brev(mC) >> rs, rG = __brev(mG) >> rs, rU = __brev(mU) >> rs, rg = __brev(mg) >> rs;
         wave_sync();
         SSTAMP(1);   // header + loop fill + masks
+        double wgc = d.gc, wau = d.au, wgu = d.gu;      // (the pair weights in vector registers of their own: expand_kernel's cell loop)
+        asm volatile("" : "+v"(wgc), "+v"(wau), "+v"(wgu));
 
         // ---- window_slide of every lag (rafft/rafft.py:36-83); a lane owns lags tl and tl + TL
         int w_nb[2], w_mi[2], w_mj[2];
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
                         const int ip = __ffs((int)any) - 1;
                         any &= any - 1;
                         const uint32_t bit = 1u << ip;
-                        const double w8 = (pGC & bit) ? d.gc : (pAU & bit) ? d.au : d.gu;
+                        const double w8 = (pGC & bit) ? wgc : (pAU & bit) ? wau : wgu;
                         if (ip != last_ip + 1) { prev = 0.0; runlen = 0; }
                         double t = w8;
                         if (cm & bit) t = (prev + w8) * w8;

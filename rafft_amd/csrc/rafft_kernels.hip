@@ -208,13 +208,22 @@ __device__ inline void build_masks(unsigned long long *F, unsigned long long *R,
 // a wavefront that finds its shard empty reads that ONE word and moves to a shard that still has chunks.
 // Chunks taper: the first Dev::taper_pct percent of a list go out CH items at a time, the rest CT at a time (`count` says which) -
 // the wavefronts that finish a launch are then a fraction of a big chunk apart, not a whole one.
-__device__ inline unsigned fetch_chunk(const Dev &d, int cls, unsigned n_items, unsigned CH, unsigned CT, int &shard, unsigned long long &failed, unsigned &count)
+struct FetchPlan { unsigned cA, nA, chunks_total, CH, CT; unsigned long long exist; };      // (what fetch_chunk needs of a list: computed once per launch)
+__device__ inline FetchPlan fetch_plan(const Dev &d, unsigned n_items, unsigned CH, unsigned CT)
+{
+    FetchPlan f;
+    f.CH = CH; f.CT = CT;
+    f.cA = CH > CT ? (unsigned)(((unsigned long long)n_items * (unsigned long long)d.taper_pct / 100ULL) / CH) : n_items / CH;      // big chunks
+    f.nA = f.cA * CH;                                                                                                            // items in them
+    f.chunks_total = f.cA + (n_items - f.nA + CT - 1) / CT;
+    f.exist = f.chunks_total >= NSHARD ? ~0ULL : ((1ULL << f.chunks_total) - 1ULL);      // shards that hold any chunk
+    return f;
+}
+__device__ inline unsigned fetch_chunk(const Dev &d, int cls, const FetchPlan &f, int &shard, unsigned long long &failed, unsigned &count)
 {
     const int lane = threadIdx.x & 63;
-    const unsigned cA = CH > CT ? (unsigned)(((unsigned long long)n_items * (unsigned long long)d.taper_pct / 100ULL) / CH) : n_items / CH;      // big chunks
-    const unsigned nA = cA * CH;                                                                               // items in them
-    const unsigned chunks_total = cA + (n_items - nA + CT - 1) / CT;
-    const unsigned long long exist = chunks_total >= NSHARD ? ~0ULL : ((1ULL << chunks_total) - 1ULL);      // shards that hold any chunk
+    const unsigned cA = f.cA, nA = f.nA, chunks_total = f.chunks_total, CH = f.CH, CT = f.CT;
+    const unsigned long long exist = f.exist;
     for (;;) {
         if ((exist >> shard) & ~(failed >> shard) & 1ULL) {
             const unsigned cnt = (chunks_total - (unsigned)shard + (NSHARD - 1)) / NSHARD;                     // chunks of this shard
@@ -336,7 +345,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
     // (class 3 is served by two kernels on one work list: the list's length says which of them works - launch_expand_cls)
     if (((cls_arg & 0x4000) && n_items > (unsigned)d.c3_switch) || ((cls_arg & 0x8000) && n_items <= (unsigned)d.c3_switch)) return;
     const int shard = gteam & (NSHARD - 1);
-    unsigned long long st_items = 0, st_n = 0, st_lags = 0, st_nbr = 0;   // per-block statistics
+    unsigned st_items = 0, st_n = 0, st_lags = 0, st_nbr = 0;   // per-team statistics (uniform over the team: scalar registers; a team's share of one launch fits 32 bits)
     if (tid < 3) misc[24 + tid] = 0;         // per team: stem energies evaluated / involving a rule or model value / kept ones that do
 
     // Work items are fetched FETCH at a time and candidate slots are reserved in slabs, so that the
@@ -347,10 +356,11 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
 #define ESTAMP(k) do { if (eprof) { const unsigned long long tn_ = clock64(); eacc[k] += tn_ - et; et = tn_; ft1 = tn_; } } while (0)
 #define FSTAMP(k) do { if (eprof) { const unsigned long long tn_ = clock64(); eacc[k] += tn_ - ft1; ft1 = tn_; } } while (0)   // inside dE (10, 11) and emit (12-15)
     const unsigned FETCH = (NT == 64 && n_items > 4u * n_teams) ? (unsigned)d.fetch_bulk : 1u;
+    const FetchPlan fplan = fetch_plan(d, n_items, NT == 64 ? FETCH : 1u, 1u);
     unsigned fetch_base = 0, fetch_left = 0;                 // uniform across the workgroup
     int fshard = (int)(gteam & (NSHARD - 1));                // work-cursor shard this team claims from next (fetch_chunk)
     unsigned long long ffailed = 0;
-    unsigned long long slab_base = 0; unsigned slab_left = 0;   // thread 0 only
+    unsigned long long slab_base = 0; unsigned slab_left = 0;   // reserved candidate slots (NT == 64: uniform over the wavefront; wider teams: thread 0 only)
 
     for (;;) {
         ESYNC();                       // previous region's LDS use is over
@@ -362,9 +372,9 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
         unsigned long long ft0 = eprof ? clock64() : 0;
         if (fetch_left == 0) {
             unsigned fcount = 1;
-            if (NT == 64) fetch_base = fetch_chunk(d, cls, n_items, FETCH, 1u, fshard, ffailed, fcount);
+            if (NT == 64) fetch_base = fetch_chunk(d, cls, fplan, fshard, ffailed, fcount);
             else {
-                if (tid < 64) { const unsigned b_ = fetch_chunk(d, cls, n_items, 1u, 1u, fshard, ffailed, fcount); if (tid == 0) misc[8] = (int)b_; }
+                if (tid < 64) { const unsigned b_ = fetch_chunk(d, cls, fplan, fshard, ffailed, fcount); if (tid == 0) misc[8] = (int)b_; }
                 ESYNC();
                 fetch_base = (unsigned)misc[8];
             }
@@ -391,7 +401,10 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
         //  that it still takes sequence positions - sx0 < 4096 never exceeds the offset of that area, the shifted pointer stays
         //  inside the LDS.  The address space is known at compile time either way.)
         const int sx0 = ci < 0 ? 0 : ci, sx1 = ci < 0 ? L : cj + 1;
-        const uint8_t *Sl = LONGSEQ ? codes : (const uint8_t *)Sl_lds - sx0;
+        // (the copy goes four bases at a time, whole aligned words of the sequence: the LDS copy starts `spad` bytes in, so that it
+        //  is aligned like its source; the 8 bytes of slack in front of and behind the area hold the up to three bases too many)
+        const int spad = LONGSEQ ? 0 : (int)((uintptr_t)(codes + sx0) & 3u);
+        const uint8_t *Sl = LONGSEQ ? codes : (const uint8_t *)Sl_lds + spad - sx0;
         const int m = 2 * n - 1;
         const int P = next_pow2_ge(m);
         const int logP = 31 - __clz(P);
@@ -420,7 +433,9 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
         }
         if (CODE_LDS && tid == 0) P2[(n + 15) >> 4] = 0u;       // (the word of slack behind the last: strand_window reads two)
         if (LONGSEQ == 0) {   // bases: only the span of this loop is ever looked at (closing pair, its neighbours inside, branches)
-            for (int x = sx0 + tid; x < sx1; x += NT) Sl_lds[x - sx0] = codes[x];
+            const uint32_t *src4 = (const uint32_t *)(codes + sx0 - spad);
+            const int nw4 = (sx1 - sx0 + spad + 3) >> 2;
+            for (int x = tid; x < nw4; x += NT) ((uint32_t *)Sl_lds)[x] = src4[x];
         }
         for (int t = tid; t < nbr; t += NT) brl[t] = d.pos_packed ? (brg[t] & 0x0FFF0FFFu) : brg[t];   // (Dev::pos_packed: the codes ride along)
         ESYNC();
@@ -804,6 +819,10 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
             // cells past the half-diagonal's eligible prefix: masked.
             const uint32_t *F32 = (const uint32_t *)F, *R32 = (const uint32_t *)R;
             const int W2 = 2 * W;
+            // (the three pair weights in vector registers of their own: a select between two scalar operands is not encodable, and
+            //  the compiler would rather copy them into vector registers again for every cell of the loop below - 6 of its 42 instructions)
+            double wgc = d.gc, wau = d.au, wgu = d.gu;
+            asm volatile("" : "+v"(wgc), "+v"(wau), "+v"(wgu));
             auto win = [](const uint32_t *X, int start) -> uint32_t { const int q_ = start >> 5; return __builtin_amdgcn_alignbit(X[q_ + 1], X[q_], (uint32_t)(start & 31)); };
             for (int rep_ = 0; rep_ < 1 + ((rep >> 2) & 1); rep_++) {
             for (int q = tid; q < Kp * C; q += NT) {
@@ -866,7 +885,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                             const int bi = __ffs((int)any) - 1;
                             any &= any - 1u;
                             const int cc = cb + bi;
-                            const double w8 = ((pGC >> bi) & 1u) ? d.gc : ((pAU >> bi) & 1u) ? d.au : d.gu;
+                            const double w8 = ((pGC >> bi) & 1u) ? wgc : ((pAU >> bi) & 1u) ? wau : wgu;
                             if (cc != last_c + 1) { prev = 0.0; runlen = 0; }   // previous cell was a zero cell
                             double t = w8;
                             if ((cm >> bi) & 1u) t = (prev + w8) * w8;
@@ -1034,8 +1053,98 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
         FSTAMP(11);  // (dE: the loop as it is + every candidate)
         ESTAMP(6);   // dE
         // ---- stable sort of the kept candidates by dE (ties keep lag-rank order), emit
-        // compact the kept lags (keep[] becomes the list of their indices)
         int nkept = 0;
+        if constexpr (NT == 64) {
+            // (round 5) One wavefront: no key array is built.  The kept flags of every slab of 64 lags are a ballot (kept in the team's
+            // LDS: nb_mode may ask for up to eight slabs) and the kept lags are compacted in place; the candidate slots are handed out
+            // by lane 0 and reach the other lanes through readfirstlane instead of an LDS word and a fence; a kept candidate finds its
+            // rank by walking the ballots - a scalar loop over the handful of kept lags, their dE read as LDS broadcasts - and only
+            // a dE tie looks at (value, lag).  (Rounds 1-4: packed keys in region A, three fences, two of them around a one-lane
+            // section - a quarter of the kernel's cycles for five candidates per region.)
+            unsigned long long *kbs = (unsigned long long *)&misc[8];      // [8] kept ballots by slab
+            for (int base = 0; base < Kp; base += 64) {
+                const int r = base + tid;
+                const int kf = (r < Kp) ? keep[r] : 0;
+                const unsigned long long bal = __ballot((kf & 1) != 0);
+                if (T->lsb) {                 // (built-in tables: how many stem energies of this launch involved a rule / model value)
+                    const int ne = __popcll(__ballot((kf & 4) != 0)), ng = __popcll(__ballot((kf & 6) == 6)), nk = __popcll(__ballot((kf & 3) == 3));
+                    if (tid == 0) { atomicAdd(&misc[24], ne); if (ng) atomicAdd(&misc[25], ng); if (nk) atomicAdd(&misc[26], nk); }
+                }
+                if (tid == 0) kbs[base >> 6] = bal;
+                // (the kept lags, compacted in place: one pass of the emit body below serves them all, whichever slab they came from;
+                //  nkept + pre <= r - a flag that has not been read yet is never overwritten)
+                if (kf & 1) keep[nkept + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = (uint16_t)r;
+                nkept += __popcll(bal);
+            }
+            st_items++; st_n += n; st_lags += Kp; st_nbr += nbr;
+            unsigned long long cbase = 0;
+            int ovf_i = 0;
+            if (nkept) {
+                unsigned long long b0 = 0;
+                const bool fresh = (unsigned)nkept > slab_left;      // reserve a new slab of candidate slots (the rest of the old one is dropped)
+                const unsigned slab = d.cand_shard_cap >= 64u * (unsigned)d.cand_slab ? (unsigned)d.cand_slab : 16u;
+                const unsigned want = (unsigned)nkept > slab ? (unsigned)nkept : slab;
+                if (fresh) {
+                    if (tid == 0) b0 = atomicAdd(&d.c->cand[shard].v, (unsigned long long)want);
+                    b0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(b0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)b0);
+                    if (b0 + want > d.cand_shard_cap) { if (tid == 0) atomicOr(&d.c->overflow, OVF_CAND); ovf_i = 1; slab_left = 0; }
+                    else { slab_base = (unsigned long long)shard * d.cand_shard_cap + b0; slab_left = want; }
+                }
+                if (!ovf_i) { cbase = slab_base; slab_base += nkept; slab_left -= nkept; }
+            }
+            wave_sync();                      // the ballots are in LDS
+            FSTAMP(13);  // (emit: counts, candidate slots)
+            if (nkept && !ovf_i)
+            for (int rep_ = 0; rep_ < 1 + ((rep >> 6) & 1); rep_++)
+            for (int x = tid; x < nkept; x += 64) {
+                {
+                    const int r = keep[x];
+                    const int my = dd[r];
+                    int rank = 0;
+                    for (int b2 = 0; b2 < Kp; b2 += 64) {
+                        const unsigned long long mv = kbs[b2 >> 6];
+                        unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(mv >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)mv);
+                        while (m) {
+                            const int y = b2 + __ffsll((long long)m) - 1;
+                            m &= m - 1;
+                            const int dy = dd[y];
+                            if (dy < my) rank++;
+                            else if (dy == my && y != r) {               // dE tie: lag-rank order, i.e. (value desc, lag desc)
+                                if (inplace) rank += y < r ? 1 : 0;      // (sorted in place: the index IS the lag's rank)
+                                else {
+                                    const int lagq = rk[y], lagr = rk[r];
+                                    const double qv = keyv[lagq], myv = keyv[lagr];
+                                    rank += ((qv > myv) || (qv == myv && lagq > lagr)) ? 1 : 0;
+                                }
+                            }
+                        }
+                    }
+                    FSTAMP(14);  // (emit: rank)
+                    const int mi = wmi[r], mj = wmj[r], nb = wnb[r];
+                    const int a0 = pos[mi], b0 = pos[mj], ao = pos[mi - nb + 1], bo = pos[mj + nb - 1];
+                    uint64_t h1 = 0, h2 = 0;
+                    if (a0 - ao == nb - 1 && bo - b0 == nb - 1) stem_hash(a0, b0, ao, bo, &h1, &h2);      // contiguous: the pair hashes telescope
+                    else
+                        for (int t = 0; t < nb; t++) {
+                            uint64_t a, b;
+                            pair_hash(pos[mi - t], pos[mj + t], &a, &b);
+                            h1 += a; h2 += b;
+                        }
+                    Cand cd;
+                    cd.ddcal = my; cd.mi = (uint16_t)mi; cd.mj = (uint16_t)mj; cd.nb = (uint16_t)nb;
+                    { int c0, c1, c2, c3; br_lower4(brl, nbr, a0, b0, ao, bo, c0, c1, c2, c3); cd.set_cuts(c0, c1, c2, c3); }
+                    cd.h1 = h1; cd.h2 = h2;
+                    if (!dry) { d.cand[cbase + rank] = cd; d.cslot[cbase + rank] = 0ULL; }   // (both child slots: nobody has asked yet)
+                    if (dbg.kept) dbg.kept[rank] = r;
+                }
+            }
+            if (tid == 0 && !dry) {
+                d.nd[nid].cand = cbase;
+                d.nd[nid].ncand = ovf_i ? 0 : nkept;
+                if (dbg.n_ranked) dbg.n_ranked[1] = nkept;
+            }
+        } else {
+        // compact the kept lags (keep[] becomes the list of their indices)
         {
             int *wave_tot = misc + 16;
             const int lane = tid & 63, wv = tid >> 6;
@@ -1140,6 +1249,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
             d.nd[nid].cand = cbase;
             d.nd[nid].ncand = ovf ? 0 : nkept;
             if (dbg.n_ranked) dbg.n_ranked[1] = nkept;
+        }
         }
         FSTAMP(15);  // (emit: pair hashes, cuts, stores)
         ESTAMP(7);   // emit
