@@ -265,6 +265,19 @@ __device__ __forceinline__ int stem_stack_windows(const SmallT *T, uint32_t w5, 
     }
     return e;
 }
+// inclusive prefix sum over the 64 lanes of a wavefront (all of them active) in six DPP additions - row_shr 1, 2, 4, 8 inside the
+// rows of 16, then lane 15 of rows 0 / 2 into rows 1 / 3 (row_bcast:15) and lane 31 into the upper half (row_bcast:31) - where six
+// rounds of __shfl_up are six trips through the LDS crossbar
+__device__ __forceinline__ int wave_incl_scan(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
+    return x;
+}
 // one step of the OR-reduction over a row of 16 lanes (DPP row_shr): lane 15 of every row ends up with the OR of the row
 __device__ __forceinline__ uint32_t row16_or(uint32_t x)
 {

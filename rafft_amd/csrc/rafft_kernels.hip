@@ -329,7 +329,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
     uint16_t *rk = (uint16_t *)(lds + lay.off_rk);
     uint16_t *wnb = (uint16_t *)(lds + lay.off_nb);
     uint16_t *wmi = (uint16_t *)(lds + lay.off_mi);
-    uint16_t *wmj = (uint16_t *)(lds + lay.off_mj);
+    uint16_t *widx = (uint16_t *)(lds + lay.off_mj);    // the lags that gave a stem, compacted (the stem's mj is lag - mi: not stored)
     int *dd = (int *)(lds + lay.off_dd);
     uint16_t *keep = (uint16_t *)(lds + lay.off_keep);
     double *wtab = (double *)(lds + lay.off_w);
@@ -898,7 +898,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                     mx_i = ip0 + mx_c; mx_j = lagp - mx_i;
                 }
                 if (C == 1) {
-                    wnb[r] = (uint16_t)mx_nb; wmi[r] = (uint16_t)mx_i; wmj[r] = (uint16_t)mx_j;
+                    wnb[r] = (uint16_t)mx_nb; wmi[r] = (uint16_t)mx_i;      // (mj = lag - mi)
                     if (dbg.nb) { dbg.nb[r] = mx_nb; dbg.mi[r] = mx_i; dbg.mj[r] = mx_j; dbg.score[r] = mx_s; }
                 } else {
                     WsPart wp; wp.score = mx_s; wp.nb = mx_nb; wp.mi = mx_i; wp.mj = mx_j; wp.any = ce > ca ? 1 : 0;
@@ -914,7 +914,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                         const WsPart wp = parts[r * C + c];
                         if (wp.any && wp.score >= mx_s) { mx_s = wp.score; mx_nb = wp.nb; mx_i = wp.mi; mx_j = wp.mj; }
                     }
-                    wnb[r] = (uint16_t)mx_nb; wmi[r] = (uint16_t)mx_i; wmj[r] = (uint16_t)mx_j;
+                    wnb[r] = (uint16_t)mx_nb; wmi[r] = (uint16_t)mx_i;      // (mj = lag - mi)
                     if (dbg.nb) { dbg.nb[r] = mx_nb; dbg.mi[r] = mx_i; dbg.mj[r] = mx_j; dbg.score[r] = mx_s; }
                 }
             }
@@ -944,7 +944,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                     prev = t;
                 }
                 if (C == 1) {
-                    wnb[r] = (uint16_t)mx_nb; wmi[r] = (uint16_t)mx_i; wmj[r] = (uint16_t)mx_j;
+                    wnb[r] = (uint16_t)mx_nb; wmi[r] = (uint16_t)mx_i;      // (mj = lag - mi)
                     if (dbg.nb) { dbg.nb[r] = mx_nb; dbg.mi[r] = mx_i; dbg.mj[r] = mx_j; dbg.score[r] = mx_s; }
                 } else {
                     WsPart w; w.score = mx_s; w.nb = mx_nb; w.mi = mx_i; w.mj = mx_j; w.any = any;
@@ -960,7 +960,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                         const WsPart w = parts[r * C + c];
                         if (w.any && w.score >= mx_s) { mx_s = w.score; mx_nb = w.nb; mx_i = w.mi; mx_j = w.mj; }
                     }
-                    wnb[r] = (uint16_t)mx_nb; wmi[r] = (uint16_t)mx_i; wmj[r] = (uint16_t)mx_j;
+                    wnb[r] = (uint16_t)mx_nb; wmi[r] = (uint16_t)mx_i;      // (mj = lag - mi)
                     if (dbg.nb) { dbg.nb[r] = mx_nb; dbg.mi[r] = mx_i; dbg.mj[r] = mx_j; dbg.score[r] = mx_s; }
                 }
             }
@@ -989,13 +989,9 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                     vm = e_stem(T, tt, p > 0 ? (int)Sl[p - 1] : 0, q < L - 1 ? (int)Sl[q + 1] : 0, false);
                     vs = q - p + 1;
                 }
-                int xe = ve, xm = vm, xs = vs;
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int ye = __shfl_up(xe, o, 64), ym = __shfl_up(xm, o, 64), ys = __shfl_up(xs, o, 64);
-                    if (tid >= o) { xe += ye; xm += ym; xs += ys; }
-                }
+                const int xe = wave_incl_scan(ve), xm = wave_incl_scan(vm), xs = wave_incl_scan(vs);
                 if (i < nbr) { pe_ext[i] = c_e + xe - ve; pe_ml[i] = c_m + xm - vm; psp[i] = (uint16_t)(c_s + xs - vs); }
-                c_e += __shfl(xe, 63, 64); c_m += __shfl(xm, 63, 64); c_s += __shfl(xs, 63, 64);
+                c_e += __builtin_amdgcn_readlane(xe, 63); c_m += __builtin_amdgcn_readlane(xm, 63); c_s += __builtin_amdgcn_readlane(xs, 63);
             }
             if (tid == 0) { pe_ext[nbr] = c_e; pe_ml[nbr] = c_m; psp[nbr] = (uint16_t)c_s; }
         }
@@ -1005,14 +1001,26 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
         const BrList all_br{brl, 0, nbr, 0, 0, 0, 0, 0};
         int g_old = 0;           // (g: the energy involves a rule / model value of the built-in tables - SmallT::lsb)
         const int e_old = loop_energy_pre(T, B, Sl, L, ci, cj, all_br, pf, g_old);      // the loop as it is (same for every stem)
+        // (round 5) the lags that gave a stem, compacted: two lags in three do, and the loop below - a lane per stem, every lane on
+        // its own path through the loop energies - takes ceil(stems / 64) rounds instead of ceil(lags / 64): one instead of two for
+        // half of the regions of the one-wavefront class
+        int nst = 0;
+        for (int base = 0; base < Kp; base += NT) {
+            const int r = base + tid;
+            const int f = (r < Kp && wnb[r] > 0) ? 1 : 0;
+            if (r < Kp) keep[r] = 0;
+            int tot, ex = block_exscan_flag<NT>(f, misc + 16, &tot);
+            if (f) widx[nst + ex] = (uint16_t)r;
+            nst += tot;
+        }
+        ESYNC();
         for (int rep_ = 0; rep_ < 1 + ((rep >> 3) & 1); rep_++)
-            for (int r = tid; r < Kp; r += NT) {
+            for (int si = tid; si < nst; si += NT) {
+                const int r = widx[si];
                 const int nb = wnb[r];
-                keep[r] = 0;
-                dd[r] = 0;
-                if (nb > 0) {
+                {
                     int g = g_old;
-                    const int mi = wmi[r], mj = wmj[r];
+                    const int mi = wmi[r], mj = (int)rk[r] - mi;
                     const int a0 = pos[mi], b0 = pos[mj], ao = pos[mi - nb + 1], bo = pos[mj + nb - 1];
                     int lo, hi, lo_o, hi_o;
                     br_lower4(brl, nbr, a0, b0, ao, bo, lo, hi, lo_o, hi_o);
@@ -1045,9 +1053,9 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                     const double dE = dcal_to_energy(par_dcal + ddc) - par_e;
                     keep[r] = (uint16_t)(((dE < d.min_nrj) ? 1 : 0) | (g ? 2 : 0) | 4);     // bit 0 kept, bit 1 involves a rule / model value, bit 2 evaluated
                     if (dbg.ddcal) dbg.ddcal[r] = ddc;
-                } else if (dbg.ddcal)
-                    dbg.ddcal[r] = INT_MIN;
+                }
             }
+        if (dbg.ddcal) for (int r = tid; r < Kp; r += NT) if (wnb[r] == 0) dbg.ddcal[r] = INT_MIN;
         ESYNC();
 
         FSTAMP(11);  // (dE: the loop as it is + every candidate)
@@ -1120,7 +1128,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                         }
                     }
                     FSTAMP(14);  // (emit: rank)
-                    const int mi = wmi[r], mj = wmj[r], nb = wnb[r];
+                    const int mi = wmi[r], mj = (int)rk[r] - mi, nb = wnb[r];
                     const int a0 = pos[mi], b0 = pos[mj], ao = pos[mi - nb + 1], bo = pos[mj + nb - 1];
                     uint64_t h1 = 0, h2 = 0;
                     if (a0 - ao == nb - 1 && bo - b0 == nb - 1) stem_hash(a0, b0, ao, bo, &h1, &h2);      // contiguous: the pair hashes telescope
@@ -1227,7 +1235,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                     }
                 }
                 FSTAMP(14);  // (emit: sort keys, rank)
-                int mi = wmi[r], mj = wmj[r], nb = wnb[r];
+                int mi = wmi[r], mj = (int)rk[r] - mi, nb = wnb[r];
                 const int a0 = pos[mi], b0 = pos[mj], ao = pos[mi - nb + 1], bo = pos[mj + nb - 1];
                 uint64_t h1 = 0, h2 = 0;
                 if (a0 - ao == nb - 1 && bo - b0 == nb - 1) stem_hash(a0, b0, ao, bo, &h1, &h2);      // contiguous: the pair hashes telescope
