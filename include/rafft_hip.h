@@ -112,6 +112,8 @@ typedef struct {
     int64_t n_dE_guessed;           /* ... those whose dE read an interior-loop table entry that no reference-held energy row exercises */
     int64_t n_kept_guessed;         /* ... and the ones of these that passed the filter dE < min_nrj (rafft/rafft.py:102): candidates a beam member may pick */
     int64_t n_regrows_prod;         /* ... of n_regrows: a structure had more productive regions than the short lists hold (same arenas, long lists) */
+    int64_t n_waves_long_lists;     /* waves of the call folded with the long productive-region lists (1024 per structure instead of 64: a structure with
+                                       more than 64 was met under these parameters; eight such waves in a row that never needed them switch back) */
 } rafft_stats;
 
 /* Select the GPU (HIP ordinal) and upload the energy tables.  Optional: every other

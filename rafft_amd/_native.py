@@ -36,7 +36,7 @@ class Stats(C.Structure):
                 ("alg_bytes_expand", C.c_int64), ("alg_bytes_expand_all", C.c_int64), ("n_regrows", C.c_int64),
                 ("alg_bytes_expand_small", C.c_int64), ("alg_bytes_expand_c2", C.c_int64), ("alg_bytes_expand_c3", C.c_int64),
                 ("alg_bytes_beam", C.c_int64), ("n_node_instances", C.c_int64), ("n_dE_evals", C.c_int64), ("n_dE_guessed", C.c_int64),
-                ("n_kept_guessed", C.c_int64), ("n_regrows_prod", C.c_int64)]
+                ("n_kept_guessed", C.c_int64), ("n_regrows_prod", C.c_int64), ("n_waves_long_lists", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

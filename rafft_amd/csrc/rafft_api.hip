@@ -60,8 +60,8 @@ struct Workspace {
     hipStream_t stream = nullptr;
     hipStream_t cls_stream[NCLS] = {};
     hipStream_t copy_stream = nullptr;   // result rows of sequences that finish early leave while the others still fold
-    hipEvent_t ev_fork = nullptr, ev_join[NCLS] = {}, ev_hot = nullptr, ev_copy = nullptr;
-    void *hot = nullptr;                 // pinned, 1 KiB
+    hipEvent_t ev_fork = nullptr, ev_join[NCLS] = {}, ev_hot[2] = {}, ev_copy = nullptr;
+    void *hot = nullptr;                 // pinned, 2 x 1 KiB: the read-back slots of two consecutive steps (the host issues a step ahead)
     // named device buffers (grow-only)
     Buf codes, seq_off, seq_len, beam, beam_n, done, nsteps, ch_parent, ch_combo, ch_dcal, ch_h, seen, seen_off,
         seen_cap, seen_cnt, st, prod, nd, nlist, nd_slot, cslot, pos, br, sp, cand, looptab, trec, tsid,
@@ -200,9 +200,9 @@ int init_ws(Workspace &w)
     HIPCHK(hipStreamCreateWithFlags(&w.copy_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&w.ev_copy, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&w.ev_hot, hipEventDisableTiming | hipEventBlockingSync));   // (the scheduler sleeps on it when it has spun long enough)
+    for (int k = 0; k < 2; k++) HIPCHK(hipEventCreateWithFlags(&w.ev_hot[k], hipEventDisableTiming | hipEventBlockingSync));   // (the scheduler sleeps on it when it has spun long enough)
     static_assert(offsetof(Counters, node) <= 1024, "hot counters must fit the pinned read-back slot");
-    HIPCHK(hipHostMalloc(&w.hot, 1024, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(&w.hot, 2048, hipHostMallocDefault));
     w.ready = true;
     return 0;
 }
@@ -286,7 +286,9 @@ int class_cfg(int K, int maxL, ClsCfg out[NGEN + 1], bool nofft1 = false, bool n
         // region A is time-shared: behind the fp64 lag values (8 P bytes) it must still hold the branch prefix sums
         // (10 bytes per branch), the select histogram and the window_slide scratch of this class
         if (c == 0 && longseq && (8 * MASK_WORDS * (big_n / 64) + 24 * 8 * std::max(Kmax, 1) + 4096 > 16 * P[c] || 10 * (BR[c] + 1) + 16 + 24 * Kmax + 2048 > 16 * P[c]))
-            return fail(RAFFT_ERR_PARAM, "nb_mode too large for the LDS scratch of the class for regions beyond 4096 positions");
+            return fail(RAFFT_ERR_PARAM, std::string("nb_mode too large for the LDS scratch of the class for regions beyond 4096 positions: with a sequence of ") +
+                                         (maxL > 16384 ? "more than 16384 nt it must stay at or below 106" : "more than 4096 nt it must stay below ~400") +
+                                         " (this wave: nb_mode " + std::to_string(K) + ", longest sequence " + std::to_string(maxL) + " nt)");
         if (c >= 1 && (10 * (BR[c] + 1) + 16 > 8 * P[c] || 2 * P[c] + 1152 + 16 > 8 * P[c] || (NT[c] > 64 && NT[c] * 24 > 8 * P[c])))
             return fail(RAFFT_ERR_PARAM, "internal: expand LDS plan does not fit its size class");
         if (c >= 1 && LM[c] > 0 && l.off_S < LDS_SEQ)      // (expand_kernel's Sl: the staged bases are addressed by sequence position)
@@ -599,6 +601,11 @@ struct Wave {
     int depth = 0;                // regrowths of this job so far
     bool big_prod = false, want_big_prod = false;   // long productive-region lists (1024 per structure) for this run / asked for by it
     bool finished = false;
+    // (round 5) read-backs issued / looked at.  In step-ahead mode the host queues the materialize step and the next folding step
+    // BEFORE it has seen the counters of the running one (grids and class choices from the step before, counts from the device's own
+    // counters): the 24 lock-step steps of a lone batch no longer wait 150 us each for the host's round trip
+    int rb_issued = 0, rb_seen = 0;
+    bool step_ahead = false;
     long long last_rows_bytes = 0;
     std::vector<OutRec> early_recs, late_recs;
     PinBuf stage{};               // pinned staging of the wave's inputs (setup)
@@ -628,7 +635,7 @@ struct Wave {
     // 1: the step's read-back has landed, 0: not yet, -1: the device reported an error (sticky: the wave is failed, not polled forever)
     int ready()
     {
-        const hipError_t e = hipEventQuery(g.ev_hot);
+        const hipError_t e = hipEventQuery(g.ev_hot[rb_seen & 1]);
         if (e == hipSuccess) return 1;
         if (e == hipErrorNotReady) return 0;
         fail(RAFFT_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(e));
@@ -636,6 +643,7 @@ struct Wave {
     }
     std::chrono::steady_clock::time_point t_issued;      // when the running step was issued (the scheduler blocks on the oldest)
     int after_beam();
+    int issue_materialize(unsigned n_mat_known, unsigned n_mat_guess);
     // (every error exit of the two leaves `finished` and `result` set: the scheduler reads `result` of a finished wave, and a failure
     //  while the rows are gathered - a device error, a pinned allocation - must not be released as a batch-level success)
     int finish() { const int rc = finish_body(); if (rc) { finished = true; draining = false; if (!result) result = rc; } return rc; }
@@ -843,6 +851,19 @@ int Wave::setup()
     out_row_lds = ((size_t)maxL + 15) & ~(size_t)15;      // output_kernel builds a dot-bracket row in LDS: the longest sequence of the wave
     if (const char *e = getenv("RAFFT_DEDUPE_PER_CU")) dedupe_per_cu = (unsigned)std::max(1, atoi(e));
     n_active = (unsigned)S;
+    {
+        // step-ahead (RAFFT_STEP_AHEAD=0: lock-step as in rounds 1-4): needs the kernel that takes the device's own count
+        // (materialize_team_kernel: short productive-region lists, no phase stamps), and no per-step diagnostics that read counters back
+        // MEASURED AND LEFT OFF (round 5, tools/ab_stepahead.sh, tools/single_probe.py): the host's round trip is not what a folding step
+        // waits for.  One synchronous call on the benchmark batch takes 9.8-10.9 ms either way (it is bound by its kernels), the
+        // pipelined rate falls 3 % (an empty step per wave, guessed grids), and a lone 76-nt sequence takes 1.07 ms instead of 0.91
+        // (its 6 steps cost ~150 us each on the DEVICE - eight dependent kernels at ~20 us of dispatch latency - and step-ahead
+        // adds a seventh).  RAFFT_STEP_AHEAD=1 switches it on.
+        static const bool on = getenv("RAFFT_STEP_AHEAD") && atoi(getenv("RAFFT_STEP_AHEAD")) != 0;
+        static const bool mat4_on = !(getenv("RAFFT_MAT4") && atoi(getenv("RAFFT_MAT4")) == 0);
+        const bool tracing = getenv("RAFFT_TRACE") && atoi(getenv("RAFFT_TRACE")) >= 2;
+        step_ahead = on && mat4_on && !seam && !tracing && d.prof_e == nullptr && d.max_prod <= MAT4_PROD && getenv("RAFFT_TEST_OVF_AT") == nullptr;
+    }
     ms_setup = since(tw0);
     if (getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] setup: encode %.3f ms, plan+buffers %.3f ms, copies+init %.3f ms\n", ms_enc, ms_plan - ms_enc, ms_setup - ms_plan);
     tw1 = std::chrono::steady_clock::now();
@@ -882,8 +903,8 @@ int Wave::issue_step()
         unsigned grid = cls >= NGEN ? (unsigned)::g.n_cu * small_wg_per_cu : (unsigned)cf[cls].grid;
         static const unsigned c1_wgs = getenv("RAFFT_C1_WGS") ? (unsigned)atoi(getenv("RAFFT_C1_WGS")) : 0u;     // A/B: fewer workgroups of the one-wavefront class
         if (cls == 1 && c1_wgs && cf[1].wpb > 1) grid = std::min(grid, c1_wgs * (unsigned)cf[1].wpb);
-        if (steps > 0) {
-            const unsigned long long bound = (unsigned long long)last_mat * (cls == 1 ? 8ULL : 4ULL) + 32ULL;
+        if (steps > 0 && !(step_ahead && steps < 3)) {       // (step-ahead: `last_mat` is the step before's - doubled; the first steps grow faster)
+            const unsigned long long bound = (unsigned long long)last_mat * (step_ahead ? 2ULL : 1ULL) * (cls == 1 ? 8ULL : 4ULL) + 32ULL;
             if (bound < grid) grid = (unsigned)bound;
         }
         if (int rc = launch_expand_cls(d, cls, cf, grid, cs)) return rc;
@@ -921,9 +942,45 @@ int Wave::issue_step()
         spans.push_back(sp);
     }
     steps++;
-    HIPCHK(hipMemcpyAsync(g.hot, g.counters.p, hot_len, hipMemcpyDeviceToHost, st));   // pinned: truly asynchronous
-    HIPCHK(hipEventRecord(g.ev_hot, st));
+    HIPCHK(hipMemcpyAsync((char *)g.hot + 1024 * (rb_issued & 1), g.counters.p, hot_len, hipMemcpyDeviceToHost, st));   // pinned: truly asynchronous
+    HIPCHK(hipEventRecord(g.ev_hot[rb_issued & 1], st));
+    rb_issued++;
     t_issued = std::chrono::steady_clock::now();
+    return 0;
+}
+
+// materialize the new beam members of the step whose beam step is queued or done, and find the loops among their regions that
+// are known already.  `n_mat_known`: the step's count when its counters have been read back, 0 when they have not (step-ahead mode:
+// the kernel takes the device's own counter and `n_mat_guess` only sizes its grid and chooses the size classes of the next step)
+int Wave::issue_materialize(unsigned n_mat_known, unsigned n_mat_guess)
+{
+    hipStream_t st = g.stream;
+    const unsigned nm = n_mat_known ? n_mat_known : n_mat_guess;
+    Span sp{next_event(), next_event(), 2};
+    SPAN_REC(sp.a, st, sp.kind);
+    // (four structures per wavefront, teams of 16 lanes, when the short productive-region lists are in use -
+    //  materialize_team_kernel; RAFFT_MAT4=0: one structure per wavefront)
+    static const bool mat4_on = !(getenv("RAFFT_MAT4") && atoi(getenv("RAFFT_MAT4")) == 0);
+    if (mat4_on && d.prof_e == nullptr && d.max_prod <= MAT4_PROD) {
+        const unsigned grid = n_mat_known ? (n_mat_known + MAT4_TEAMS - 1) / MAT4_TEAMS
+                                          : std::min<unsigned>((unsigned)((c.mat + MAT4_TEAMS - 1) / MAT4_TEAMS), std::max<unsigned>(64u, nm / 2u + 64u));
+        hipLaunchKernelGGL(materialize_team_kernel, dim3(grid), dim3(64), 0, st, d, n_mat_known ? (int)n_mat_known : -1);
+    }
+    else if (d.prof_e == nullptr) hipLaunchKernelGGL(materialize_kernel<true>, dim3(n_mat_known), dim3(MAT_NT), mat_lds, st, d);
+    else hipLaunchKernelGGL(materialize_kernel<false>, dim3(n_mat_known), dim3(MAT_NT), mat_lds, st, d);
+    HIPCHK(hipGetLastError());
+    // tail of the batch: so few new structures that their regions fit one wave of workgroups of the widest class
+    // (measured on the benchmark batch: 18.8 -> 17.3 ms; thresholds in new structures per step, per CU)
+    // (round 3, after the 256-thread class got its production build and four workgroups per CU: everything goes to the widest
+    //  class only below 2 structures per CU - 16 per CU before; a burst of 20 shard batches 18.5 -> 17.8 ms, the rest unchanged)
+    const unsigned merge_below = getenv("RAFFT_MERGE_BELOW") ? (unsigned)atoi(getenv("RAFFT_MERGE_BELOW")) : 2u * (unsigned)::g.n_cu;
+    const unsigned merge2_below = getenv("RAFFT_MERGE2_BELOW") ? (unsigned)atoi(getenv("RAFFT_MERGE2_BELOW")) : 128u * (unsigned)::g.n_cu;
+    d.merge_cls = seam ? 0 : nm < merge_below ? merge_target : nm < merge2_below ? 2 : 0;
+    merged_now = d.merge_cls;
+    hipLaunchKernelGGL(dedupe_kernel, dim3(::g.n_cu * dedupe_per_cu), dim3(DEDUPE_NT), 0, st, d);
+    HIPCHK(hipGetLastError());
+    SPAN_REC(sp.b, st, sp.kind);
+    spans.push_back(sp);
     return 0;
 }
 
@@ -935,7 +992,8 @@ int Wave::after_beam()
     hipStream_t st = g.stream;
     if (draining) return finish_done();            // the last rows have landed
     const size_t hot_len = offsetof(Counters, node);
-    memcpy(&hc, g.hot, hot_len);
+    memcpy(&hc, (const char *)g.hot + 1024 * (rb_seen & 1), hot_len);
+    rb_seen++;
     if (hc.overflow) { ovf = hc.overflow; return finish(); }
     // test hook: pretend an arena overflowed at this step of the first attempt (regrowth late in a wave)
     if (const char *e = getenv("RAFFT_TEST_OVF_AT")) if (depth == 0 && steps == atoi(e)) { ovf = OVF_STRUCT; return finish(); }
@@ -946,30 +1004,9 @@ int Wave::after_beam()
     // are queued (below): the host's share of it, a millisecond or two for a wave of 16 k sequences, is off the wave's own path
     const bool harvest_now = !p.traj && !seam && !harvested && S >= 256 && (size_t)hc.trec_n * 10 >= S * 7 && getenv("RAFFT_NO_HARVEST") == nullptr;
     const size_t harvest_n = (size_t)hc.trec_n;
-    {
-        Span sp{next_event(), next_event(), 2};
-        SPAN_REC(sp.a, st, sp.kind);
-        // (four structures per wavefront, teams of 16 lanes, when the short productive-region lists are in use -
-        //  materialize_team_kernel; RAFFT_MAT4=0: one structure per wavefront)
-        static const bool mat4_on = !(getenv("RAFFT_MAT4") && atoi(getenv("RAFFT_MAT4")) == 0);
-        if (mat4_on && d.prof_e == nullptr && d.max_prod <= MAT4_PROD)
-            hipLaunchKernelGGL(materialize_team_kernel, dim3((hc.n_mat + MAT4_TEAMS - 1) / MAT4_TEAMS), dim3(64), 0, st, d, (int)hc.n_mat);
-        else if (d.prof_e == nullptr) hipLaunchKernelGGL(materialize_kernel<true>, dim3(hc.n_mat), dim3(MAT_NT), mat_lds, st, d);
-        else hipLaunchKernelGGL(materialize_kernel<false>, dim3(hc.n_mat), dim3(MAT_NT), mat_lds, st, d);
-        HIPCHK(hipGetLastError());
-        // tail of the batch: so few new structures that their regions fit one wave of workgroups of the widest class
-        // (measured on the benchmark batch: 18.8 -> 17.3 ms; thresholds in new structures per step, per CU)
-        // (round 3, after the 256-thread class got its production build and four workgroups per CU: everything goes to the widest
-        //  class only below 2 structures per CU - 16 per CU before; a burst of 20 shard batches 18.5 -> 17.8 ms, the rest unchanged)
-        const unsigned merge_below = getenv("RAFFT_MERGE_BELOW") ? (unsigned)atoi(getenv("RAFFT_MERGE_BELOW")) : 2u * (unsigned)::g.n_cu;
-        const unsigned merge2_below = getenv("RAFFT_MERGE2_BELOW") ? (unsigned)atoi(getenv("RAFFT_MERGE2_BELOW")) : 128u * (unsigned)::g.n_cu;
-        d.merge_cls = seam ? 0 : hc.n_mat < merge_below ? merge_target : hc.n_mat < merge2_below ? 2 : 0;
-        merged_now = d.merge_cls;
-        hipLaunchKernelGGL(dedupe_kernel, dim3(::g.n_cu * dedupe_per_cu), dim3(DEDUPE_NT), 0, st, d);
-        HIPCHK(hipGetLastError());
-        SPAN_REC(sp.b, st, sp.kind);
-        spans.push_back(sp);
-    }
+    // step-ahead mode: this step's materialize and the next folding step are queued already (when the step before was looked at);
+    // what is issued now is the materialize of the step in flight and the folding step after it, sized by this step's counters
+    if (int rc = issue_materialize(step_ahead ? 0u : hc.n_mat, hc.n_mat)) return rc;
     if (const char *tr = getenv("RAFFT_TRACE")) if (atoi(tr) >= 2) {
         Counters h2;
         HIPCHK(hipMemcpyAsync(&h2, g.counters.p, hot_len, hipMemcpyDeviceToHost, st));
@@ -1072,7 +1109,9 @@ int Wave::finish_body()
     finished = true;
     const double ms_loop = ms_loop_ = since(tw1);
     auto tw2 = tw2_ = std::chrono::steady_clock::now();
-    bt.stats.n_steps = std::max<int64_t>(bt.stats.n_steps, steps);
+    bt.stats.n_steps = std::max<int64_t>(bt.stats.n_steps, step_ahead ? rb_seen : steps);
+    // (step-ahead: the step queued behind the last read-back has nothing to do - every sequence is done, no work list holds anything -
+    //  and touches none of the counters and records read below)
     if (ovf && getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] wave S=%zu est %.1f overflowed (bits %u) after %d steps, %.1f ms\n", S, est, ovf, steps, since(tw0));
     if (ovf) {
         HIPCHK(hipStreamSynchronize(st));
@@ -1138,7 +1177,10 @@ int Wave::finish_body()
         HIPCHK(hipEventRecord(g.ev_copy, g.copy_stream));
         HIPCHK(hipStreamWaitEvent(st, g.ev_copy, 0));
     }
-    HIPCHK(hipEventRecord(g.ev_hot, st));
+    // (a step queued ahead of the last read-back has nothing to do - every sequence is done - and its read-back is never looked at)
+    rb_seen = rb_issued;
+    HIPCHK(hipEventRecord(g.ev_hot[rb_issued & 1], st));
+    rb_issued++;
     finished = false; draining = true;
     (void)ms_loop;
     return 0;
@@ -1450,6 +1492,8 @@ static void scheduler_main()
     };
     bool big_prod_seen = false;               // a wave with `big_prod_params` met a structure with more productive regions than the short lists hold
     rafft_params big_prod_params{};
+    int big_prod_quiet = 0;                   // ... and this many waves in a row since then, folded with the long lists, never needed them:
+                                              // after eight the short lists are back (one outlier batch does not slow the process for good)
     auto last_progress = std::chrono::steady_clock::now();
     for (;;) {
         {
@@ -1510,7 +1554,7 @@ static void scheduler_main()
                             sl.job.big_prod = true;
                             sl.job.members[0]->stats.n_regrows_prod++;
                             // sticky: later waves with these parameters start with the long lists instead of paying the double fold again
-                            big_prod_seen = true; big_prod_params = sl.job.members[0]->p;
+                            big_prod_seen = true; big_prod_params = sl.job.members[0]->p; big_prod_quiet = 0;
                         }
                         else sl.job.est *= (sl.job.depth >= 2 ? 4.0 : 2.0);
                         sl.job.depth++;
@@ -1521,8 +1565,16 @@ static void scheduler_main()
                     { hipError_t e_ = hipDeviceSynchronize(); (void)e_; }
                     sl.wave.reset();
                     fail_or_split(sl, rc, err, queue);
-                } else
+                } else {
+                    if (sl.wave->big_prod && !sl.job.members.empty()) {
+                        sl.job.members[0]->stats.n_waves_long_lists++;
+                        if (!sl.job.big_prod && big_prod_seen) {       // the long lists came from the sticky flag, not from this job's own overflow
+                            if (sl.wave->hc.max_nprod <= MAX_PROD) { if (++big_prod_quiet >= 8) { big_prod_seen = false; big_prod_quiet = 0; } }
+                            else big_prod_quiet = 0;
+                        }
+                    }
                     release(sl.job, 0, "");
+                }
                 sl.wave.reset();
             } else if (rc) {
                 const std::string err = g_err;
@@ -1575,12 +1627,16 @@ static void scheduler_main()
                 // continuous batching: queued jobs with the same parameters join this one (first regrowths stay alone)
                 Job job = std::move(front);
                 queue[ln].pop_front();
+                // (a sequence beyond 16 384 nt makes the class for the biggest regions plan for 32 768 positions, which lowers the
+                //  wave's nb_mode limit from ~400 to 106 - class_cfg: jobs are not merged across that line)
+                auto very_long = [](const Job &j) { for (auto &sq : j.seqs) if (sq.len > 16384) return true; return false; };
+                const bool job_vl = very_long(job);
                 while (job.depth == 0 && !job.no_merge && !queue[ln].empty()) {
                     Job &nx = queue[ln].front();
                     bool nx_failed = false;
                     for (auto &m : nx.members) nx_failed = nx_failed || m->rc != 0;
                     if (nx.depth != 0 || nx.no_merge || nx_failed || !same_params(nx.members[0]->p, job.members[0]->p) ||
-                        job.seqs.size() + nx.seqs.size() > merge_cap())
+                        job.seqs.size() + nx.seqs.size() > merge_cap() || very_long(nx) != job_vl)
                         break;
                     const int off = (int)job.members.size();
                     for (SeqIn sq : nx.seqs) { sq.bi += off; job.seqs.push_back(sq); }
@@ -1626,6 +1682,12 @@ static void scheduler_main()
                     sl.wave->big_prod = sl.job.big_prod || (big_prod_seen && same_params(big_prod_params, sl.job.members[0]->p));
                     rc = sl.wave->setup();
                     if (!rc) rc = sl.wave->issue_step();
+                    // step-ahead: the materialize of the first step and the second step are queued at once (counts from the device,
+                    // no size class merged away: the first steps are the big ones)
+                    if (!rc && sl.wave->step_ahead) {
+                        rc = sl.wave->issue_materialize(0u, 0x7fffffffu);
+                        if (!rc) rc = sl.wave->issue_step();
+                    }
                 }
                 progressed = true;
                 if (rc) {

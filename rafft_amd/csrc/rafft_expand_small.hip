@@ -76,6 +76,7 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
     unsigned long long *ck = (unsigned long long *)(lds + LY::off_ck);
     double *val = (double *)(lds + LY::off_val);
 
+    if (d.c->overflow) return;                    // (an arena overflowed earlier in this wave: see expand_kernel)
     const unsigned n_items = d.c->n_work[cls].v;
     if (diag == 3) return;
     const unsigned gw = blockIdx.x * SM_WG_WAVES + wv, n_waves = gridDim.x * SM_WG_WAVES;

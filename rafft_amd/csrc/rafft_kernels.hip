@@ -340,6 +340,9 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
         int tp = pair_type(a, b);
         wtab[tid] = (tp == 5 || tp == 6) ? d.au : (tp == 1 || tp == 2) ? d.gc : (tp == 3 || tp == 4) ? d.gu : 0.0;
     }
+    // an arena overflowed in an earlier kernel of this wave: the host regrows and folds the wave again, whatever is queued behind
+    // that kernel (the host issues a step ahead of its read-backs) finds records that were never written - and does nothing
+    if (d.c->overflow) return;
     const unsigned n_items = d.c->n_work[cls].v;
     if (gteam == 0 && tid == 0) d.c->n_mat = 0;                // the beam step that follows counts its new structures here
     // (class 3 is served by two kernels on one work list: the list's length says which of them works - launch_expand_cls)
@@ -2175,7 +2178,12 @@ __global__ __launch_bounds__(64, RAFFT_MAT_WAVES) void materialize_team_kernel(D
     int *ps = ps_[team], *bs = bs_[team], *ns = ns_[team];
     const int tb = team * MAT4_TL;                       // first lane of my team
     const unsigned long long tmask = ((1ULL << MAT4_TL) - 1ULL) << tb;
-    const int mat_i = blockIdx.x * MAT4_TEAMS + team;
+    // (round 5) n_mat < 0: the count is the device's own (the beam step's counter) and the grid whatever the host guessed - it issues
+    // this kernel before it has read the step's counters back; the workgroups stride over the list
+    if (d.c->overflow) return;                           // (see expand_kernel)
+    if (n_mat < 0) n_mat = (int)d.c->n_mat;
+    for (int mat_i0 = blockIdx.x * MAT4_TEAMS; mat_i0 < n_mat; mat_i0 += gridDim.x * MAT4_TEAMS) {
+    const int mat_i = mat_i0 + team;
     const bool live = mat_i < n_mat;
     MatRec rec;
     rec.sid = 0; rec.sq = 0; rec.L = 0; rec.dcal = 0; rec.nprod = 0; rec.combo = 0; rec.prod = 0; rec.pad2 = 0;
@@ -2347,6 +2355,8 @@ __global__ __launch_bounds__(64, RAFFT_MAT_WAVES) void materialize_team_kernel(D
         wave_sync();
     }
     if (ok && tl == 0) { d.st[sid].node0 = (int)lbase; d.st[sid].nnodes = tot_nodes; d.st[sid].sp = sbase; d.st[sid].nsp = tot_sp; }
+    wave_sync();
+    }
 }
 
 // ------------------------------------------------------------ dedupe kernel

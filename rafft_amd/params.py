@@ -98,6 +98,13 @@ def ensure_default_params():
     _auto_done = True
     env = os.environ.get("RAFFT_PARAMS")
     if env:
-        load_params(env)
+        # a parameter file that was asked for and cannot be read is an error at EVERY fold - never a silent fall back to the built-in
+        # tables (whose unexercised entries are rule / model values: the caller asked for ViennaRNA's own)
+        try:
+            load_params(env)
+        except Exception as e:
+            _auto_done = False
+            raise RuntimeError(f"RAFFT_PARAMS={env!r}: the parameter file could not be loaded ({e}); unset RAFFT_PARAMS to fold with "
+                               "the built-in 37 C tables") from e
     elif os.environ.get("RAFFT_NO_VIENNARNA") is None:
         load_params_from_viennarna()

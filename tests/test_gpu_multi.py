@@ -56,6 +56,27 @@ def _check_two_rank_line(out):
     assert out["config"]["sequences_per_step"] == 2 * 2296 and 2000 < out["config"]["sequences_on_rank0"] < 2600
     assert out["sharded_parity"] == {"sequences": 2 * 2296, "final_beam_identical_to_single_gpu_fold": 2 * 2296}
     assert out["strong_sharded_value"] > 0 and out["roofline"]["frac"] > 0
+    # (round 5) the N > 1 line explains itself: weak and strong figures under their own names with their step counts, and what the
+    # process group really was - ranks seen, the device of each (here both ranks share the one card), sequences and elapsed time by rank
+    assert out["weak_value"] == out["value"] and out["weak_steps"] == 4 and out["weak_sequences_per_step"] == 2 * 2296
+    assert out["strong_value"] == out["strong_sharded_value"] and out["strong_steps"] == 4 and out["strong_sequences_per_step"] == 2296
+    rk = out["ranks"]
+    assert rk["world_size_seen"] == 2 and rk["distinct_devices"] == 1 and rk["device_ordinals"] == [0, 0]
+    assert sum(rk["sequences_per_step_by_rank"]) == 2 * 2296 and len(rk["elapsed_s_by_rank"]) == 2
+    assert rk["elapsed_s_min"] <= rk["elapsed_s_mean"] <= rk["elapsed_s_max"] <= rk["elapsed_s_with_barrier_max_over_ranks"] + 1e-3
+
+
+def test_bench_self_launch_ends_the_run_when_a_rank_dies(tmp_path):
+    """a rank that dies at start-up ends the whole run at once with a non-zero exit (its siblings are terminated instead of sitting in the
+    rendezvous until the process group's timeout) and its stderr is shown"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(BENCH_SAME_GPU="1", BENCH_BACKEND="gloo", BENCH_SKIP_CFG4="1", BENCH_TEST_DIE_RANK="1", BENCH_LAUNCH_TIMEOUT_S="120")
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "ranks failed" in r.stderr and "BENCH_TEST_DIE_RANK" in r.stderr
+    assert time.time() - t0 < 100
 
 
 def test_gpu_bench_two_ranks_sharded_mode():

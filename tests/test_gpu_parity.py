@@ -343,6 +343,14 @@ def test_gpu_more_productive_regions_than_the_short_lists_hold(monkeypatch):
     assert st["n_regrows"] >= 1 and st["n_regrows_prod"] >= 1
     again = [as_lists(t) for _, t in rafft_amd.fold_batch(seqs, 100, 8, 1000, traj=True)]
     assert rafft_amd.last_stats()["n_regrows"] == 0
+    assert rafft_amd.last_stats()["n_waves_long_lists"] >= 1          # ... and the library says so
     monkeypatch.delenv("RAFFT_TEST_MAX_PROD")
     assert got == want and again == want
+    # the flag decays: eight waves in a row that never needed the long lists, and the short ones (and the four-structures-per-
+    # wavefront materialize kernel with them) are back - one outlier batch does not slow a process down for good
+    n_long = 0
+    for _ in range(10):
+        assert [as_lists(t) for _, t in rafft_amd.fold_batch(seqs, 100, 8, 1000, traj=True)] == want
+        n_long += rafft_amd.last_stats()["n_waves_long_lists"]
+    assert 6 <= n_long < 20 and rafft_amd.last_stats()["n_waves_long_lists"] == 0      # (the fold above was the first of the eight)
     _native.lib().rafft_shutdown()

@@ -33,7 +33,7 @@ def test_cabi_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(_native.Params) == 4 * 4 + 8 + 4 + 4 + 8 + 3 * 8
     assert ctypes.sizeof(_native.SeqResult) == 16 + 4 * 8
-    assert ctypes.sizeof(_native.Stats) == 9 * 8 + 23 * 8
+    assert ctypes.sizeof(_native.Stats) == 9 * 8 + 24 * 8
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -153,6 +153,25 @@ def test_viennarna_is_touched_once_up_front(synthetic_par, monkeypatch):
     assert not params.params_info()["has_enthalpies"]
 
 
+def test_unreadable_parameter_file_is_an_error_at_every_fold(monkeypatch, tmp_path):
+    """RAFFT_PARAMS names a file that is missing or malformed: every fold fails loudly - never a silent fall back to the built-in
+    tables (whose unexercised entries are rule / model values; the caller asked for ViennaRNA's own, rafft/utils.py:17-21)"""
+    params.reset_params()
+    bad = tmp_path / "broken.par"
+    bad.write_text("## RNAfold parameter file v2.0\n\n# stack\n 1 2 x3\n")
+    for target in (str(tmp_path / "missing.par"), str(bad)):
+        monkeypatch.setenv("RAFFT_PARAMS", target)
+        monkeypatch.setattr(params, "_auto_done", False)
+        for _ in range(2):                       # the second call fails like the first
+            with pytest.raises(RuntimeError, match="RAFFT_PARAMS"):
+                params.ensure_default_params()
+        assert not params.params_info()["has_enthalpies"]       # nothing was loaded
+    monkeypatch.delenv("RAFFT_PARAMS")
+    monkeypatch.setenv("RAFFT_NO_VIENNARNA", "1")
+    monkeypatch.setattr(params, "_auto_done", False)
+    params.ensure_default_params()               # without the variable: the built-in set, as before
+
+
 def test_other_temperature_needs_enthalpies():
     """the built-in tables are 37 C only: any other temp is an error, never silently 37 C energies"""
     params.reset_params()

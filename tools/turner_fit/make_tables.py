@@ -43,8 +43,10 @@ def halfunit_int22(th, cnt, rule="up", lam=0.3, sweeps=8):
     mismatches): value = round10(H[t1][a][d] + H[t2][c][b] + D[{mismatch 1, mismatch 2}]) with H in units of 5 dcal (half of a
     value given to 0.1 kcal/mol) and halves rounded up.  Least squares on the pinned entries, snapped to the 5-dcal grid, then
     coordinate descent on the number of pinned entries reproduced exactly.  Against the additive model of round 2 (no D, no
-    half units): 5-fold hold-out over the pinned ENTRIES 18.6 % -> 68.5 % exact, mean error 25 -> 7 dcal; rounding halves
-    down 68.1 %, away from zero 63.4 %, to even 55.9 % (tools/turner_fit/int22_models.py)."""
+    half units): 5-fold hold-out over the pinned ENTRIES (tools/turner_fit/int22_models.py -> profiles/r05_int22_models.json,
+    round 5: the script round 4 quoted was not kept; this is the comparison again, by-entry folds, seed 0) additive 19.0 % exact
+    (mean error 26 dcal), half units rounded up 65.9 % (9 dcal), down 69.2 %, away from zero 61.3 %, to even 56.1 % - round 4 had
+    18.6 / 68.5 / 68.1 / 63.4 / 55.9 from its own split: up and down are within the spread of the split, the tables keep `up`."""
     import math
 
     def params_of(k):
