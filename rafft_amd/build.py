@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libraffthip.so")
-SOURCES = ["rafft_api.hip", "rafft_kernels.hip", "rafft_expand_small.hip", "rafft_kin.hip", "rafft_kernels.h", "rafft_device.h", "rafft_params.h", "../../params/turner2004_tables.h"]
+SOURCES = ["rafft_api.hip", "rafft_kernels.hip", "rafft_expand_small.hip", "rafft_kin.hip", "rafft_kernels.h", "rafft_device.h", "rafft_params.h", "rafft_config.h", "../../params/turner2004_tables.h"]
 
 
 def needs_build():

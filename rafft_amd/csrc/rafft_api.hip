@@ -8,6 +8,7 @@
 #include "../../include/rafft_hip.h"
 #include "rafft_kernels.h"
 #include "rafft_params.h"
+#include "rafft_config.h"
 
 #include <algorithm>
 #include <atomic>
@@ -113,6 +114,8 @@ struct Ctx {
     int n_inflight = 0;                // batches submitted and not yet finished
     bool last_submit_async = false;    // under qmu: the last batch came through rafft_fold_submit (its caller may be about to queue more)
     std::chrono::steady_clock::time_point t_last_submit{};   // under qmu: when the last batch was queued (the scheduler lingers on a stream of them)
+    Config proc_cfg;                   // read at rafft_init: the process-wide switches (rafft_config.h)
+    Config sched_cfg;                  // read when the scheduler thread starts: its own settings
     bool sched_started = false;
     bool stop = false;                 // under qmu: the process is exiting (rafft_shutdown): the scheduler thread returns
     std::thread sched_thread;
@@ -150,8 +153,8 @@ int ensure(Buf &b, size_t bytes)
         unsigned long long w = g_dev_worst_us.load();
         while (us > w && !g_dev_worst_us.compare_exchange_weak(w, us)) { }
     }
-    if (getenv("RAFFT_TRACE_ALLOC")) fprintf(stderr, "[rafft] ptr %p (mod 2MiB %zu KiB) ", b.p, ((size_t)(uintptr_t)b.p & (((size_t)2 << 20) - 1)) >> 10);
-    if (getenv("RAFFT_TRACE_ALLOC")) fprintf(stderr, "[rafft] t=%.3f device buffer -> %.1f MB in %.3f ms\n", std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(), (double)want / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count());
+    if (g.proc_cfg.trace_alloc) fprintf(stderr, "[rafft] ptr %p (mod 2MiB %zu KiB) ", b.p, ((size_t)(uintptr_t)b.p & (((size_t)2 << 20) - 1)) >> 10);
+    if (g.proc_cfg.trace_alloc) fprintf(stderr, "[rafft] t=%.3f device buffer -> %.1f MB in %.3f ms\n", std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(), (double)want / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count());
     if (e != hipSuccess) {
         b.p = nullptr;
         return fail(RAFFT_ERR_HIP, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
@@ -189,7 +192,7 @@ int init_ws(Workspace &w)
     // the long tail high 15.4 ms.)  RAFFT_PRIO=0 switches priorities off.
     int plo = 0, phi = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&plo, &phi));
-    const int prio_mode = getenv("RAFFT_PRIO") ? atoi(getenv("RAFFT_PRIO")) : 1;
+    const int prio_mode = g.proc_cfg.prio;
     const int idx = (int)(&w - g.ws);
     const int prio = prio_mode == 0 ? 0 : idx == 1 ? (prio_mode > 0 ? phi : plo) : idx == 3 ? (prio_mode > 0 ? plo : phi) : 0;
     HIPCHK(hipStreamCreateWithPriority(&w.stream, hipStreamNonBlocking, prio));
@@ -213,6 +216,7 @@ int init_ctx(int device)
         HIPCHK(hipSetDevice(g.device));    // HIP's current device is per host thread: bind it on every entry
         return 0;
     }
+    g.proc_cfg = read_config();
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0)
@@ -244,34 +248,34 @@ struct ClsCfg { int nt, Pmax, Lmax, nmax, brmax, Kmax, lds, grid; bool tab; int 
 // limits of the one-wavefront class: its LDS per wavefront (hence its occupancy) follows from them
 // (not below 256: the kernel addresses the staged bases through a pointer shifted back by up to 4095 positions, which must stay
 //  inside the LDS - the 16 * P bytes in front of that area see to it)
-static int cls1_P() { static const int v = getenv("RAFFT_CLS1_P") ? std::max(256, std::min(next_pow2_ge(atoi(getenv("RAFFT_CLS1_P"))), CLS1_P)) : CLS1_P; return v; }
-static int cls1_br() { return std::min(CLS1_BR, (8 * cls1_P() - 16) / 10 - 1); }
+static int cls1_P(const Config &cfg) { return std::max(256, std::min(next_pow2_ge(cfg.cls1_p), CLS1_P)); }
+static int cls1_br(const Config &cfg) { return std::min(CLS1_BR, (8 * cls1_P(cfg) - 16) / 10 - 1); }
 
 // `nofft1`: the one-wavefront class correlates every region by popcounts (production mode: no seam, no forced FFT, no negative
 // weights, Dev::direct_n >= 256): its FFT buffers and twiddles go, its branch lists shrink to 128 entries, and a workgroup of twelve
 // wavefronts leaves ~32 KiB of a CU's LDS - room for a workgroup of the small-region kernel beside it.
 // `nofft2`: the same for the 256-thread class when Dev::direct_n covers all of its regions (<= 1024 positions): 46 -> 39 KiB, four
 // workgroups per CU instead of three.
-int class_cfg(int K, int maxL, ClsCfg out[NGEN + 1], bool nofft1 = false, bool nofft2 = false, bool direct3_ok = false)
+int class_cfg(const Config &cfg, int K, int maxL, ClsCfg out[NGEN + 1], bool nofft1 = false, bool nofft2 = false, bool direct3_ok = false)
 {
     // sequences longer than LDS_SEQ: classes 2 and 3 read the bases of a loop from HBM/L2 (no LDS copy), class 0 takes the
     // regions whose FFT would not fit
     const bool longseq = maxL > LDS_SEQ;
-    const int P[NGEN] = {CLS0_P, cls1_P(), CLS2_P, MAX_P}, LM[NGEN] = {0, CLS01_L, longseq ? 0 : LDS_SEQ, longseq ? 0 : LDS_SEQ};
-    const int NT[NGEN] = {512, 64, getenv("RAFFT_NT2") ? atoi(getenv("RAFFT_NT2")) : 256, 512}, BR[NGEN] = {BIG_BR + 1, nofft1 ? 128 : cls1_br(), MAX_BR, MAX_BR};
+    const int P[NGEN] = {CLS0_P, cls1_P(cfg), CLS2_P, MAX_P}, LM[NGEN] = {0, CLS01_L, longseq ? 0 : LDS_SEQ, longseq ? 0 : LDS_SEQ};
+    const int NT[NGEN] = {512, 64, cfg.nt2, 512}, BR[NGEN] = {BIG_BR + 1, nofft1 ? 128 : cls1_br(cfg), MAX_BR, MAX_BR};
     // class 0 (tiny regions in their own kernel) is kept compiled for experiments but receives no work (see node_class)
-    const int tabm = getenv("RAFFT_TAB") ? atoi(getenv("RAFFT_TAB")) : 0;      // bit c: energy tables of class c in LDS
+    const int tabm = cfg.tab;      // bit c: energy tables of class c in LDS
     // The one-wavefront class packs 12 wavefronts - what a CU holds of them anyway - into one workgroup that shares ONE LDS
     // copy of the energy tables and twiddles: the table look-ups of the dE phase stop being dependent L2 round trips
     // (measured: 5.9 -> 5.4 ms per benchmark batch in this kernel; with 4 or 8 per workgroup a CU holds fewer wavefronts
     // and loses more than it gains).  Falls back to one wavefront per workgroup, tables in L2, when nb_mode makes the
     // per-wavefront arrays too big for 12 to fit.  RAFFT_WPB=1/4/12 overrides.
-    int wpb1 = getenv("RAFFT_WPB") ? atoi(getenv("RAFFT_WPB")) : (nofft1 ? 16 : 12);
+    int wpb1 = cfg.wpb ? cfg.wpb : (nofft1 ? 16 : 12);
     if (!(wpb1 == 4 || wpb1 == 12 || (wpb1 == 16 && nofft1))) wpb1 = 1;
     if (wpb1 > 1) {
-        const int Kmax1 = std::max(1, std::min(K, cls1_P() - 1));
-        if (wpb1 == 16 && expand_lds(cls1_P(), CLS01_L, cls1_P() / 2, BR[1], Kmax1, true, wpb1, nofft1, 64).total > 160 * 1024) wpb1 = 12;
-        if (expand_lds(cls1_P(), CLS01_L, cls1_P() / 2, BR[1], Kmax1, true, wpb1, nofft1, 64).total > 160 * 1024) wpb1 = 1;
+        const int Kmax1 = std::max(1, std::min(K, cls1_P(cfg) - 1));
+        if (wpb1 == 16 && expand_lds(cls1_P(cfg), CLS01_L, cls1_P(cfg) / 2, BR[1], Kmax1, true, wpb1, nofft1, 64).total > 160 * 1024) wpb1 = 12;
+        if (expand_lds(cls1_P(cfg), CLS01_L, cls1_P(cfg) / 2, BR[1], Kmax1, true, wpb1, nofft1, 64).total > 160 * 1024) wpb1 = 1;
     }
     const int WPB[NGEN] = {1, wpb1, 1, 1};
     const bool TAB[NGEN] = {false, (tabm & 2) != 0 || WPB[1] > 1, (tabm & 4) != 0, false};    // (LDS tables come with LDS twiddles: FFT sizes <= CLS2_P only)
@@ -294,7 +298,7 @@ int class_cfg(int K, int maxL, ClsCfg out[NGEN + 1], bool nofft1 = false, bool n
         if (c >= 1 && LM[c] > 0 && l.off_S < LDS_SEQ)      // (expand_kernel's Sl: the staged bases are addressed by sequence position)
             return fail(RAFFT_ERR_PARAM, "internal: the LDS copy of the bases sits too low for its shifted pointer");
         int per_cu = std::max(1, std::min(32 / (NT[c] / 64), WPB[c] * ((160 * 1024) / l.total)));      // teams per CU
-        if (c == 1 && getenv("RAFFT_C1_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(getenv("RAFFT_C1_PER_CU"))));
+        if (c == 1 && cfg.c1_per_cu > 0) per_cu = std::max(1, std::min(per_cu, cfg.c1_per_cu));
         out[c] = {NT[c], P[c], LM[c], nmax, BR[c], Kmax, l.total, g.n_cu * per_cu, TAB[c], WPB[c], nf};
         // a size class that no region of this batch can reach need not fit (class 3 needs n > 1024, class 0 n > 4096)
         const bool reachable = c == 0 ? longseq : (c < 3 || maxL > CLS2_P / 2);
@@ -310,7 +314,7 @@ int class_cfg(int K, int maxL, ClsCfg out[NGEN + 1], bool nofft1 = false, bool n
     // (measured on the configs[3] shard: 202 -> 177 ms per call, the class itself 93 -> 66 ms - its regions cost 330 kcycles each at
     //  three workgroups per CU against 182 at one; the benchmark set, whose two 23S sequences are all it has of such regions, is
     //  unchanged.  RAFFT_C3_DIRECT=0: the FFT plan; read at every call, tests switch it.)
-    const int c3_direct = getenv("RAFFT_C3_DIRECT") ? atoi(getenv("RAFFT_C3_DIRECT")) : 1;
+    const int c3_direct = cfg.c3_direct;
     if (c3_direct && direct3_ok && !longseq) {
         const int Kmax = std::max(1, std::min(K, MAX_P - 1)), nmax = MAX_P / 2, Pd = 2048;
         // (256 threads: at the 168 VGPRs the kernel needs without spilling a SIMD holds three wavefronts - three 256-thread
@@ -341,11 +345,11 @@ int launch_expand(const Dev &d, int cls, const ClsCfg &cf, unsigned n_teams, hip
     return 0;
 }
 
-int launch_expand_cls(const Dev &d, int cls, const ClsCfg cf[NGEN + 1], unsigned n_blocks, hipStream_t st, bool dry = false)
+int launch_expand_cls(const Config &cfg, const Dev &d, int cls, const ClsCfg cf[NGEN + 1], unsigned n_blocks, hipStream_t st, bool dry = false)
 {
     if (cls >= NGEN) {        // small regions: teams of 16 / 32 lanes, four wavefronts per workgroup (n_blocks = workgroups)
-        const int arg = cls | ((getenv("RAFFT_SMALL_DIAG") ? atoi(getenv("RAFFT_SMALL_DIAG")) : 0) << 8);
-        const bool prod_ok = !(getenv("RAFFT_PROD") && atoi(getenv("RAFFT_PROD")) == 0);      // (read at every launch: tests switch it)
+        const int arg = cls | (cfg.small_diag << 8);
+        const bool prod_ok = cfg.prod != 0;
         const bool prod = prod_ok && arg == cls && d.prof_e == nullptr && d.dbg.lag == nullptr;      // no diagnostics asked for: the production build
         if (cls == 4 && prod) hipLaunchKernelGGL((expand_small_kernel<16, true>), dim3(n_blocks), dim3(64 * SM_WG_WAVES), small_lds_bytes<16>(), st, d, arg);
         else if (cls == 4) hipLaunchKernelGGL((expand_small_kernel<16, false>), dim3(n_blocks), dim3(64 * SM_WG_WAVES), small_lds_bytes<16>(), st, d, arg);
@@ -357,7 +361,7 @@ int launch_expand_cls(const Dev &d, int cls, const ClsCfg cf[NGEN + 1], unsigned
     const bool longseq = cf[2].Lmax == 0;          // (class_cfg: no LDS copy of the bases)
     const int nf = cls < NGEN && cf[cls].nofft ? 0x2000 : 0;
     // the production build of the classes without FFT buffers: no diagnostics of any kind asked for (RAFFT_PROD=0: the general build)
-    const bool prod_ok = !(getenv("RAFFT_PROD") && atoi(getenv("RAFFT_PROD")) == 0);      // (read at every launch: tests switch it)
+    const bool prod_ok = cfg.prod != 0;
     const bool nodiag = prod_ok && !dry && d.prof_e == nullptr && d.rep == 0 && d.dbg.lag == nullptr && !d.force_fft && d.gc >= 0.0 && d.au >= 0.0 && d.gu >= 0.0;
     const bool prod = nodiag && nf;
     if (cls == 0) return nodiag ? launch_expand<512, false, 1, 2, 2>(d, 0, cf[0], n_blocks, st) : launch_expand<512, false, 1, 2>(d, 0, cf[0], n_blocks, st);
@@ -367,7 +371,7 @@ int launch_expand_cls(const Dev &d, int cls, const ClsCfg cf[NGEN + 1], unsigned
         if (cf[1].wpb == 4) return launch_expand<64, true, 4>(d, 1, cf[1], n_blocks, st);
         if (cf[1].wpb == 16 && prod) return launch_expand<64, true, 16, 0, 1>(d, 1 | nf, cf[1], n_blocks, st);
         if (cf[1].wpb == 16) return launch_expand<64, true, 16>(d, 1 | (cf[1].nofft ? 0x2000 : 0), cf[1], n_blocks, st);
-        if (cf[1].wpb == 12) return launch_expand<64, true, 12>(d, (dry ? (0x101 | (std::max(0, atoi(getenv("RAFFT_TWICE")) - 2) << 9)) : 1) | (cf[1].nofft ? 0x2000 : 0), cf[1], n_blocks, st);
+        if (cf[1].wpb == 12) return launch_expand<64, true, 12>(d, (dry ? (0x101 | (std::max(0, cfg.twice - 2) << 9)) : 1) | (cf[1].nofft ? 0x2000 : 0), cf[1], n_blocks, st);
         return cf[1].tab ? launch_expand<64, true>(d, 1, cf[1], n_blocks, st) : launch_expand<64, false>(d, 1, cf[1], n_blocks, st);
     }
     if (cls == 2) {
@@ -423,7 +427,7 @@ struct Caps {
     bool capped;      // a table hit the limit of its 31-bit ids: the job is folded in halves when it has more than one sequence
 };
 
-Caps plan_caps(size_t S, size_t sumL, const rafft_params &p, double est)
+Caps plan_caps(const Config &cfg, size_t S, size_t sumL, const rafft_params &p, double est)
 {
     // Arena sizes from measured usage on the BASELINE workloads (benchmark set, L 28..2968, ms 50;
     // random L 100..3000, ms 200): per surviving structure about 2 + L/100 regions, 0.6 L region
@@ -447,13 +451,13 @@ Caps plan_caps(size_t S, size_t sumL, const rafft_params &p, double est)
     //  table stops growing with the regions it HAS.  Measured, tools/arena_probe.py, candidates per structure: 10-20 on the benchmark
     //  set, 200-nt and 40-nt random sequences, ms 50 and 400; 15 on L 100..3000 at ms 200 - where the line above plans 238 -; 46 at
     //  ms 1; 50 on G/C-only sequences of 600 nt; 59 and 95 on 2.9-knt and 8-knt sequences at ms 50 and 20)
-    const bool memo_on = p.min_nrj == 0.0 && !(getenv("RAFFT_NO_MEMO") && atoi(getenv("RAFFT_NO_MEMO")));
+    const bool memo_on = p.min_nrj == 0.0 && !cfg.no_memo;
     if (memo_on) c.cand = std::min(c.cand, (size_t)((double)c.st * (60.0 + avgL / 40.0)) + 4096);
     c.cand = std::max<size_t>(c.cand, (size_t)NSHARD * 16384);
     // (a child slot is named by 2 x candidate + side in 31 bits - the node lists hold -(slot + 1), rafft_kernels.h - so a wave has
     //  at most 2^30 candidate records; round 4's structure rows used to keep the byte budget of a wave below that by themselves)
     size_t cand_limit = ((size_t)1 << 30) - 4096;
-    if (const char *e = getenv("RAFFT_TEST_CAND_LIMIT")) cand_limit = std::min<size_t>(cand_limit, std::max<size_t>((size_t)atoll(e), (size_t)NSHARD * 16384));   // (tests: the split path on small jobs)
+    if (cfg.test_cand_limit > 0) cand_limit = std::min<size_t>(cand_limit, std::max<size_t>((size_t)cfg.test_cand_limit, (size_t)NSHARD * 16384));   // (tests: the split path on small jobs)
     if (c.cand > cand_limit) { c.cand = cand_limit; c.capped = true; }
     // accepted children per sequence ~ steps * min(max_branch, ...); regions double and old ones are dropped
     // (measured, ms 50, max_branch 1000, regions abandoned by rehashing included: the benchmark set's bulk uses 4.6 x est x
@@ -515,7 +519,7 @@ PinBuf pin_acquire(size_t bytes)
     const auto t0_ = std::chrono::steady_clock::now();
     if (hipHostMalloc(&b.p, want, hipHostMallocDefault) != hipSuccess) { b.p = nullptr; return b; }
     g_pin_allocs++; g_pin_bytes += want;
-    if (getenv("RAFFT_TRACE_ALLOC")) fprintf(stderr, "[rafft] t=%.3f pinned chunk %.1f MB in %.3f ms (pool %zu)\n", std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(), (double)want / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count(), g.pin_free.size());
+    if (g.proc_cfg.trace_alloc) fprintf(stderr, "[rafft] t=%.3f pinned chunk %.1f MB in %.3f ms (pool %zu)\n", std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(), (double)want / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count(), g.pin_free.size());
     b.cap = want;
     return b;
 }
@@ -529,7 +533,7 @@ void pin_release(PinBuf b)
     else {
         const auto t0_ = std::chrono::steady_clock::now();
         hipError_t e = hipHostFree(b.p); (void)e;
-        if (getenv("RAFFT_TRACE_ALLOC")) fprintf(stderr, "[rafft] pinned chunk freed in %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count());
+        if (g.proc_cfg.trace_alloc) fprintf(stderr, "[rafft] pinned chunk freed in %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count());
     }
 }
 
@@ -552,6 +556,7 @@ struct Job { std::vector<SeqIn> seqs; double est; int depth; std::vector<std::sh
 // the batch, lane 1: the bulk - see rafft_fold_submit) and what the scheduler needs to finish it.
 struct Batch {
     rafft_params p;
+    Config cfg;                               // the environment switches as they were when the batch was submitted (rafft_config.h)
     int n_seq = 0;
     std::vector<char> seqbuf;                 // the caller's sequences, copied at submit
     std::vector<uint8_t> codebuf;             // ... and as base codes, same offsets
@@ -579,6 +584,7 @@ struct SeamIn {     // rafft_expand_node: one region of one given structure
 // for one wave's 152-byte read-back the kernels of the other keep the GPU busy.
 struct Wave {
     Workspace &g;                 // NB: named `g` on purpose - the buffers used to live in the global context
+    const Config &cfg;            // of the first member batch (batches with other snapshots are never merged into the wave)
     rafft_params p;
     std::vector<SeqIn> seqs;
     double est;
@@ -620,7 +626,7 @@ struct Wave {
     double ms_setup = 0, ms_issue = 0, ms_after = 0;   // host time inside issue_step / after_beam (trace)
 
     Wave(Workspace &w, std::vector<std::shared_ptr<Batch>> m, std::vector<SeqIn> s, double e, const SeamIn *sm = nullptr)
-        : g(w), p(m[0]->p), seqs(std::move(s)), est(e), members(std::move(m)), bt(*members[0]), spans(members[0]->spans), seam(sm) {}
+        : g(w), cfg(m[0]->cfg), p(m[0]->p), seqs(std::move(s)), est(e), members(std::move(m)), bt(*members[0]), spans(members[0]->spans), seam(sm) {}
     HostOut &out_of(int local_seq) { return *members[seqs[local_seq].bi]->ho; }
 
     double since(std::chrono::steady_clock::time_point t) const
@@ -657,7 +663,7 @@ int Wave::setup()
     S = seqs.size();
     tw0 = std::chrono::steady_clock::now();
     // test hook: a wave of exactly this many sequences fails hard (what a structure beyond the kernels' limits does)
-    if (const char *e = getenv("RAFFT_TEST_HARD_FAIL")) if ((int)S == atoi(e)) return fail(RAFFT_ERR_PARAM, "test hook: hard failure of this wave");
+    if (cfg.test_hard_fail >= 0 && (int)S == cfg.test_hard_fail) return fail(RAFFT_ERR_PARAM, "test hook: hard failure of this wave");
     off.resize(S); len.resize(S);
     sumL = 0;
     for (size_t i = 0; i < S; i++) { off[i] = (int)sumL; len[i] = seqs[i].len; sumL += seqs[i].len; }
@@ -683,18 +689,18 @@ int Wave::setup()
     const double ms_enc = since(tw0);
     int maxL = 0;
     for (size_t i = 0; i < S; i++) maxL = std::max(maxL, len[i]);
-    const int direct_n_ = getenv("RAFFT_DIRECT_N") ? atoi(getenv("RAFFT_DIRECT_N")) : 1024;
-    const bool force_fft_ = getenv("RAFFT_FORCE_FFT") && atoi(getenv("RAFFT_FORCE_FFT"));
-    const bool nofft1 = !seam && !force_fft_ && direct_n_ >= cls1_P() / 2 && p.gc_wei >= 0.0 && p.au_wei >= 0.0 && p.gu_wei >= 0.0 &&
-                        !(getenv("RAFFT_C1_FFT") && atoi(getenv("RAFFT_C1_FFT")));
-    const bool nofft2 = nofft1 && direct_n_ >= CLS2_P / 2 && !(getenv("RAFFT_C2_FFT") && atoi(getenv("RAFFT_C2_FFT")));
-    if (int rc = class_cfg(p.nb_mode, maxL, cf, nofft1, nofft2, nofft1)) return rc;      // (direct class 3: the same conditions as the other FFT-free plans)
-    if (getenv("RAFFT_TRACE"))
+    const int direct_n_ = cfg.direct_n;
+    const bool force_fft_ = cfg.force_fft != 0;
+    const bool nofft1 = !seam && !force_fft_ && direct_n_ >= cls1_P(cfg) / 2 && p.gc_wei >= 0.0 && p.au_wei >= 0.0 && p.gu_wei >= 0.0 &&
+                        !cfg.c1_fft;
+    const bool nofft2 = nofft1 && direct_n_ >= CLS2_P / 2 && !cfg.c2_fft;
+    if (int rc = class_cfg(cfg, p.nb_mode, maxL, cf, nofft1, nofft2, nofft1)) return rc;      // (direct class 3: the same conditions as the other FFT-free plans)
+    if (cfg.trace)
         for (int c = 0; c < NGEN; c++)
             fprintf(stderr, "[rafft] expand class %d: %d threads x %d regions per workgroup, P <= %d, branches <= %d, lags <= %d, LDS %d B%s\n", c, cf[c].nt, cf[c].wpb,
                     cf[c].Pmax, cf[c].brmax, cf[c].Kmax, cf[c].lds, cf[c].nofft ? " (no FFT buffers)" : "");
     merge_target = maxL > CLS2_P / 2 ? 3 : 2;
-    c = plan_caps(S, sumL, p, est);
+    c = plan_caps(cfg, S, sumL, p, est);
     if (std::max((size_t)c.sort_cap * 8, (size_t)24 * 1024) + RL_CAP * 12 + (size_t)(p.max_stack + 4) * (sizeof(ParentInfo) + 12) + 1024 > 150 * 1024)
         return fail(RAFFT_ERR_PARAM, "max_branch + 2*max_stack too large for the LDS-resident beam sort");
     B = (size_t)p.max_stack;
@@ -711,12 +717,12 @@ int Wave::setup()
         // (a long-tail job has a few sequences per batch: sized once for 64 of them, whatever gets merged later)
         // bulk batches: for the merge cap itself (a stream of small batches is merged up to it whatever their size), or for five of
         // them when that is too much
-        static const double reserve_frac = getenv("RAFFT_RESERVE_FRAC") ? atof(getenv("RAFFT_RESERVE_FRAC")) : 0.10;
+        const double reserve_frac = cfg.reserve_frac;
         const size_t tries[2] = {S >= 256 ? merge_cap() : std::max<size_t>(S, std::min<size_t>(64, 32 * S)), S >= 256 ? std::min(merge_cap(), 5 * S) : S};
         Sr = S;
         for (size_t want : tries) {
             if (want <= S) continue;
-            Caps big = plan_caps(want, (size_t)((double)sumL * (double)want / (double)S), p, est);
+            Caps big = plan_caps(cfg, want, (size_t)((double)sumL * (double)want / (double)S), p, est);
             if (big.bytes <= (size_t)((double)::g.hbm_total * reserve_frac)) { cr = big; Sr = want; break; }
         }
     }
@@ -746,8 +752,8 @@ int Wave::setup()
     // identical loops share one expansion only when the energy filter cannot depend on the
     // parent's absolute energy through float32 rounding, i.e. for the default min_nrj == 0
     d.memo = (p.min_nrj == 0.0) ? 1 : 0;
-    if (const char *e = getenv("RAFFT_NO_MEMO")) if (atoi(e)) d.memo = 0;
-    if (const char *e = getenv("RAFFT_FORCE_FFT")) if (atoi(e)) d.force_fft = 1;   // tests: FFT path for short regions too
+    if (cfg.no_memo) d.memo = 0;
+    if (cfg.force_fft) d.force_fft = 1;   // tests: FFT path for short regions too
     d.rl_cap = RL_CAP;
     longseq = maxL > LDS_SEQ;
     d.pos_packed = longseq ? 0 : 1;          // 12 bits of position leave room for the base code (Dev::pos_packed)
@@ -756,7 +762,7 @@ int Wave::setup()
     // 86 VGPRs (measured: 68.4 -> 62.2 ms per 36 benchmark batches), with 1024 entries 8 (1.5 -> 2.3 ms per batch) - so the long
     // lists are for sequences beyond 4096 nt and for a wave that overflowed the short ones and is being folded again
     d.max_prod = (longseq || big_prod) ? MAX_PROD_LONG : MAX_PROD;
-    if (const char *e = getenv("RAFFT_TEST_MAX_PROD")) if (!big_prod && !longseq) d.max_prod = std::max(1, std::min(atoi(e), MAX_PROD));   // test hook: short lists overflow early
+    if (cfg.test_max_prod > 0 && !big_prod && !longseq) d.max_prod = std::max(1, std::min(cfg.test_max_prod, MAX_PROD));   // test hook: short lists overflow early
     if (longseq) {       // scratch of the class for regions beyond 4096 positions: lag values (fp64) + lag column, per workgroup
         d.big_stride = (size_t)2 * cf[0].nmax + (size_t)2 * cf[0].nmax / 4;
         if (int rc = ensure(g.big, (size_t)cf[0].grid * d.big_stride * 8)) return rc;
@@ -766,23 +772,22 @@ int Wave::setup()
         if (int rc = ensure(g.big, (size_t)cf[3].grid * d.big_stride * 8)) return rc;
         d.big_keyv = (double *)g.big.p;
     }
-    d.cls1_P = cls1_P(); d.cls1_br = cf[1].brmax;
-    d.c3_switch = getenv("RAFFT_C3_SWITCH") ? atoi(getenv("RAFFT_C3_SWITCH")) : ::g.n_cu;
-    d.cand_slab = getenv("RAFFT_SLAB") ? std::max(16, atoi(getenv("RAFFT_SLAB"))) : 64;
-    d.fetch_bulk = getenv("RAFFT_FETCH") ? std::max(1, atoi(getenv("RAFFT_FETCH"))) : 4;
-    d.taper_pct = getenv("RAFFT_TAPER") ? std::max(0, std::min(100, atoi(getenv("RAFFT_TAPER")))) : 25;
+    d.cls1_P = cls1_P(cfg); d.cls1_br = cf[1].brmax;
+    d.c3_switch = cfg.c3_switch >= 0 ? cfg.c3_switch : ::g.n_cu;
+    d.cand_slab = std::max(16, cfg.slab);
+    d.fetch_bulk = std::max(1, cfg.fetch);
+    d.taper_pct = std::max(0, std::min(100, cfg.taper));
     // wide classes: regions of up to 1024 positions are correlated by the exact direct form on multi-word bit masks, longer ones
     // by the LDS FFT (measured on the configs[3] shard: n <= 1024 direct 219.7 ms against 222.8 with the FFT everywhere, 236.4
     // with the direct form up to 4096 - scipy itself switches at 2381, rafft/utils.py:121).  RAFFT_DIRECT_N moves the limit.
-    d.direct_n = getenv("RAFFT_DIRECT_N") ? atoi(getenv("RAFFT_DIRECT_N")) : 1024;
+    d.direct_n = cfg.direct_n;
     // small-region classes (expand_small_kernel): packed positions (no sequence beyond 4096 nt), the bit-mask form of
     // window_slide (non-negative weights, no forced FFT).  RAFFT_SMALL="n4,n5" moves the limits ("0,0": off).
-    d.sm_n4 = 16; d.sm_n5 = 32;
-    if (const char *e = getenv("RAFFT_SMALL")) { int a = 16, b = 32; if (sscanf(e, "%d,%d", &a, &b) >= 1) { d.sm_n4 = std::max(0, std::min(a, 16)); d.sm_n5 = std::max(d.sm_n4, std::min(b, 32)); } }
+    d.sm_n4 = std::max(0, std::min(cfg.small_n4, 16)); d.sm_n5 = std::max(d.sm_n4, std::min(cfg.small_n5, 32));
     if (!d.pos_packed || d.force_fft || !(p.gc_wei >= 0.0 && p.au_wei >= 0.0 && p.gu_wei >= 0.0)) d.sm_n4 = d.sm_n5 = 0;
     d.mat_tile = 64;
-    if (const char *e = getenv("RAFFT_MAT_TILE")) d.mat_tile = std::max(1, std::min(atoi(e), 64));   // tests: several tiles per structure
-    if (const char *e = getenv("RAFFT_RL_CAP")) d.rl_cap = std::max(0, std::min(atoi(e), RL_CAP));   // tests: region lists not resident in LDS
+    d.mat_tile = std::max(1, std::min(cfg.mat_tile, 64));                  // tests: several tiles per structure
+    if (cfg.rl_cap >= 0) d.rl_cap = std::min(cfg.rl_cap, RL_CAP);         // tests: region lists not resident in LDS
     d.beam = (int *)g.beam.p; d.beam_n = (int *)g.beam_n.p; d.done = (int *)g.done.p; d.nsteps = (int *)g.nsteps.p;
     d.ch_cap = c.ch_cap;
     d.ch_parent = (uint16_t *)g.ch_parent.p; d.ch_combo = (uint64_t *)g.ch_combo.p; d.ch_dcal = (int *)g.ch_dcal.p; d.ch_h = (uint64_t *)g.ch_h.p;
@@ -807,16 +812,16 @@ int Wave::setup()
     d.sp_shard_cap = c.sp / NSHARD;
     d.br_shard_cap = c.br / NSHARD; d.cand_shard_cap = c.cand / NSHARD;
     if (seam) d.dbg = seam->dbg;
-    if (const char *rp = getenv("RAFFT_REP")) d.rep = atoi(rp);
+    d.rep = cfg.rep;
     static unsigned long long *prof_buf = nullptr;
-    if (getenv("RAFFT_TRACE") && atoi(getenv("RAFFT_TRACE")) >= 3) {
+    if (cfg.trace >= 3) {
         if (!prof_buf) HIPCHK(hipMalloc((void **)&prof_buf, 128));
         HIPCHK(hipMemset(prof_buf, 0, 128));
         d.prof = prof_buf;
         int best = 0;
         for (size_t i = 0; i < S; i++) if (len[i] > len[best]) best = (int)i;
         d.prof_seq = best;
-        if (const char *ps = getenv("RAFFT_PROF_SEQ")) d.prof_seq = atoi(ps);
+        if (cfg.prof_seq != INT_MIN) d.prof_seq = cfg.prof_seq;
         static unsigned long long *ws_buf = nullptr; static size_t ws_cap = 0;
         if (ws_cap < S) { if (ws_buf) HIPCHK(hipFree(ws_buf)); HIPCHK(hipMalloc((void **)&ws_buf, S * 24)); ws_cap = S; }
         HIPCHK(hipMemset(ws_buf, 0, S * 24));
@@ -849,7 +854,7 @@ int Wave::setup()
     }
     mat_lds = 20 * (size_t)d.max_prod;
     out_row_lds = ((size_t)maxL + 15) & ~(size_t)15;      // output_kernel builds a dot-bracket row in LDS: the longest sequence of the wave
-    if (const char *e = getenv("RAFFT_DEDUPE_PER_CU")) dedupe_per_cu = (unsigned)std::max(1, atoi(e));
+    if (cfg.dedupe_per_cu > 0) dedupe_per_cu = (unsigned)cfg.dedupe_per_cu;
     n_active = (unsigned)S;
     {
         // step-ahead (RAFFT_STEP_AHEAD=0: lock-step as in rounds 1-4): needs the kernel that takes the device's own count
@@ -859,13 +864,10 @@ int Wave::setup()
         // pipelined rate falls 3 % (an empty step per wave, guessed grids), and a lone 76-nt sequence takes 1.07 ms instead of 0.91
         // (its 6 steps cost ~150 us each on the DEVICE - eight dependent kernels at ~20 us of dispatch latency - and step-ahead
         // adds a seventh).  RAFFT_STEP_AHEAD=1 switches it on.
-        static const bool on = getenv("RAFFT_STEP_AHEAD") && atoi(getenv("RAFFT_STEP_AHEAD")) != 0;
-        static const bool mat4_on = !(getenv("RAFFT_MAT4") && atoi(getenv("RAFFT_MAT4")) == 0);
-        const bool tracing = getenv("RAFFT_TRACE") && atoi(getenv("RAFFT_TRACE")) >= 2;
-        step_ahead = on && mat4_on && !seam && !tracing && d.prof_e == nullptr && d.max_prod <= MAT4_PROD && getenv("RAFFT_TEST_OVF_AT") == nullptr;
+        step_ahead = cfg.step_ahead != 0 && cfg.mat4 != 0 && !seam && cfg.trace < 2 && d.prof_e == nullptr && d.max_prod <= MAT4_PROD && cfg.test_ovf_at < 0;
     }
     ms_setup = since(tw0);
-    if (getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] setup: encode %.3f ms, plan+buffers %.3f ms, copies+init %.3f ms\n", ms_enc, ms_plan - ms_enc, ms_setup - ms_plan);
+    if (cfg.trace) fprintf(stderr, "[rafft] setup: encode %.3f ms, plan+buffers %.3f ms, copies+init %.3f ms\n", ms_enc, ms_plan - ms_enc, ms_setup - ms_plan);
     tw1 = std::chrono::steady_clock::now();
     return 0;
 }
@@ -876,22 +878,22 @@ int Wave::issue_step()
     const auto t_in = std::chrono::steady_clock::now();
     struct Acc { double &a; std::chrono::steady_clock::time_point t; ~Acc() { a += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); } } acc_{ms_issue, t_in};
     hipStream_t st = g.stream;
-    static const unsigned wide_below = getenv("RAFFT_WIDE_BELOW") ? (unsigned)atoi(getenv("RAFFT_WIDE_BELOW")) : 600u;
-    static const bool serial = getenv("RAFFT_SERIAL") && atoi(getenv("RAFFT_SERIAL"));
-    static const unsigned small_wg_per_cu = getenv("RAFFT_SMALL_WG") ? (unsigned)std::max(1, atoi(getenv("RAFFT_SMALL_WG"))) : 4u;   // 4 wavefronts each
+    const unsigned wide_below = (unsigned)std::max(0, cfg.wide_below);
+    const bool serial = cfg.serial != 0;
+    const unsigned small_wg_per_cu = (unsigned)std::max(1, cfg.small_wg);   // 4 wavefronts each
     const size_t hot_len = offsetof(Counters, node);
     HIPCHK(hipEventRecord(g.ev_fork, st));
     Span wall{next_event(), next_event(), 4};
     SPAN_REC(wall.a, st, 4);
     static const int order_big_first[NCLS] = {3, 0, 2, 1, 5, 4}, order_small_first[NCLS] = {5, 4, 3, 0, 2, 1};    // big-LDS classes first
-    static const int *order = getenv("RAFFT_SMALL_FIRST") && atoi(getenv("RAFFT_SMALL_FIRST")) ? order_small_first : order_big_first;
+    const int *order = cfg.small_first ? order_small_first : order_big_first;
     for (int oi = 0; oi < NCLS; oi++) {
         const int cls = order[oi];
         if (cls == 0 && !longseq) continue;                      // regions beyond 4096 positions: only sequences longer than that have them
         if (cls == 3 && merge_target == 2) continue;             // no sequence long enough for a region of that class
         if (merged_now == 3 && cls != 3 && cls != 0) continue;   // the dedupe of the last step sent everything to one class
         if (merged_now == 2 && cls == 1) continue;               // ... or the one-wavefront class to the 256-thread one
-        static const bool small_step0 = getenv("RAFFT_SMALL_STEP0") != nullptr;      // diagnostic: empty launches (their fixed cost)
+        const bool small_step0 = cfg.small_step0 != 0;      // diagnostic: empty launches (their fixed cost)
         if (cls >= NGEN && (merged_now != 0 || (steps == 0 && !small_step0) || (cls == 4 ? d.sm_n4 : d.sm_n5) == 0 || (cls == 5 && d.sm_n5 == d.sm_n4))) continue;   // small-region classes: off, or nothing was sent there
         const bool inline_ = serial || (merged_now == 3 && !longseq);   // a single kernel: no fork/join through another stream
         hipStream_t cs = inline_ ? st : g.cls_stream[cls];
@@ -901,18 +903,18 @@ int Wave::issue_step()
         // persistent workgroups loop over the work list, so any grid is correct: when few structures were
         // materialized (the tail of a batch) a small grid avoids dispatching thousands of empty workgroups
         unsigned grid = cls >= NGEN ? (unsigned)::g.n_cu * small_wg_per_cu : (unsigned)cf[cls].grid;
-        static const unsigned c1_wgs = getenv("RAFFT_C1_WGS") ? (unsigned)atoi(getenv("RAFFT_C1_WGS")) : 0u;     // A/B: fewer workgroups of the one-wavefront class
+        const unsigned c1_wgs = (unsigned)std::max(0, cfg.c1_wgs);     // A/B: fewer workgroups of the one-wavefront class
         if (cls == 1 && c1_wgs && cf[1].wpb > 1) grid = std::min(grid, c1_wgs * (unsigned)cf[1].wpb);
         if (steps > 0 && !(step_ahead && steps < 3)) {       // (step-ahead: `last_mat` is the step before's - doubled; the first steps grow faster)
             const unsigned long long bound = (unsigned long long)last_mat * (step_ahead ? 2ULL : 1ULL) * (cls == 1 ? 8ULL : 4ULL) + 32ULL;
             if (bound < grid) grid = (unsigned)bound;
         }
-        if (int rc = launch_expand_cls(d, cls, cf, grid, cs)) return rc;
-        static const int twice = getenv("RAFFT_TWICE") ? atoi(getenv("RAFFT_TWICE")) : 0;   // diagnostic: the same work again, caches warm
+        if (int rc = launch_expand_cls(cfg, d, cls, cf, grid, cs)) return rc;
+        const int twice = cfg.twice;   // diagnostic: the same work again, caches warm
         if (twice && cls == 1) {
             HIPCHK(hipMemsetAsync((char *)g.counters.p + offsetof(Counters, wcur) + sizeof(ShardCtr) * NSHARD * cls, 0, sizeof(ShardCtr) * NSHARD, cs));
             HIPCHK(hipMemsetAsync((char *)g.counters.p + offsetof(Counters, wdone) + 8 * cls, 0, 8, cs));
-            if (int rc = launch_expand_cls(d, cls, cf, grid, cs, twice >= 2)) return rc;
+            if (int rc = launch_expand_cls(cfg, d, cls, cf, grid, cs, twice >= 2)) return rc;
         }
         if (cls == 1) bt.stats.n_expand_launches++;       // launches of the dominant kernel (ms_expand is their sum)
         SPAN_REC(sp.b, cs, sp.kind);
@@ -960,7 +962,7 @@ int Wave::issue_materialize(unsigned n_mat_known, unsigned n_mat_guess)
     SPAN_REC(sp.a, st, sp.kind);
     // (four structures per wavefront, teams of 16 lanes, when the short productive-region lists are in use -
     //  materialize_team_kernel; RAFFT_MAT4=0: one structure per wavefront)
-    static const bool mat4_on = !(getenv("RAFFT_MAT4") && atoi(getenv("RAFFT_MAT4")) == 0);
+    const bool mat4_on = cfg.mat4 != 0;
     if (mat4_on && d.prof_e == nullptr && d.max_prod <= MAT4_PROD) {
         const unsigned grid = n_mat_known ? (n_mat_known + MAT4_TEAMS - 1) / MAT4_TEAMS
                                           : std::min<unsigned>((unsigned)((c.mat + MAT4_TEAMS - 1) / MAT4_TEAMS), std::max<unsigned>(64u, nm / 2u + 64u));
@@ -973,11 +975,14 @@ int Wave::issue_materialize(unsigned n_mat_known, unsigned n_mat_guess)
     // (measured on the benchmark batch: 18.8 -> 17.3 ms; thresholds in new structures per step, per CU)
     // (round 3, after the 256-thread class got its production build and four workgroups per CU: everything goes to the widest
     //  class only below 2 structures per CU - 16 per CU before; a burst of 20 shard batches 18.5 -> 17.8 ms, the rest unchanged)
-    const unsigned merge_below = getenv("RAFFT_MERGE_BELOW") ? (unsigned)atoi(getenv("RAFFT_MERGE_BELOW")) : 2u * (unsigned)::g.n_cu;
-    const unsigned merge2_below = getenv("RAFFT_MERGE2_BELOW") ? (unsigned)atoi(getenv("RAFFT_MERGE2_BELOW")) : 128u * (unsigned)::g.n_cu;
+    const unsigned merge_below = cfg.merge_below >= 0 ? (unsigned)cfg.merge_below : 2u * (unsigned)::g.n_cu;
+    const unsigned merge2_below = cfg.merge2_below >= 0 ? (unsigned)cfg.merge2_below : 128u * (unsigned)::g.n_cu;
     d.merge_cls = seam ? 0 : nm < merge_below ? merge_target : nm < merge2_below ? 2 : 0;
     merged_now = d.merge_cls;
-    hipLaunchKernelGGL(dedupe_kernel, dim3(::g.n_cu * dedupe_per_cu), dim3(DEDUPE_NT), 0, st, d);
+    // (a thread per region created in this step - two or three per new structure: light steps launch a handful of workgroups instead
+    //  of two per CU, which used to queue behind the expand kernels of the other waves only to find nothing)
+    const unsigned dd_grid = std::min<unsigned>((unsigned)::g.n_cu * dedupe_per_cu, (unsigned)std::min<unsigned long long>(0x7fffffffULL, (unsigned long long)nm * 4ULL / DEDUPE_NT + 2ULL));
+    hipLaunchKernelGGL(dedupe_kernel, dim3(dd_grid), dim3(DEDUPE_NT), 0, st, d);
     HIPCHK(hipGetLastError());
     SPAN_REC(sp.b, st, sp.kind);
     spans.push_back(sp);
@@ -996,18 +1001,18 @@ int Wave::after_beam()
     rb_seen++;
     if (hc.overflow) { ovf = hc.overflow; return finish(); }
     // test hook: pretend an arena overflowed at this step of the first attempt (regrowth late in a wave)
-    if (const char *e = getenv("RAFFT_TEST_OVF_AT")) if (depth == 0 && steps == atoi(e)) { ovf = OVF_STRUCT; return finish(); }
+    if (cfg.test_ovf_at >= 0 && depth == 0 && steps == cfg.test_ovf_at) { ovf = OVF_STRUCT; return finish(); }
     if (hc.n_mat == 0) return finish();
     n_active = (unsigned)S - hc.n_done;
     last_mat = hc.n_mat;
     // most sequences of the wave have finished: their rows leave beside the folding steps of the others - once this step's kernels
     // are queued (below): the host's share of it, a millisecond or two for a wave of 16 k sequences, is off the wave's own path
-    const bool harvest_now = !p.traj && !seam && !harvested && S >= 256 && (size_t)hc.trec_n * 10 >= S * 7 && getenv("RAFFT_NO_HARVEST") == nullptr;
+    const bool harvest_now = !p.traj && !seam && !harvested && S >= 256 && (size_t)hc.trec_n * 10 >= S * 7 && !cfg.no_harvest;
     const size_t harvest_n = (size_t)hc.trec_n;
     // step-ahead mode: this step's materialize and the next folding step are queued already (when the step before was looked at);
     // what is issued now is the materialize of the step in flight and the folding step after it, sized by this step's counters
     if (int rc = issue_materialize(step_ahead ? 0u : hc.n_mat, hc.n_mat)) return rc;
-    if (const char *tr = getenv("RAFFT_TRACE")) if (atoi(tr) >= 2) {
+    if (cfg.trace >= 2) {
         Counters h2;
         HIPCHK(hipMemcpyAsync(&h2, g.counters.p, hot_len, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -1018,7 +1023,7 @@ int Wave::after_beam()
     if (harvest_now && !finished) {
         if (int rc = emit_rows(0, harvest_n, true, nullptr)) return rc;
         harvested = harvest_n;
-        if (getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] early harvest after step %d: %zu of %zu sequences\n", step_of_harvest, harvested, S);
+        if (cfg.trace) fprintf(stderr, "[rafft] early harvest after step %d: %zu of %zu sequences\n", step_of_harvest, harvested, S);
     }
     return 0;
 }
@@ -1112,7 +1117,7 @@ int Wave::finish_body()
     bt.stats.n_steps = std::max<int64_t>(bt.stats.n_steps, step_ahead ? rb_seen : steps);
     // (step-ahead: the step queued behind the last read-back has nothing to do - every sequence is done, no work list holds anything -
     //  and touches none of the counters and records read below)
-    if (ovf && getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] wave S=%zu est %.1f overflowed (bits %u) after %d steps, %.1f ms\n", S, est, ovf, steps, since(tw0));
+    if (ovf && cfg.trace) fprintf(stderr, "[rafft] wave S=%zu est %.1f overflowed (bits %u) after %d steps, %.1f ms\n", S, est, ovf, steps, since(tw0));
     if (ovf) {
         HIPCHK(hipStreamSynchronize(st));
         if (harvested) HIPCHK(hipStreamSynchronize(g.copy_stream));
@@ -1265,7 +1270,7 @@ int Wave::finish_done_body()
         fprintf(stderr, "[rafft] beam_step stamps of the longest sequence (cycles): prepass %llu, product loop %llu, single phase %llu, sort %llu, survivors %llu over %llu steps\n",
                 pv[0], pv[1], pv[2], pv[3], pv[4], pv[5]);
     }
-    if (getenv("RAFFT_TRACE")) {
+    if (cfg.trace) {
         auto mx = [&](const ShardCtr *sc) { unsigned long long m = 0, t = 0; for (int i = 0; i < NSHARD; i++) { m = std::max(m, sc[i].v); t += sc[i].v; } return std::make_pair(m, t); };
         auto nd = mx(hc.node), po = mx(hc.pos), br = mx(hc.br), spr = mx(hc.sp), ca = mx(hc.cand), pr = mx(hc.prod), nl = mx(hc.nlist);
         fprintf(stderr, "[rafft] max productive regions per structure: %u (limit %d)\n", hc.max_nprod, d.max_prod);
@@ -1274,8 +1279,8 @@ int Wave::finish_done_body()
                 br.first, (unsigned long long)d.br_shard_cap, br.second, spr.first, (unsigned long long)d.sp_shard_cap, spr.second,
                 ca.first, (unsigned long long)d.cand_shard_cap, ca.second, pr.first, (unsigned long long)d.prod_shard_cap, pr.second, nl.first, (unsigned long long)d.nd_shard_cap, nl.second, hc.seen_top, c.seen, est);
     }
-    if (getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] host time inside issue_step %.3f ms, inside after_beam (incl. nested issue_step and this tail) %.3f ms\n", ms_issue, ms_after);
-    if (getenv("RAFFT_TRACE")) fprintf(stderr, "[rafft] wave S=%zu setup %.2f ms, loop %.2f ms (%d steps), tail %.2f ms (counters %.3f, records+gather %.3f, rows out %.3f incl. %.1f MB D2H)\n",
+    if (cfg.trace) fprintf(stderr, "[rafft] host time inside issue_step %.3f ms, inside after_beam (incl. nested issue_step and this tail) %.3f ms\n", ms_issue, ms_after);
+    if (cfg.trace) fprintf(stderr, "[rafft] wave S=%zu setup %.2f ms, loop %.2f ms (%d steps), tail %.2f ms (counters %.3f, records+gather %.3f, rows out %.3f incl. %.1f MB D2H)\n",
                                        S, ms_setup, ms_loop, steps, since(tw2), tl_stats, tl_gather - tl_stats, tl_copy - tl_gather, (double)tot_bytes / 1e6);
     return result = 0;
 }
@@ -1313,7 +1318,7 @@ int run_seam(Batch &bt, const std::vector<SeqIn> &one, const SeamIn &sm)
     w.hc.n_work[cls].v = 1;
     HIPCHK(hipMemcpy(W.counters.p, &w.hc, sizeof w.hc, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(w.d.work[cls], &zero, 4, hipMemcpyHostToDevice));
-    if (int rc = launch_expand_cls(w.d, cls, w.cf, 1, W.stream)) return rc;
+    if (int rc = launch_expand_cls(w.cfg, w.d, cls, w.cf, 1, W.stream)) return rc;
     HIPCHK(hipStreamSynchronize(W.stream));
     return 0;
 }
@@ -1335,7 +1340,7 @@ struct Slot { std::unique_ptr<Wave> wave; Job job; int lane = 0; };
 
 static unsigned admit_below()
 {
-    static const unsigned v = getenv("RAFFT_ADMIT_BELOW") ? (unsigned)atoi(getenv("RAFFT_ADMIT_BELOW")) : 0u;
+    const unsigned v = (unsigned)std::max(0, g.sched_cfg.admit_below);
     return v ? v : 128u * (unsigned)g.n_cu;     // = the step size below which the one-wavefront expand class is merged away
 }
 // sequences one merged wave may hold (a wave of the whole benchmark set four times over folds 25 % faster per sequence
@@ -1345,8 +1350,7 @@ static unsigned admit_below()
 // one at a time)
 static size_t merge_cap()
 {
-    static const size_t v = getenv("RAFFT_MERGE_SEQS") ? (size_t)atol(getenv("RAFFT_MERGE_SEQS")) : 16384;
-    return v;
+    return (size_t)std::max(1L, g.sched_cfg.merge_seqs);
 }
 
 static bool same_params(const rafft_params &a, const rafft_params &b)
@@ -1365,7 +1369,7 @@ static void finalize_batch(const std::shared_ptr<Batch> &bp)
         free_out(b.ho);
         b.ho = nullptr;
     } else {
-        if (getenv("RAFFT_TRACE")) {       // per-step timeline: spans are recorded in step order
+        if (b.cfg.trace) {       // per-step timeline: spans are recorded in step order
             float acc[16] = {0};
             int stepno = 0;
             for (auto &sp : b.spans) {
@@ -1448,7 +1452,8 @@ static void scheduler_main()
     //  part of that: steady state over 80 benchmark batches 367-377 k -> 384-388 k sequences/s with 15 in flight, a 20-step bench run
     //  366 -> 373 k; four waves of four batches 372-375 k - smaller waves, more launches.  Round 2 measured the opposite with waves of
     //  one or two batches and twice the kernel time per batch.)
-    const int max_waves = std::max(1, std::min(getenv("RAFFT_MAX_WAVES") ? atoi(getenv("RAFFT_MAX_WAVES")) : 3, MAX_PIPES));
+    const Config &scfg = g.sched_cfg;          // (read by start_scheduler, before this thread was started)
+    const int max_waves = std::max(1, std::min(scfg.max_waves, MAX_PIPES));
     // a member batch is finished when its last job is: finalise it
     auto release = [&](Job &job, int rc, const std::string &err) {
         for (auto &m : job.members) {
@@ -1590,7 +1595,7 @@ static void scheduler_main()
         // The long-tail lane has a wave slot of its own: a long-tail wave (a handful of sequences, two dozen latency-bound steps)
         // never keeps a second bulk wave from starting (288 -> 294 k sequences/s with eight batches in flight, three interleaved
         // pairs of runs; RAFFT_TAIL_SLOT=0: the lanes share the `max_waves` slots as in round 2)
-        static const bool tail_slot = getenv("RAFFT_TAIL_SLOT") ? atoi(getenv("RAFFT_TAIL_SLOT")) != 0 : true;
+        const bool tail_slot = scfg.tail_slot != 0;
         int n_lane[2] = {0, 0};
         for (int i = 0; i < MAX_PIPES; i++) if (slot[i].wave) n_lane[slot[i].lane]++;
         // A caller that streams batches (two or more in flight) queues them microseconds apart: a bulk wave admitted the moment the
@@ -1598,7 +1603,7 @@ static void scheduler_main()
         // other (heavy phases do not overlap) where one merged wave would do.  So while submissions keep coming (the last one less
         // than RAFFT_LINGER_US = 150 us ago) and the queues are below the merge cap, both lanes wait for them.  A lone synchronous
         // call never lingers.
-        static const long linger_us = getenv("RAFFT_LINGER_US") ? atol(getenv("RAFFT_LINGER_US")) : 150;
+        const long linger_us = scfg.linger_us;
         bool linger = false;
         if (linger_us > 0 && (!queue[1].empty() || !queue[0].empty())) {
             size_t queued = 0;
@@ -1635,7 +1640,7 @@ static void scheduler_main()
                     Job &nx = queue[ln].front();
                     bool nx_failed = false;
                     for (auto &m : nx.members) nx_failed = nx_failed || m->rc != 0;
-                    if (nx.depth != 0 || nx.no_merge || nx_failed || !same_params(nx.members[0]->p, job.members[0]->p) ||
+                    if (nx.depth != 0 || nx.no_merge || nx_failed || !same_params(nx.members[0]->p, job.members[0]->p) || !same_config(nx.members[0]->cfg, job.members[0]->cfg) ||
                         job.seqs.size() + nx.seqs.size() > merge_cap() || very_long(nx) != job_vl)
                         break;
                     const int off = (int)job.members.size();
@@ -1646,20 +1651,20 @@ static void scheduler_main()
                 }
                 size_t sl_ = 0;
                 for (auto &sq : job.seqs) sl_ += sq.len;
-                const Caps cc = plan_caps(job.seqs.size(), sl_, job.members[0]->p, job.est);
+                const Caps cc = plan_caps(job.members[0]->cfg, job.seqs.size(), sl_, job.members[0]->p, job.est);
                 size_t others = 0;
                 for (int k = 0; k < MAX_PIPES; k++) if (k != w) others += g.ws[k].bytes();
                 const size_t budget = (size_t)((double)g.hbm_total * 0.55 / 2.0);
                 bool fits_now = std::max(cc.bytes, g.ws[w].bytes()) + others <= (size_t)((double)g.hbm_total * 0.85);
                 // waves whose arenas take more than a tenth of the HBM run one at a time (the halves of a split job would
                 // otherwise fill two workspaces of that size)
-                static const double big_wave_frac = getenv("RAFFT_BIG_WAVE_FRAC") ? atof(getenv("RAFFT_BIG_WAVE_FRAC")) : 0.10;
+                const double big_wave_frac = scfg.big_wave_frac;
                 const size_t big_wave = (size_t)((double)g.hbm_total * big_wave_frac);
                 if (cc.bytes > big_wave)
                     for (int k = 0; k < MAX_PIPES; k++) if (slot[k].wave && slot[k].wave->c.bytes > big_wave) fits_now = false;
                 if ((cc.bytes > budget || cc.capped || (!fits_now && n_running == 0)) && job.seqs.size() > 1) {
                     const size_t h = job.seqs.size() / 2;          // too big for one wave: two jobs, one after the other
-                    if (getenv("RAFFT_TRACE"))
+                    if (job.members[0]->cfg.trace)
                         fprintf(stderr, "[rafft] job of %zu sequences folded in halves: plan %.1f GB (budget %.1f), this workspace holds %.1f GB, the others %.1f GB, %s%s\n",
                                 job.seqs.size(), (double)cc.bytes / 1e9, (double)budget / 1e9, (double)g.ws[w].bytes() / 1e9, (double)others / 1e9,
                                 cc.capped ? "a table at the limit of its ids, " : "", fits_now ? "fits" : "does not fit beside what is held");
@@ -1706,7 +1711,7 @@ static void scheduler_main()
         const auto now = std::chrono::steady_clock::now();
         if (progressed) { last_progress = now; continue; }
         if (linger) { std::this_thread::yield(); continue; }          // (at most linger_us: keep looking)
-        static const long spin_us = getenv("RAFFT_SCHED_SPIN_US") ? atol(getenv("RAFFT_SCHED_SPIN_US")) : 200;
+        const long spin_us = scfg.spin_us;
         if (std::chrono::duration_cast<std::chrono::microseconds>(now - last_progress).count() < spin_us) { std::this_thread::yield(); continue; }
         bool any_wave = false;
         for (int i = 0; i < MAX_PIPES; i++) any_wave = any_wave || (bool)slot[i].wave;
@@ -1715,7 +1720,7 @@ static void scheduler_main()
             // (measured: the long-tail wave's steps - 14 sequences, 0.3 ms of kernels - sat 0.5 ms on average, up to 1.6 ms, behind
             // a bulk wave's step, and while the long-tail wave holds one of the two wave slots the bulk waves do not overlap).  So
             // the thread naps in short slices and looks at all of them; a nap costs no core to speak of.
-            static const long nap_us = getenv("RAFFT_SCHED_NAP_US") ? atol(getenv("RAFFT_SCHED_NAP_US")) : 50;
+            const long nap_us = scfg.nap_us;
             std::this_thread::sleep_for(std::chrono::microseconds(nap_us));
             continue;
         } else {
@@ -1742,6 +1747,7 @@ static void start_scheduler()
     std::lock_guard<std::mutex> lk(g.qmu);    // (sched_started / sched_thread: the same mutex as rafft_shutdown)
     if (g.sched_started) return;
     g.sched_started = true;
+    g.sched_cfg = read_config();              // the scheduler's own settings: read when it starts (rafft_config.h)
     g.sched_thread = std::thread(scheduler_main);
     static bool registered = false;
     if (!registered) {
@@ -1820,9 +1826,10 @@ static int submit_locked(const rafft_params *p, int n_seq, const char *const *se
         drain();
         if (int rc = ensure_tables(p->temp)) return rc;
     }
-    g_span_level = getenv("RAFFT_TRACE") ? 2 : getenv("RAFFT_SPANS") ? atoi(getenv("RAFFT_SPANS")) : 1;
     std::shared_ptr<Batch> bp(new Batch());
     Batch &b = *bp;
+    b.cfg = read_config();                    // the environment switches as they are NOW travel with the batch (rafft_config.h)
+    g_span_level = b.cfg.trace ? 2 : b.cfg.spans >= 0 ? b.cfg.spans : 1;
     b.p = *p; b.n_seq = n_seq; b.t0 = std::chrono::steady_clock::now();
     HostOut *ho = b.ho = new HostOut();
     ho->seq.resize(n_seq); ho->step_size.resize(n_seq); ho->step_off.resize(n_seq); ho->one_size.assign(n_seq, 0); ho->one_off.assign(n_seq, 0);
@@ -1861,8 +1868,7 @@ static int submit_locked(const rafft_params *p, int n_seq, const char *const *se
     // RAFFT_SPLIT: unset / -1 automatic, 0 never, > 0 cut at that length.
     int split_len = 0;
     {
-        const char *sp = getenv("RAFFT_SPLIT");
-        const int want = sp ? atoi(sp) : -1;
+        const int want = b.cfg.split;
         if (good.size() >= 32 && want != 0 && (want > 0 || good.size() < 16384)) {     // (very large batches amortise the tail anyway)
             if (want > 0) split_len = want;
             else {   // the sequences at least twice as long as the 99th percentile of the batch (leaving room for two)
@@ -1881,7 +1887,7 @@ static int submit_locked(const rafft_params *p, int n_seq, const char *const *se
             size_t sl = 0;
             for (auto &sq : v) sl += sq.len;
             double e0 = 6.0 + (v.empty() ? 0.0 : (double)sl / (double)v.size()) / 100.0;
-            if (const char *e = getenv("RAFFT_EST")) if (atof(e) > 0) e0 = atof(e);
+            if (b.cfg.est > 0) e0 = b.cfg.est;
             return e0;
         };
         std::vector<SeqIn> shorts, longs;
@@ -2210,6 +2216,7 @@ int rafft_expand_node(const rafft_params *p, const char *seq, const char *db, co
     ho.seq.resize(1); ho.step_size.resize(1); ho.step_off.resize(1); ho.one_size.assign(1, 0); ho.one_off.assign(1, 0); ho.dcal_ptr.assign(1, nullptr); ho.db_ptr.assign(1, nullptr);
     Batch bt;                                  // a private batch: the scheduler is idle (drained above) and g.mu is held
     bt.p = *p;
+    bt.cfg = read_config();
     bt.p.max_stack = std::max(1, bt.p.max_stack);
     bt.n_seq = 1; bt.ho = &ho;
     const int src = run_seam(bt, one, sm);
