@@ -204,6 +204,25 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
             w_nb[s] = mx_nb; w_mi[s] = mx_i; w_mj[s] = mx_j; w_sc[s] = mx_s;
         }
 
+        // (round 5) the lags that gave a stem, compacted over the team: half of a small region's lags do, so a lane's second slot
+        // is usually empty afterwards - and the second copy of the loop-energy code below (the dE of slot 1: every lane on a path of
+        // its own) is skipped by the whole wavefront when no team has more stems than lanes.  The seam reports every lag: as it was.
+        int w_k[2] = {tl, tl + TL};                   // the lag a slot holds
+        if (!dbg) {
+            const unsigned long long sb0 = __ballot(w_nb[0] > 0) & tmask, sb1 = __ballot(w_nb[1] > 0) & tmask;
+            const int n0 = __popcll(sb0), nst = n0 + __popcll(sb1);
+            uint32_t *sl = (uint32_t *)ck;            // (the sort keys take this place once dE is done)
+            if (w_nb[0] > 0) sl[__popcll(sb0 & lt_lane)] = (uint32_t)w_nb[0] | ((uint32_t)w_mi[0] << 8) | ((uint32_t)tl << 16);
+            if (w_nb[1] > 0) sl[n0 + __popcll(sb1 & lt_lane)] = (uint32_t)w_nb[1] | ((uint32_t)w_mi[1] << 8) | ((uint32_t)(tl + TL) << 16);
+            wave_sync();
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const int idx = tl + s * TL;
+                const uint32_t e = idx < nst ? sl[idx] : 0u;
+                w_nb[s] = (int)(e & 255u); w_mi[s] = (int)((e >> 8) & 255u); w_k[s] = (int)(e >> 16); w_mj[s] = w_k[s] - w_mi[s];
+            }
+            wave_sync();
+        }
         SSTAMP(2);   // window_slide
         // ---- dE of every candidate stem: only the loops it changes (rafft/rafft.py:97-98 evaluates the whole structure)
         // prefix sums of the branches' stem terms: every loop below costs O(1) whatever its number of branches
@@ -288,7 +307,7 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
         double w_val[2] = {0.0, 0.0};
 #pragma unroll
         for (int s = 0; s < 2; s++) {
-            const int k = tl + s * TL;
+            const int k = w_k[s];
             if ((w_keep[s] || dbg) && act && k < m) {
                 const int sft = n - 1 - k;
                 const uint32_t xU = sm_shift(rU, sft), xC = sm_shift(rC, sft);
@@ -342,7 +361,7 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
 #pragma unroll
         for (int s = 0; s < 2; s++)
             if (w_keep[s]) {
-                ck[slot[s]] = ((unsigned long long)((unsigned)w_dd[s] ^ 0x80000000u) << 32) | (unsigned)(tl + s * TL);
+                ck[slot[s]] = ((unsigned long long)((unsigned)w_dd[s] ^ 0x80000000u) << 32) | (unsigned)w_k[s];
                 val[slot[s]] = w_val[s];
             }
         wave_sync();
@@ -351,7 +370,7 @@ __global__ __launch_bounds__(64 * SM_WG_WAVES, RAFFT_SMALL_WAVES) void expand_sm
 #pragma unroll
             for (int s = 0; s < 2; s++)
                 if (w_keep[s]) {
-                    const int k = tl + s * TL;
+                    const int k = w_k[s];
                     const unsigned long long kx = ck[slot[s]];
                     int rank = 0;
                     for (int y = 0; y < nkept; y++) {
