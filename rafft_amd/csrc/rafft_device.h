@@ -75,7 +75,12 @@ __device__ __forceinline__ uint32_t loop_key(const uint8_t *S, int i, int m)
     return k;
 }
 
-__device__ inline int e_hairpin(const SmallT *T, const BigT *B, int size, int type, const uint8_t *S, int ci, int cj)
+// (round 5: NOT inlined.  Every expansion of a region calls it from three or four places - the loop as it is, the loop inside a
+//  stem, a loop between two pairs of a stem with a gap - and each inlined copy kept its operands alive across the kernel's densest
+//  stretch: out of line the one-wavefront kernel spills 6 VGPRs instead of 12, the 256-thread class 17 instead of 35, the small-region
+//  kernels 6 instead of 24; same rate, less scratch traffic - tools/kernel_regs.py, tools/ab_many.sh.  e_intloop out of line as well
+//  was slower.)
+__device__ __noinline__ int e_hairpin(const SmallT *T, const BigT *B, int size, int type, const uint8_t *S, int ci, int cj)
 {
     int e = (size <= 30) ? T->hairpin[size] : T->hairpin[30] + B->logext[size];
     if (size < 3) return e;
