@@ -354,3 +354,24 @@ def test_gpu_more_productive_regions_than_the_short_lists_hold(monkeypatch):
         n_long += rafft_amd.last_stats()["n_waves_long_lists"]
     assert 6 <= n_long < 20 and rafft_amd.last_stats()["n_waves_long_lists"] == 0      # (the fold above was the first of the eight)
     _native.lib().rafft_shutdown()
+
+
+def test_gpu_long_stems_vs_oracle():
+    """perfect and wobbled hairpin stems of 15, 16, 17, 20, 33 and 60 pairs (round 5: a contiguous stem of up to 16 pairs takes its
+    stacking energies from the packed strands, one look-up per pair, and its pair hash from two mixes; longer stems take the pair-by-pair
+    forms - both sides of the line, nested and side by side, bare and with flanks): full trajectories equal the oracle's"""
+    rng = np.random.default_rng(1617)
+    comp = {"A": "U", "U": "A", "G": "C", "C": "G"}
+    seqs = []
+    for nb in (15, 16, 17, 20, 33, 60):
+        left = "".join(rng.choice(list("GCAU"), nb))
+        right = "".join(comp[c] for c in reversed(left))
+        wob = "".join(("U" if (c == "C" and rng.random() < 0.3) else c) for c in right)       # G-C -> G.U here and there
+        seqs += ["G" * nb + "GAAA" + "C" * nb, left + "UUCG" + right, "AC" + left + "GCAA" + wob + "UUA",
+                 left + "GAAA" + right + "AAAA" + left[::-1] + "UUUU" + "".join(comp[c] for c in left)]
+    from _oracle_pool import fold_many
+    want = fold_many([(s, 100, 6, 1000, True) for s in seqs])
+    got = rafft_amd.fold_batch(seqs, 100, 6, 1000, traj=True)
+    for k, (fin, traj) in enumerate(got):
+        assert [[(x.str_struct, x.dcal) for x in st] for st in traj] == want[k], (k, seqs[k])
+    assert any(x.str_struct.count("(") >= 60 for fin, _ in got for x in fin)       # the 60-pair stems do form

@@ -302,3 +302,16 @@ def test_batch_front_end_reads_csv_fasta_and_lines(tmp_path):
     assert out3.read_text() == want
     with pytest.raises(SystemExit):
         cli.main(["-sf", str(csvf), "--batch", "--csv_column", "nope"], fold_batch=_oracle_fold_batch)
+
+
+def test_round5_device_helpers_on_the_host(tmp_path):
+    """the telescoping pair hash (a stem = two mixes, a pair set hashes the same whatever stems it is assembled from, no collision on the
+    pattern a polynomial hash would confuse), the packed-strand stacking table against the plain table for every quadruple of bases and
+    random stems, and the special-hairpin filter never hiding a listed loop - rafft_device.h's host-callable forms, built host-only"""
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    exe = str(tmp_path / "device_helpers_check")
+    subprocess.check_call([hipcc, "-x", "hip", "--offload-host-only", "-O1", "-std=c++17", "-Wno-unused-function", "-Wno-missing-braces",
+                           os.path.join(ROOT, "tests", "hostcheck", "device_helpers_check.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "0 failures" in r.stdout, r.stdout + r.stderr
