@@ -43,13 +43,9 @@ template <int NT>
 __device__ inline int block_exscan(int v, int *scratch, int *tot)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int x = v;
-    for (int o = 1; o < 64; o <<= 1) {
-        int y = __shfl_up(x, o, 64);
-        if (lane >= o) x += y;
-    }
+    const int x = wave_incl_scan(v);           // (round 5: six DPP additions - every caller has the whole wavefront active - instead of six __shfl_up)
     if (NT == 64) {
-        *tot = __shfl(x, 63, 64);
+        *tot = __builtin_amdgcn_readlane(x, 63);
         return x - v;
     }
     __syncthreads();
@@ -580,6 +576,19 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
         const bool inplace = (ranked && !selected) || (dbgrank && !selected);    // keys sorted in place, rk[] in rank order
         double *keyv = LONGSEQ == 2 ? d.big_keyv + (size_t)gteam * d.big_stride : (double *)(lds + lay.offA);
         uint16_t *lagk = LONGSEQ == 2 ? (uint16_t *)(keyv + P) : (uint16_t *)(lds + lay.offA + 8 * P);
+        // (round 5, production builds - weights >= 0) The top byte of the order-preserving key of a lag value - sign and the upper seven
+        // bits of the exponent - only says whether the value is 0, below 2 or at least 2: counted here with three ballots per 64 lags
+        // (wavefront-uniform counters: scalar registers), which is the radix select's first pass without a pass over the keys - for the
+        // class whose lag values live in HBM one read of them less.  Values outside [2^-15, 2^17) (user weights of another scale) or a
+        // negative one: `c_odd`, and the select starts at the top byte as before.
+        int c_hi = 0, c_lo = 0, c_odd = 0;
+        auto tally = [&](double v_, bool valid) {
+            if (PROD && selected) {
+                c_hi += __popcll(__ballot(valid && v_ >= 2.0));
+                c_lo += __popcll(__ballot(valid && v_ > 0.0 && v_ < 2.0));
+                c_odd |= __ballot(valid && (v_ >= 131072.0 || v_ < 0.0 || (v_ > 0.0 && v_ < 0x1p-15))) != 0ULL ? 1 : 0;
+            }
+        };
         if (LONGSEQ == 2 || mw) {
             // base masks of the region (the same arrays window_slide uses below, built once here) ...
             const int W = (n + 63) >> 6;
@@ -617,6 +626,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                     v = raw / ((double)nk + 1.0);
                 }
                 keyv[k] = v;
+                tally(v, k < m);
             }
             ESYNC();
             if (inplace) {                                  // lag column of the in-place sort (tiny regions in a class without FFT buffers;
@@ -642,6 +652,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                     v = raw / ((double)nk + 1.0);
                 }
                 keyv[k] = v;
+                tally(v, k < m);
             }
             ESYNC();
             if (inplace) {                                  // lag column of the in-place sort
@@ -663,6 +674,7 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
                     v = raw / ((double)nk + 1.0);
                 }
                 keyv[k] = v;
+                tally(v, k < m);
             }
             ESYNC();
             if (inplace) {                                  // lag column of the in-place sort
@@ -683,7 +695,26 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
             unsigned long long prefix = 0;
             int kk = Kp;
             bool take_ge = false;          // every key >= prefix is selected (the threshold fell between two values)
-            for (int pass = 7; pass >= 0; pass--) {
+            int pass0 = 7;
+            if (PROD) {
+                if (NT > 64) {             // (the counters are per wavefront: summed over the team)
+                    if (tid < 3) shs[20 + tid] = 0;
+                    ESYNC();
+                    if ((tid & 63) == 0) { atomicAdd(&shs[20], c_hi); atomicAdd(&shs[21], c_lo); atomicOr(&shs[22], c_odd); }
+                    ESYNC();
+                    c_hi = shs[20]; c_lo = shs[21]; c_odd = shs[22];
+                }
+                if (!c_odd) {              // byte 7 of the keys: 0xC0 for [2, 2^17), 0xBF for [2^-15, 2), 0x80 for 0
+                    const int c_zero = m - c_hi - c_lo;
+                    int binc;
+                    if (kk <= c_hi) { prefix = 0xC0ULL << 56; binc = c_hi; }
+                    else if (kk <= c_hi + c_lo) { prefix = 0xBFULL << 56; kk -= c_hi; binc = c_lo; }
+                    else { prefix = 0x80ULL << 56; kk -= c_hi + c_lo; binc = c_zero; }
+                    pass0 = kk == binc ? -1 : 6;       // (the whole bin is wanted: nothing below that byte needs looking at)
+                    take_ge = kk == binc;
+                }
+            }
+            for (int pass = pass0; pass >= 0; pass--) {
                 for (int i = tid; i < 256; i += NT) hist[i] = 0;
                 ESYNC();
                 const int sh_hi = 8 * (pass + 1);
