@@ -283,6 +283,15 @@ __device__ __forceinline__ int wave_incl_scan(int x)
     x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
     return x;
 }
+// the same over the rows of 16 lanes (a team of materialize_team_kernel is one row): four row_shr additions
+__device__ __forceinline__ int row16_incl_scan(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
+    return x;
+}
 // one step of the OR-reduction over a row of 16 lanes (DPP row_shr): lane 15 of every row ends up with the OR of the row
 __device__ __forceinline__ uint32_t row16_or(uint32_t x)
 {

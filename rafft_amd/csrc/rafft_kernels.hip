@@ -2266,10 +2266,12 @@ __global__ __launch_bounds__(64, RAFFT_MAT_WAVES) void materialize_team_kernel(D
             npos = ((win & 1) ? md.npos_in : 0) + ((win & 2) ? md.npos_out : 0);
             nbrr = ((win & 1) ? md.nbr_in : 0) + ((win & 2) ? md.nbr_out : 0);
         }
-        for (int o = MAT4_TL / 2; o > 0; o >>= 1) {
-            nnod += __shfl_xor(nnod, o, MAT4_TL); nnew += __shfl_xor(nnew, o, MAT4_TL); npos += __shfl_xor(npos, o, MAT4_TL); nbrr += __shfl_xor(nbrr, o, MAT4_TL);
-            nsp += __shfl_xor(nsp, o, MAT4_TL);
-        }
+        // (round 5: sums over the team - a row of 16 lanes - by DPP row scans and one read of the row's last lane each, instead of four
+        //  rounds of five __shfl_xor through the LDS crossbar)
+        static_assert(MAT4_TL == 16, "a team is one DPP row");
+        nnod = __shfl(row16_incl_scan(nnod), MAT4_TL - 1, MAT4_TL); nnew = __shfl(row16_incl_scan(nnew), MAT4_TL - 1, MAT4_TL);
+        npos = __shfl(row16_incl_scan(npos), MAT4_TL - 1, MAT4_TL); nbrr = __shfl(row16_incl_scan(nbrr), MAT4_TL - 1, MAT4_TL);
+        nsp = __shfl(row16_incl_scan(nsp), MAT4_TL - 1, MAT4_TL);
         tot_nodes += nnod; tot_new += nnew; tot_pos += npos; tot_br += nbrr; tot_sp += nsp;
     }
     bool ok = live;
@@ -2308,10 +2310,7 @@ __global__ __launch_bounds__(64, RAFFT_MAT_WAVES) void materialize_team_kernel(D
         const int cb_in = act && (md.win & 1) ? md.nbr_in : 0, cb_out = act && (md.win & 2) ? md.nbr_out : 0;
         int xn = act ? md.nnod : 0, xw = act ? (md.win & 1) + (md.win >> 1) : 0, xp = cp_in + cp_out, xb = cb_in + cb_out, xs = act ? md.nb : 0;
         const int vn = xn, vw = xw, vp = xp, vb = xb, vs = xs;
-        for (int o = 1; o < MAT4_TL; o <<= 1) {
-            const int yn = __shfl_up(xn, o, MAT4_TL), yw = __shfl_up(xw, o, MAT4_TL), yp = __shfl_up(xp, o, MAT4_TL), yb = __shfl_up(xb, o, MAT4_TL), ys = __shfl_up(xs, o, MAT4_TL);
-            if (tl >= o) { xn += yn; xw += yw; xp += yp; xb += yb; xs += ys; }
-        }
+        xn = row16_incl_scan(xn); xw = row16_incl_scan(xw); xp = row16_incl_scan(xp); xb = row16_incl_scan(xb); xs = row16_incl_scan(xs);
         const int tn = __shfl(xn, MAT4_TL - 1, MAT4_TL), tw = __shfl(xw, MAT4_TL - 1, MAT4_TL), tp = __shfl(xp, MAT4_TL - 1, MAT4_TL),
                   tbr = __shfl(xb, MAT4_TL - 1, MAT4_TL), ts = __shfl(xs, MAT4_TL - 1, MAT4_TL);
         const int p0 = xp - vp, b0 = xb - vb;          // exclusive
