@@ -315,3 +315,16 @@ def test_round5_device_helpers_on_the_host(tmp_path):
                            os.path.join(ROOT, "tests", "hostcheck", "device_helpers_check.cpp"), "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "0 failures" in r.stdout, r.stdout + r.stderr
+
+
+def test_bench_self_launch_ends_the_run_when_a_rank_dies(tmp_path):
+    """a rank that dies at start-up ends the whole run at once with a non-zero exit (its siblings are terminated instead of sitting in the
+    rendezvous until the process group's timeout) and its stderr is shown"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(BENCH_SAME_GPU="1", BENCH_BACKEND="gloo", BENCH_SKIP_CFG4="1", BENCH_TEST_DIE_RANK="1", BENCH_LAUNCH_TIMEOUT_S="120")
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "ranks failed" in r.stderr and "BENCH_TEST_DIE_RANK" in r.stderr
+    assert time.time() - t0 < 100
