@@ -328,3 +328,24 @@ def test_bench_self_launch_ends_the_run_when_a_rank_dies(tmp_path):
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 1 and "ranks failed" in r.stderr and "BENCH_TEST_DIE_RANK" in r.stderr
     assert time.time() - t0 < 100
+
+
+def test_one_config_struct_is_the_only_reader_of_the_environment(tmp_path):
+    """every environment switch of the library is a field of Config (rafft_config.h), read_config() there is the ONLY getenv
+    caller of the library, defaults / parsing / snapshot equality hold, and the test hooks compile out with -DRAFFT_NO_TEST_HOOKS"""
+    import subprocess
+    csrc = os.path.join(ROOT, "rafft_amd", "csrc")
+    for name in os.listdir(csrc):
+        if name.endswith((".hip", ".h")) and name != "rafft_config.h":
+            assert "getenv" not in open(os.path.join(csrc, name)).read(), name
+    cfg = open(os.path.join(csrc, "rafft_config.h")).read()
+    fields = set(re.findall(r"//\s+(RAFFT_[A-Z0-9_]+)", cfg))
+    read = set(re.findall(r'"(RAFFT_[A-Z0-9_]+)"', cfg))
+    assert read and read <= fields | {"RAFFT_TAPER", "RAFFT_C2_FFT", "RAFFT_SCHED_NAP_US"}, sorted(read - fields)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert "rafft_config.h" in doc and "RAFFT_NO_TEST_HOOKS" in doc
+    for flags in ([], ["-DRAFFT_NO_TEST_HOOKS"]):
+        exe = str(tmp_path / ("config_check" + str(len(flags))))
+        subprocess.check_call(["g++", "-std=c++17", "-O1"] + flags + [os.path.join(ROOT, "tests", "hostcheck", "config_check.cpp"), "-o", exe])
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and "0 failures" in r.stdout, r.stdout + r.stderr
