@@ -701,7 +701,7 @@ int Wave::setup()
                     cf[c].Pmax, cf[c].brmax, cf[c].Kmax, cf[c].lds, cf[c].nofft ? " (no FFT buffers)" : "");
     merge_target = maxL > CLS2_P / 2 ? 3 : 2;
     c = plan_caps(cfg, S, sumL, p, est);
-    if (std::max((size_t)c.sort_cap * 8, (size_t)24 * 1024) + RL_CAP * 12 + (size_t)(p.max_stack + 4) * (sizeof(ParentInfo) + 12) + 1024 > 150 * 1024)
+    if (std::max((size_t)c.sort_cap * 8, (size_t)24 * 1024) + RL_CAP * 12 + (size_t)(p.max_stack + 4) * (sizeof(ParentInfo) + 16) + 1024 > 150 * 1024)
         return fail(RAFFT_ERR_PARAM, "max_branch + 2*max_stack too large for the LDS-resident beam sort");
     B = (size_t)p.max_stack;
 
@@ -850,7 +850,7 @@ int Wave::setup()
     // beam_step_kernel LDS: time-shared region 0 (walk scratch 24 B/thread, then sort keys), region list, per-member records
     for (int v = 0; v < 2; v++) {
         const size_t nt = v ? 1024 : 256;
-        bs_lds[v] = std::max((size_t)c.sort_cap * 8, 24 * nt) + RL_CAP * 12 + B * sizeof(ParentInfo) + (B + 1) * 8 + ((B + 3) & ~(size_t)3) * 4 + 128;
+        bs_lds[v] = std::max((size_t)c.sort_cap * 8, 24 * nt) + RL_CAP * 12 + B * sizeof(ParentInfo) + (B + 1) * 8 + ((B + 3) & ~(size_t)3) * 4 + 128 + B * 4;      // (+ B ints: the prepass's first node-list entries)
     }
     mat_lds = 20 * (size_t)d.max_prod;
     out_row_lds = ((size_t)maxL + 15) & ~(size_t)15;      // output_kernel builds a dot-bracket row in LDS: the longest sequence of the wave

@@ -1330,13 +1330,36 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
 
 // --------------------------------------------------------- beam step kernel
 
-__device__ inline bool seen_lookup(const uint64_t *tab, uint32_t cap, uint64_t h1, uint64_t h2)
+// (round 5: four slots per round trip.  A wavefront waits for the longest probe chain among its 64 lanes - at half load that was four or
+//  five dependent trips for a lookup whose expected length is 1.5; the four 16-byte loads are independent and mostly one 64-byte line.
+//  `free_sl`: the empty slot that ended the search - where seen_insert_at starts, every slot before it holds another key for good)
+__device__ inline bool seen_lookup(const uint64_t *tab, uint32_t cap, uint64_t h1, uint64_t h2, uint32_t &free_sl)
 {
-    uint32_t mask = cap - 1, sl = (uint32_t)h1 & mask;
+    const uint32_t mask = cap - 1;
+    uint32_t sl = (uint32_t)h1 & mask;
+    const ulonglong2 *t2 = (const ulonglong2 *)tab;
     for (;;) {
-        uint64_t k1 = tab[2 * (uint64_t)sl];
-        if (k1 == 0) return false;
-        if (k1 == h1 && tab[2 * (uint64_t)sl + 1] == h2) return true;
+        const uint32_t s1 = (sl + 1) & mask, s2 = (sl + 2) & mask, s3 = (sl + 3) & mask;
+        const ulonglong2 e0 = t2[sl], e1 = t2[s1], e2 = t2[s2], e3 = t2[s3];
+        if (e0.x == 0) { free_sl = sl; return false; }
+        if (e0.x == h1 && e0.y == h2) return true;
+        if (e1.x == 0) { free_sl = s1; return false; }
+        if (e1.x == h1 && e1.y == h2) return true;
+        if (e2.x == 0) { free_sl = s2; return false; }
+        if (e2.x == h1 && e2.y == h2) return true;
+        if (e3.x == 0) { free_sl = s3; return false; }
+        if (e3.x == h1 && e3.y == h2) return true;
+        sl = (sl + 4) & mask;
+    }
+}
+// insert a key that seen_lookup did not find, starting at the empty slot it stopped at (other threads of the pass may have taken it since)
+__device__ inline void seen_insert_at(uint64_t *tab, uint32_t cap, uint64_t h1, uint64_t h2, uint32_t sl)
+{
+    const uint32_t mask = cap - 1;
+    for (;;) {
+        unsigned long long old = atomicCAS((unsigned long long *)&tab[2 * (uint64_t)sl], 0ULL, (unsigned long long)h1);
+        if (old == 0) { tab[2 * (uint64_t)sl + 1] = h2; return; }
+        if (old == h1 && tab[2 * (uint64_t)sl + 1] == h2) return;
         sl = (sl + 1) & mask;
     }
 }
@@ -1383,7 +1406,7 @@ __device__ __forceinline__ unsigned long long sat_mul(unsigned long long a, unsi
 
 // LDS: sort keys (dynamic) + product description + per-parent prepass records
 template <int BS_NT, bool PROD = false>      // (PROD: the diagnostic stamps compiled out - see expand_kernel)
-__global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
+__global__ __launch_bounds__(BS_NT, BS_NT == 256 ? 5 : 1) void beam_step_kernel(Dev d, int sort_cap)
 {
     extern __shared__ __align__(16) unsigned char lds[];
     // region 0 is time-shared: scratch of the product walk (per-thread keys + dedupe table), then the sort keys
@@ -1422,6 +1445,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
         prof_ws[3 * sq + 2] += n_par; } } while (0)
 #define STAMP(k) do { if (prof) { unsigned long long tn_ = clock64(); atomicAdd(&d.prof[k], tn_ - tprev); tprev = tn_; } } while (0)
     const int nbeam = d.beam_n[sq];
+    const int step_no = d.nsteps[sq];          // (read by everyone before the barrier below; thread 0 counts the step after it)
     int *beam = d.beam + (size_t)sq * d.B;
     for (int i = tid; i < nbeam; i += BS_NT) oldbeam[i] = beam[i];
     __syncthreads();
@@ -1441,119 +1465,125 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
     }
     if (tid == 0) d.nsteps[sq] += 1;
 
-    // ---- prepass: product size and combo 0 of every parent, and its regions with a real choice (>= 2
-    // candidates) as a compact list in LDS.  A group of G lanes per beam member (G = 16 for short sequences,
-    // whose structures have few regions; a whole wavefront otherwise): every member costs a chain of dependent
-    // loads (structure -> regions -> canonical region -> candidate), so the more members are in flight at once
-    // the fewer round trips the prepass takes.
-    if (tid == 0) sh[26] = 0;                  // fill of the LDS region list
-    __syncthreads();
+    // ---- prepass: product size and combo 0 of every parent, its productive regions as a compact list in HBM (written on the first
+    // visit, read back by later product walks and by materialize_kernel) and its regions with a real choice (>= 2 candidates) as a
+    // (count, offset) list in LDS.
+    // Round 5: FLAT over (beam member, region) items.  Every member costs a chain of dependent loads - structure row -> node list ->
+    // child slot -> region header -> first candidate - and the kernel lives on how many of those chains are in flight at once: a group
+    // of 8 / 16 / 64 lanes per member walked the 50 members of a beam in two to thirteen passes of nine dependent round trips each (the
+    // row's fields, the list allocation and the header's two words were trips of their own).  Now one thread per member reads its whole
+    // row (one trip), a prefix sum over the region counts numbers the items, and one thread per item runs the remaining four trips -
+    // 200 items of a short sequence's beam in ONE pass of a 256-thread workgroup; sums go to the member's record with LDS atomics, the
+    // lists are placed by a workgroup-wide prefix sum (member-major, node order: rafft/rafft.py:166-171).
     {
-        // (round 4: 8 lanes for sequences of up to 300 nt - their structures have 3-5 regions - i.e. 32 members per pass of a
-        //  256-thread workgroup instead of 16: a beam of 50 takes two passes of the chain instead of four)
-        const int G = d.seq_len[sq] <= 300 ? 8 : d.seq_len[sq] <= 800 ? 16 : 64;
-        const int gpw = 64 / G, gl = lane & (G - 1), grp = lane / G;
-        const int nslots = (BS_NT / 64) * gpw;
-        const unsigned long long gmask = G == 64 ? ~0ULL : ((1ULL << G) - 1ULL);
-        const unsigned long long lt = (1ULL << gl) - 1ULL;
-        for (int b0 = 0; b0 < nbeam; b0 += nslots) {
-            const int b = b0 + wv * gpw + grp;
-            if (b >= nbeam) continue;
-            const int sid = oldbeam[b];
-            const unsigned long long cur0 = d.st[sid].cursor, tot0 = d.st[sid].total;
-            if (tot0 && cur0 >= tot0) { if (gl == 0) pinfo[b].flag = 1; continue; }
-            const bool resumed = tot0 && cur0 > 0;
-            unsigned long long pbase = 0, tot = 1, h1 = 0, h2 = 0;
-            int dc = 0, np = 0, wpos = 0, nm = 0, rl0 = -1;
-            if (resumed) {       // expanded in an earlier step: cursor, total and combo 0 are on record
-                pbase = d.st[sid].prod; wpos = d.st[sid].nprod;
-                for (int base = 0; base < wpos; base += G) {
-                    const int i = base + gl;
-                    const int cnt = i < wpos ? (int)d.prod[pbase + i].cnt : 0;
-                    nm += __popcll((__ballot(cnt >= 2) >> (grp * G)) & gmask);
-                }
-            } else {
-                const int node0 = d.st[sid].node0, nn = d.st[sid].nnodes;
-                // first visit of this structure: its productive regions (node order, rafft/rafft.py:166-171) are
-                // written once as a compact list that later product walks and materialize_kernel read back
-                if (gl == 0) {
-                    const int shd = (sq + b) & (NSHARD - 1);       // (members of one sequence spread over the sub-arenas)
-                    pbase = atomicAdd(&d.c->prod[shd].v, (unsigned long long)nn);
-                    if (pbase + nn > d.prod_shard_cap) { atomicOr(&d.c->overflow, OVF_PRODLIST); pbase = ~0ULL; }
-                    else pbase += (unsigned long long)shd * d.prod_shard_cap;
-                }
-                pbase = __shfl(pbase, grp * G, 64);
-                for (int base = 0; base < nn; base += G) {
-                    int i = base + gl, cnt = 0, cn = 0;
-                    unsigned long long coff = 0;
-                    if (i < nn) {
-                        cn = d.nlist[node0 + i];
-                        // (written by materialize_kernel as -(slot + 1): the region that hangs in that child slot - created there by
-                        //  whichever beam member asked first, or the known loop dedupe_kernel found for it)
-                        if (cn < 0) cn = (int)(((const uint32_t *)d.cslot)[-cn - 1] & 0x7FFFFFFFu) - 1;
-                        cnt = cn >= 0 ? d.nd[cn].ncand : 0;
-                        if (cnt > 0) {
-                            coff = d.nd[cn].cand;
-                            const Cand *cp = &d.cand[coff];
-                            tot = sat_mul(tot, (unsigned long long)cnt);
-                            dc += cp->ddcal; h1 += cp->h1; h2 += cp->h2; np++;
-                        }
-                    }
-                    const unsigned long long bal = (__ballot(cnt > 0) >> (grp * G)) & gmask;   // this group's lanes
-                    const unsigned long long bal2 = (__ballot(cnt >= 2) >> (grp * G)) & gmask;
-                    if (cnt > 0 && pbase != ~0ULL) {
-                        ProdEnt pe; pe.cnt = (uint32_t)cnt; pe.node = cn; pe.off = coff;
-                        d.prod[pbase + wpos + __popcll(bal & lt)] = pe;
-                    }
-                    if (nn <= G) {           // the usual case, one round: the region list straight from registers
-                        nm = __popcll(bal2);
-                        if (gl == 0) { const int o = atomicAdd(&sh[26], nm); rl0 = o + nm <= d.rl_cap ? o : -1; }
-                        rl0 = __shfl(rl0, grp * G, 64);
-                        if (cnt >= 2 && rl0 >= 0) { const int sl = rl0 + __popcll(bal2 & lt); rl_cnt[sl] = cnt; rl_off[sl] = coff; }
-                    } else nm += __popcll(bal2);
-                    wpos += __popcll(bal);
-                }
-                if (pbase == ~0ULL) { pbase = 0; wpos = 0; nm = 0; }
-                if (wpos > d.max_prod && gl == 0) atomicOr(&d.c->overflow, OVF_PROD);     // materialize_kernel's limit
-                if (gl == 0) { d.st[sid].prod = pbase; d.st[sid].nprod = wpos; }
-                if (gl == 0 && wpos > 64) atomicMax(&d.c->max_nprod, (unsigned int)wpos);
-                for (int o = G >> 1; o > 0; o >>= 1) {
-                    tot = sat_mul(tot, __shfl_xor(tot, o, 64));
-                    h1 += __shfl_xor(h1, o, 64); h2 += __shfl_xor(h2, o, 64);
-                    dc += __shfl_xor(dc, o, 64); np += __shfl_xor(np, o, 64);
-                }
-                if (nn > G) __threadfence_block();       // the list is read back below by other lanes of the group
-            }
-            if (resumed || (!resumed && wpos > 0 && rl0 < 0 && nm > 0 && d.st[sid].nnodes > G)) {
-                // region list from the productive-region list in global memory
-                if (gl == 0) { const int o = atomicAdd(&sh[26], nm); rl0 = o + nm <= d.rl_cap ? o : -1; }
-                rl0 = __shfl(rl0, grp * G, 64);
-                int w = 0;
-                if (rl0 >= 0)
-                    for (int base = 0; base < wpos; base += G) {
-                        const int i = base + gl;
-                        ProdEnt pe; pe.cnt = 0; pe.off = 0;
-                        if (i < wpos) pe = d.prod[pbase + i];
-                        const unsigned long long bal2 = (__ballot(pe.cnt >= 2) >> (grp * G)) & gmask;
-                        if (pe.cnt >= 2) { const int sl = rl0 + w + __popcll(bal2 & lt); rl_cnt[sl] = (int)pe.cnt; rl_off[sl] = pe.off; }
-                        w += __popcll(bal2);
-                    }
-            }
-            if (gl == 0) {
+        unsigned long long *istart = ppre;                 // [B + 1] first item of a member (ppre proper is written after the prepass)
+        int *pnode0 = sh + 32;                             // [B] first node-list entry of a member on its first visit
+        unsigned int irun = 0;
+        if (tid == 0) sh[28] = 0;                          // regions of this step's first visits
+        __syncthreads();
+        for (int b0 = 0; b0 < nbeam; b0 += BS_NT) {
+            const int b = b0 + tid;
+            int ic = 0;
+            if (b < nbeam) {
+                const int sid = oldbeam[b];
+                const StRec r = d.st[sid];                 // the whole row: one round trip
                 ParentInfo pi;
-                pi.sid = sid; pi.prod = pbase; pi.nprod = wpos; pi.rl0 = nm == 0 ? 0 : rl0; pi.nrl = nm;
-                if (resumed) {
-                    pi.flag = 2; pi.total = tot0; pi.cur = cur0;
-                    pi.h1 = d.st[sid].c0h1; pi.h2 = d.st[sid].c0h2; pi.dcal0 = d.st[sid].c0d;
-                } else {
-                    pi.flag = np == 0 ? 1 : 0; pi.total = tot; pi.cur = 0;
-                    pi.h1 = d.st[sid].h1 + h1; pi.h2 = d.st[sid].h2 + h2;
-                    pi.dcal0 = d.st[sid].dcal + dc;
-                    d.st[sid].c0h1 = pi.h1; d.st[sid].c0h2 = pi.h2; d.st[sid].c0d = pi.dcal0;
-                    if (np == 0) { d.st[sid].total = 1; d.st[sid].cursor = 1; }
+                pi.sid = sid; pi.rl0 = 0; pi.nrl = 0; pi.prod = 0; pi.nprod = 0; pi.total = 0; pi.cur = 0; pi.h1 = 0; pi.h2 = 0; pi.dcal0 = 0;
+                if (r.total && r.cursor >= r.total) pi.flag = 1;                       // product exhausted
+                else if (r.total && r.cursor > 0) {      // expanded in an earlier step: cursor, total and combo 0 are on record
+                    pi.flag = 2; pi.total = r.total; pi.cur = r.cursor; pi.h1 = r.c0h1; pi.h2 = r.c0h2; pi.dcal0 = r.c0d;
+                    pi.prod = r.prod; pi.nprod = r.nprod; ic = r.nprod;
+                } else {                                  // first visit: combo 0 = the first candidate of every region that has one
+                    pi.flag = 0; pi.total = 1; pi.h1 = r.h1; pi.h2 = r.h2; pi.dcal0 = r.dcal;
+                    pnode0[b] = r.node0; ic = r.nnodes;
+                    if (ic) atomicAdd(&sh[28], ic);
                 }
                 pinfo[b] = pi;
             }
+            int tot, ex = block_exscan<BS_NT>(ic, sh, &tot);
+            if (b < nbeam) istart[b] = irun + (unsigned int)ex;
+            irun += (unsigned int)tot;
+            __syncthreads();
+        }
+        const int nitems = (int)irun;
+        // ONE allocation for the productive-region lists of all first visits of the step (at most one entry per region): a returning
+        // atomic per member was 50 per sequence and step on the 64 sub-arena counters - same-address atomics are served one after the
+        // other (1.20 -> 1.29 ms per batch).  The sub-arena rotates with the step, so that a lone sequence spreads over all of them.
+        // The answer is needed when the lists are written, i.e. after the item loads below are under way: kept in a register till then.
+        const int nfirst = sh[28], pshard = (sq + step_no) & (NSHARD - 1);
+        unsigned long long pb_raw = 0, pball = 0;
+        if (tid == BS_NT - 1 && nfirst) pb_raw = atomicAdd(&d.c->prod[pshard].v, (unsigned long long)nfirst);
+        unsigned int run1 = 0, run2 = 0;
+        for (int t0 = 0; t0 < nitems; t0 += BS_NT) {
+            const int t = t0 + tid;
+            int b = -1, i = 0, cnt = 0, cn = -1, first = 0;
+            unsigned long long coff = 0;
+            if (t < nitems) {
+                int lo = 0, hi = nbeam - 1;              // the last member whose items start at or before t
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (istart[mid] <= (unsigned long long)t) lo = mid; else hi = mid - 1; }
+                b = lo; i = t - (int)istart[b];
+                first = pinfo[b].flag == 0 ? 1 : 0;
+                if (first) {
+                    cn = d.nlist[pnode0[b] + i];
+                    // (written by materialize_kernel as -(slot + 1): the region that hangs in that child slot - created there by
+                    //  whichever beam member asked first, or the known loop dedupe_kernel found for it)
+                    if (cn < 0) cn = (int)(((const uint32_t *)d.cslot)[-cn - 1] & 0x7FFFFFFFu) - 1;
+                    if (cn >= 0) { cnt = d.nd[cn].ncand; coff = d.nd[cn].cand; }
+                    if (cnt > 0) {
+                        const Cand *cp = &d.cand[coff];
+                        const int dd = cp->ddcal;
+                        const ulonglong2 hh = *(const ulonglong2 *)&cp->h1;
+                        atomicAdd(&pinfo[b].dcal0, dd);
+                        atomicAdd(&pinfo[b].h1, hh.x); atomicAdd(&pinfo[b].h2, hh.y);
+                        if (cnt >= 2) {                  // product size: a saturating product commutes (every factor >= 1)
+                            unsigned long long old = pinfo[b].total, seen_;
+                            do { seen_ = old; old = atomicCAS(&pinfo[b].total, seen_, sat_mul(seen_, (unsigned long long)cnt)); } while (old != seen_);
+                        }
+                    }
+                } else {
+                    const ProdEnt pe = d.prod[pinfo[b].prod + i];
+                    cnt = (int)pe.cnt; coff = pe.off; cn = pe.node;
+                }
+            }
+            if (t0 == 0 && tid == BS_NT - 1) {
+                unsigned long long v = pb_raw;
+                if (v + (unsigned long long)nfirst > d.prod_shard_cap) { atomicOr(&d.c->overflow, OVF_PRODLIST); v = ~0ULL; }
+                else v += (unsigned long long)pshard * d.prod_shard_cap;
+                *(unsigned long long *)&sh[30] = v;
+            }
+            const int f1 = (first && cnt > 0) ? 1 : 0, f2 = cnt >= 2 ? 1 : 0;
+            int tot12, ex12 = block_exscan<BS_NT>(f1 | (f2 << 16), sh, &tot12);      // (barriers inside: sh[30] is there for everyone)
+            if (t0 == 0) pball = *(const unsigned long long *)&sh[30];
+            const unsigned int pos1 = run1 + (unsigned int)(ex12 & 0xFFFF), pos2 = run2 + (unsigned int)(ex12 >> 16);
+            if (b >= 0) {
+                if (i == 0) { pinfo[b].rl0 = (int)pos2; if (first) pinfo[b].prod = pball == ~0ULL ? ~0ULL : pball + pos1; }
+                if (f1) {
+                    atomicAdd(&pinfo[b].nprod, 1);
+                    if (pball != ~0ULL) { ProdEnt pe; pe.cnt = (uint32_t)cnt; pe.node = cn; pe.off = coff; d.prod[pball + pos1] = pe; }
+                }
+                if (f2) {
+                    atomicAdd(&pinfo[b].nrl, 1);
+                    if ((int)pos2 < d.rl_cap) { rl_cnt[pos2] = cnt; rl_off[pos2] = coff; }
+                }
+            }
+            run1 += (unsigned int)(tot12 & 0xFFFF); run2 += (unsigned int)(tot12 >> 16);
+            __syncthreads();
+        }
+        for (int b = tid; b < nbeam; b += BS_NT) {
+            ParentInfo pi = pinfo[b];
+            if (pi.flag == 1) continue;
+            if (pi.nrl == 0) pi.rl0 = 0;
+            else if (pi.rl0 + pi.nrl > d.rl_cap) pi.rl0 = -1;      // a list that does not fit whole is read from HBM by the walk
+            if (pi.flag == 0) {
+                if (pi.prod == ~0ULL) { pi.prod = 0; pi.nprod = 0; pi.nrl = 0; pi.rl0 = 0; pi.total = 1; }
+                const int np = pi.nprod;
+                if (np > d.max_prod) atomicOr(&d.c->overflow, OVF_PROD);     // materialize_kernel's limit
+                if (np > 64) atomicMax(&d.c->max_nprod, (unsigned int)np);
+                StRec *sr = &d.st[pi.sid];
+                sr->prod = pi.prod; sr->nprod = np; sr->c0h1 = pi.h1; sr->c0h2 = pi.h2; sr->c0d = pi.dcal0;
+                if (np == 0) { pi.flag = 1; sr->total = 1; sr->cursor = 1; }
+            }
+            pinfo[b] = pi;
         }
     }
     __syncthreads();
@@ -1622,6 +1652,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
         STAMP(6);   // loop head / seen growth
         const int need = d.max_branch - nb_branch;      // > 0
         int b = 0, sidb = 0, cd = 0, slot = -1;
+        uint32_t free_sl = 0;
         bool cand_new = false, last_combo = false;
         unsigned long long idx = 0, totb = 0, h1 = 0, h2 = 0;
         const unsigned long long pos = W + (unsigned long long)tid;
@@ -1649,7 +1680,10 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
             if (pi.rl0 >= 0) {
                 int j = pi.nrl - 1;
                 // up to four changed digits are located first and their candidates loaded together
-                const Cand *pn0 = nullptr, *pn1 = nullptr, *pn2 = nullptr, *pn3 = nullptr, *po0 = nullptr, *po1 = nullptr, *po2 = nullptr, *po3 = nullptr;
+                // (round 5: digits that did not change point both at the arena's first record - the eight records are loaded unconditionally,
+                //  i.e. together, one round trip; loads behind `if (changed)` were one dependent trip per changed digit)
+                const Cand *const same = d.cand;
+                const Cand *pn0 = same, *pn1 = same, *pn2 = same, *pn3 = same, *po0 = same, *po1 = same, *po2 = same, *po3 = same;
                 auto next = [&](const Cand *&pn, const Cand *&po) {
                     while (j >= 0 && rest) {
                         unsigned int r;
@@ -1659,14 +1693,18 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
                     }
                 };
                 next(pn0, po0); next(pn1, po1); next(pn2, po2); next(pn3, po3);
-                if (pn0) { ad += pn0->ddcal - po0->ddcal; a1 += pn0->h1 - po0->h1; a2 += pn0->h2 - po0->h2; }
-                if (pn1) { ad += pn1->ddcal - po1->ddcal; a1 += pn1->h1 - po1->h1; a2 += pn1->h2 - po1->h2; }
-                if (pn2) { ad += pn2->ddcal - po2->ddcal; a1 += pn2->h1 - po2->h1; a2 += pn2->h2 - po2->h2; }
-                if (pn3) { ad += pn3->ddcal - po3->ddcal; a1 += pn3->h1 - po3->h1; a2 += pn3->h2 - po3->h2; }
+                {
+                    const int dn0 = pn0->ddcal, dn1 = pn1->ddcal, dn2 = pn2->ddcal, dn3 = pn3->ddcal, do0 = po0->ddcal, do1 = po1->ddcal, do2 = po2->ddcal, do3 = po3->ddcal;
+                    const ulonglong2 hn0 = *(const ulonglong2 *)&pn0->h1, hn1 = *(const ulonglong2 *)&pn1->h1, hn2 = *(const ulonglong2 *)&pn2->h1, hn3 = *(const ulonglong2 *)&pn3->h1;
+                    const ulonglong2 ho0 = *(const ulonglong2 *)&po0->h1, ho1 = *(const ulonglong2 *)&po1->h1, ho2 = *(const ulonglong2 *)&po2->h1, ho3 = *(const ulonglong2 *)&po3->h1;
+                    ad += (dn0 - do0) + (dn1 - do1) + (dn2 - do2) + (dn3 - do3);
+                    a1 += (hn0.x - ho0.x) + (hn1.x - ho1.x) + (hn2.x - ho2.x) + (hn3.x - ho3.x);
+                    a2 += (hn0.y - ho0.y) + (hn1.y - ho1.y) + (hn2.y - ho2.y) + (hn3.y - ho3.y);
+                }
                 while (j >= 0 && rest) {
-                    const Cand *pn = nullptr, *po = nullptr;
+                    const Cand *pn = same, *po = same;
                     next(pn, po);
-                    if (pn) { ad += pn->ddcal - po->ddcal; a1 += pn->h1 - po->h1; a2 += pn->h2 - po->h2; }
+                    ad += pn->ddcal - po->ddcal; a1 += pn->h1 - po->h1; a2 += pn->h2 - po->h2;
                 }
             } else {
                 // region list not resident in LDS (more than RL_CAP regions with a choice in this beam)
@@ -1680,7 +1718,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
             }
             h1 = a1 ? a1 : 1; h2 = a2 ? a2 : 1; cd = ad;
             wk_h1[tid] = h1; wk_h2[tid] = h2;
-            cand_new = !seen_lookup(stab, scap, h1, h2);
+            cand_new = !seen_lookup(stab, scap, h1, h2, free_sl);
         }
         // the same structure can come from several parents of this chunk: its first position wins (`seen` order)
         if (cand_new) {
@@ -1712,7 +1750,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
                 d.ch_h[2 * (chb + ci2)] = h1;
                 d.ch_h[2 * (chb + ci2) + 1] = h2;
             } else atomicOr(&d.c->overflow, OVF_SORT);
-            seen_insert(stab, scap, h1, h2);
+            seen_insert_at(stab, scap, h1, h2, free_sl);
         }
         STAMP(9);
         if (hit) {
@@ -1767,12 +1805,13 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
         for (int base = single_from; base < nbeam; base += BS_NT) {
             const int b = base + tid;
             int isnew = 0;
+            uint32_t free_sl = 0;
             uint64_t h1 = 0, h2 = 0;
             if (b < nbeam && pinfo[b].flag == 0) {       // live and cursor == 0
                 h1 = pinfo[b].h1; h2 = pinfo[b].h2;
                 if (h1 == 0) h1 = 1;
                 if (h2 == 0) h2 = 1;
-                isnew = seen_lookup(stab, scap, h1, h2) ? 0 : 1;
+                isnew = seen_lookup(stab, scap, h1, h2, free_sl) ? 0 : 1;
                 // an earlier parent of this phase producing the same structure wins (`seen` order)
                 for (int e = single_from; isnew && e < b; e++)
                     if (pinfo[e].flag == 0) {
@@ -1792,7 +1831,7 @@ __global__ __launch_bounds__(BS_NT) void beam_step_kernel(Dev d, int sort_cap)
                     d.ch_h[2 * (chb + ci2)] = h1;
                     d.ch_h[2 * (chb + ci2) + 1] = h2;
                 } else atomicOr(&d.c->overflow, OVF_SORT);
-                seen_insert(stab, scap, h1, h2);
+                seen_insert_at(stab, scap, h1, h2, free_sl);
             }
             if (b < nbeam && pinfo[b].flag == 0) { d.st[oldbeam[b]].cursor = 1; d.st[oldbeam[b]].total = pinfo[b].total; }
             nchild += tot; nb_branch += tot; scnt += tot;
