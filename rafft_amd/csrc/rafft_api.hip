@@ -427,7 +427,38 @@ struct Caps {
     bool capped;      // a table hit the limit of its 31-bit ids: the job is folded in halves when it has more than one sequence
 };
 
-Caps plan_caps(const Config &cfg, size_t S, size_t sumL, const rafft_params &p, double est)
+// Initial slots of a sequence's `seen` set (round 5).  A set that outgrows its table is rehashed into one of twice the size inside
+// beam_step_kernel - ~100 us of ONE workgroup (dependent compare-and-swap round trips), i.e. of the whole launch when it is the
+// slowest: on the benchmark set every sequence beyond 200 nt grew once or twice (RAFFT_TRACE=2 prints the fill by length) and a
+// fixed 65 536 slots took a sixth off both beam-step kernels.  Sized from the length instead: the upper envelope of the entries at
+// the end of a fold (measured at max_stack 50, max_branch 1000: 1.9 k at 80 nt, 3.3 k at 130, 5.5 k at 300, 7.6 k at 500, 8.8 k at
+// 1000, 20 k at 3000), scaled by the children a step accepts, for a table that is at most half full (the kernel's own growth rule).
+// A set that still outgrows it grows as before.
+static uint32_t seen_slots0(int L, const rafft_params &p, const Config &cfg)
+{
+    if (cfg.seen_fixed) return SEEN0;
+    const double l = (double)L;
+    const double e = l <= 130 ? 26.0 * l : l <= 300 ? 3380.0 + 13.0 * (l - 130) : l <= 500 ? 5590.0 + 10.5 * (l - 300) : l <= 1000 ? 7690.0 + 2.4 * (l - 500) : 8890.0 + 5.6 * (l - 1000);
+    const double per_step = p.max_branch > 0 ? std::min((double)p.max_branch, 8.2 * (double)p.max_stack) : (double)p.max_stack;
+    const double need = 2.0 * (e * std::max(per_step / 410.0, 0.1) + 384.0);
+    uint32_t cap = 2048;
+    while ((double)cap < need && cap < (1u << 22)) cap <<= 1;
+    return cap;
+}
+// ... for a wave: per-sequence slots with the big tables halved until the initial tables fit `budget_slots` (the growth path does the rest)
+static size_t seen_slots0_wave(const int *len, size_t S, const rafft_params &p, const Config &cfg, size_t budget_slots, uint32_t *out)
+{
+    uint32_t limit = 1u << 22;
+    for (;;) {
+        size_t tot = 0;
+        for (size_t i = 0; i < S; i++) { const uint32_t c = std::min(seen_slots0(len[i], p, cfg), limit); if (out) out[i] = c; tot += c; }
+        if (tot <= budget_slots || limit <= SEEN0) return tot;
+        limit >>= 1;
+    }
+}
+#define SEEN0_BUDGET ((size_t)192 << 20)        // slots: 3 GB of initial tables per wave at most
+
+Caps plan_caps(const Config &cfg, size_t S, size_t sumL, const rafft_params &p, double est, double seen0_per_seq)
 {
     // Arena sizes from measured usage on the BASELINE workloads (benchmark set, L 28..2968, ms 50;
     // random L 100..3000, ms 200): per surviving structure about 2 + L/100 regions, 0.6 L region
@@ -464,7 +495,7 @@ Caps plan_caps(const Config &cfg, size_t S, size_t sumL, const rafft_params &p, 
     //  (B + max_branch / 4) slots per sequence, its two 2.9-knt sequences 11.6 x.  A factor of 24 used to reserve 1 MB per
     //  sequence - 12 GB for a merged wave of five batches, and a hipMalloc of that size now and then took seconds.)
     double per_seq_seen = std::min(std::max(14.0 * est * ((double)B + (double)p.max_branch / 4.0), 16384.0), 16777216.0);
-    c.seen = S * (size_t)SEEN0 + (size_t)((double)S * per_seq_seen);
+    c.seen = (size_t)((double)S * seen0_per_seq) + (size_t)((double)S * per_seq_seen);
     c.trec = p.traj ? S * (size_t)(est * 3 + 16) : S + 16;
     c.tsid = c.trec * B + 16;
     c.mat = S * B + 16;
@@ -597,6 +628,8 @@ struct Wave {
     bool longseq = false;         // a sequence longer than LDS_SEQ: its loops' bases are read from HBM, regions beyond 4096 positions exist
     unsigned dedupe_per_cu = 1024 / DEDUPE_NT;
     std::vector<int> off, len;
+    std::vector<uint32_t> seen_cap0;      // initial slots of every sequence's `seen` set (seen_slots0)
+    size_t seen0_total = 0;
     ClsCfg cf[NGEN + 1];          // (cf[NGEN]: the FFT plan of class 3 beside its FFT-free kernel)
     Caps c;
     Dev d;
@@ -671,7 +704,8 @@ int Wave::setup()
     // asynchronous and the scheduler thread goes on to the other waves' steps at once (it used to wait here, 0.6-0.7 ms per
     // wave of five batches); the chunk goes back to the pool with the wave
     const size_t st_codes = 0, st_off = (sumL + 16 + 63) & ~(size_t)63, st_len = st_off + ((S * 4 + 63) & ~(size_t)63),
-                 st_ctr = st_len + ((S * 4 + 63) & ~(size_t)63), st_bytes = st_ctr + sizeof(Counters);
+                 st_ctr = st_len + ((S * 4 + 63) & ~(size_t)63), st_soff = st_ctr + ((sizeof(Counters) + 63) & ~(size_t)63),
+                 st_scap = st_soff + ((S * 8 + 63) & ~(size_t)63), st_bytes = st_scap + S * 4;
     stage = pin_acquire(st_bytes);
     if (!stage.p) return fail(RAFFT_ERR_HIP, "hipHostMalloc failed for the input staging buffer");
     uint8_t *codes = (uint8_t *)stage.p + st_codes;
@@ -700,7 +734,10 @@ int Wave::setup()
             fprintf(stderr, "[rafft] expand class %d: %d threads x %d regions per workgroup, P <= %d, branches <= %d, lags <= %d, LDS %d B%s\n", c, cf[c].nt, cf[c].wpb,
                     cf[c].Pmax, cf[c].brmax, cf[c].Kmax, cf[c].lds, cf[c].nofft ? " (no FFT buffers)" : "");
     merge_target = maxL > CLS2_P / 2 ? 3 : 2;
-    c = plan_caps(cfg, S, sumL, p, est);
+    seen_cap0.resize(S);
+    seen0_total = seen_slots0_wave(len.data(), S, p, cfg, SEEN0_BUDGET, seen_cap0.data());
+    const double seen0_avg = (double)seen0_total / (double)std::max<size_t>(S, 1);
+    c = plan_caps(cfg, S, sumL, p, est, seen0_avg);
     if (std::max((size_t)c.sort_cap * 8, (size_t)24 * 1024) + RL_CAP * 12 + (size_t)(p.max_stack + 4) * (sizeof(ParentInfo) + 16) + 1024 > 150 * 1024)
         return fail(RAFFT_ERR_PARAM, "max_branch + 2*max_stack too large for the LDS-resident beam sort");
     B = (size_t)p.max_stack;
@@ -722,7 +759,7 @@ int Wave::setup()
         Sr = S;
         for (size_t want : tries) {
             if (want <= S) continue;
-            Caps big = plan_caps(cfg, want, (size_t)((double)sumL * (double)want / (double)S), p, est);
+            Caps big = plan_caps(cfg, want, (size_t)((double)sumL * (double)want / (double)S), p, est, seen0_avg);
             if (big.bytes <= (size_t)((double)::g.hbm_total * reserve_frac)) { cr = big; Sr = want; break; }
         }
     }
@@ -839,11 +876,19 @@ int Wave::setup()
     HIPCHK(hipMemcpyAsync(g.seq_off.p, (char *)stage.p + st_off, S * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(g.seq_len.p, (char *)stage.p + st_len, S * 4, hipMemcpyHostToDevice, st));
     memset(&hc, 0, sizeof hc);
-    hc.n_struct = S; hc.seen_top = S * (size_t)SEEN0;
+    {       // the sequences' initial `seen` tables, back to back (seen_slots0)
+        uint64_t *so = (uint64_t *)((char *)stage.p + st_soff);
+        uint32_t *sc = (uint32_t *)((char *)stage.p + st_scap);
+        size_t o = 0;
+        for (size_t i = 0; i < S; i++) { so[i] = o; sc[i] = seen_cap0[i]; o += seen_cap0[i]; }
+        HIPCHK(hipMemcpyAsync(g.seen_off.p, so, S * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(g.seen_cap.p, sc, S * 4, hipMemcpyHostToDevice, st));
+    }
+    hc.n_struct = S; hc.seen_top = seen0_total;
     memcpy((char *)stage.p + st_ctr, &hc, sizeof hc);
     HIPCHK(hipMemcpyAsync(g.counters.p, (char *)stage.p + st_ctr, sizeof hc, hipMemcpyHostToDevice, st));
     if (d.memo) HIPCHK(hipMemsetAsync(g.looptab.p, 0, c.looptab * 8, st));
-    HIPCHK(hipMemsetAsync(g.seen.p, 0, S * (size_t)SEEN0 * 16, st));   // first region of every sequence; later regions are zeroed on allocation
+    HIPCHK(hipMemsetAsync(g.seen.p, 0, seen0_total * 16, st));   // first region of every sequence; later regions are zeroed on allocation
     hipLaunchKernelGGL(init_roots_kernel, dim3((unsigned)S), dim3(64), 0, st, d);
     HIPCHK(hipGetLastError());
     if (seam) HIPCHK(hipStreamSynchronize(st));      // (the seam overwrites the root region with synchronous copies right after)
@@ -1265,8 +1310,8 @@ int Wave::finish_done_body()
     if (d.prof) {
         unsigned long long pv[16];
         HIPCHK(hipMemcpy(pv, d.prof, 128, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[rafft]   product loop detail: head %llu, digits+base %llu, decode+lookup %llu, scans %llu, write+insert %llu\n",
-                pv[6], pv[7], pv[8], pv[9], pv[10]);
+        fprintf(stderr, "[rafft]   product loop detail: head %llu, decode+lookup %llu, scans %llu, write+insert %llu; %llu growths of `seen` in the walk: before %llu, allocation %llu, zero fill %llu, rehash %llu\n",
+                pv[6], pv[8], pv[9], pv[10], pv[14], pv[7], pv[11], pv[12], pv[13]);
         fprintf(stderr, "[rafft] beam_step stamps of the longest sequence (cycles): prepass %llu, product loop %llu, single phase %llu, sort %llu, survivors %llu over %llu steps\n",
                 pv[0], pv[1], pv[2], pv[3], pv[4], pv[5]);
     }
@@ -1278,6 +1323,17 @@ int Wave::finish_done_body()
                 hc.n_struct, c.st, nd.first, (unsigned long long)d.nd_shard_cap, nd.second, po.first, (unsigned long long)d.pos_shard_cap, po.second,
                 br.first, (unsigned long long)d.br_shard_cap, br.second, spr.first, (unsigned long long)d.sp_shard_cap, spr.second,
                 ca.first, (unsigned long long)d.cand_shard_cap, ca.second, pr.first, (unsigned long long)d.prod_shard_cap, pr.second, nl.first, (unsigned long long)d.nd_shard_cap, nl.second, hc.seen_top, c.seen, est);
+    }
+    if (cfg.trace >= 2) {       // how full the `seen` sets got, by sequence length (sizes the initial tables: a growth is a rehash)
+        std::vector<uint32_t> cnt(S), cap(S);
+        HIPCHK(hipMemcpy(cnt.data(), d.seen_cnt, S * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(cap.data(), d.seen_cap, S * 4, hipMemcpyDeviceToHost));
+        const int edges[] = {0, 80, 100, 130, 200, 300, 500, 1000, 2000, 1 << 30};
+        for (int e = 0; e + 1 < (int)(sizeof(edges) / sizeof(edges[0])); e++) {
+            unsigned long long n = 0, sum = 0, mxc = 0, grown = 0, slots = 0;
+            for (size_t i = 0; i < S; i++) if (len[i] > edges[e] && len[i] <= edges[e + 1]) { n++; sum += cnt[i]; mxc = std::max<unsigned long long>(mxc, cnt[i]); grown += cap[i] > seen_cap0[i] ? 1 : 0; slots += cap[i]; }
+            if (n) fprintf(stderr, "[rafft] seen sets, %d < L <= %d: %llu sequences, mean %llu entries, max %llu, %llu grew, %llu slots at the end\n", edges[e], edges[e + 1], n, sum / n, mxc, grown, slots);
+        }
     }
     if (cfg.trace) fprintf(stderr, "[rafft] host time inside issue_step %.3f ms, inside after_beam (incl. nested issue_step and this tail) %.3f ms\n", ms_issue, ms_after);
     if (cfg.trace) fprintf(stderr, "[rafft] wave S=%zu setup %.2f ms, loop %.2f ms (%d steps), tail %.2f ms (counters %.3f, records+gather %.3f, rows out %.3f incl. %.1f MB D2H)\n",
@@ -1651,7 +1707,10 @@ static void scheduler_main()
                 }
                 size_t sl_ = 0;
                 for (auto &sq : job.seqs) sl_ += sq.len;
-                const Caps cc = plan_caps(job.members[0]->cfg, job.seqs.size(), sl_, job.members[0]->p, job.est);
+                std::vector<int> lens_(job.seqs.size());
+                for (size_t i = 0; i < job.seqs.size(); i++) lens_[i] = job.seqs[i].len;
+                const double s0_ = (double)seen_slots0_wave(lens_.data(), lens_.size(), job.members[0]->p, job.members[0]->cfg, SEEN0_BUDGET, nullptr) / (double)std::max<size_t>(lens_.size(), 1);
+                const Caps cc = plan_caps(job.members[0]->cfg, job.seqs.size(), sl_, job.members[0]->p, job.est, s0_);
                 size_t others = 0;
                 for (int k = 0; k < MAX_PIPES; k++) if (k != w) others += g.ws[k].bytes();
                 const size_t budget = (size_t)((double)g.hbm_total * 0.55 / 2.0);

@@ -75,7 +75,7 @@ struct Config {
     int test_hard_fail = -1;   // RAFFT_TEST_HARD_FAIL  H  a wave of exactly this many sequences fails hard
     int test_max_prod = 0;     // RAFFT_TEST_MAX_PROD   H  short productive-region lists of this length (overflow early)
     int test_ovf_at = -1;      // RAFFT_TEST_OVF_AT     H  pretend an arena overflowed at this step of the first attempt
-    int pad_ = 0;
+    int seen_fixed = 0;        // RAFFT_SEEN_FIXED    X  1: every `seen` set starts at SEEN0 slots instead of a table sized from the length (tests: the growth path)
 };
 static_assert(sizeof(Config) == 8 * 8 + 4 * 48, "Config: 8-byte fields first, an even number of ints - no padding (same_config compares bytes)");
 
@@ -94,7 +94,7 @@ inline Config read_config()
     I("RAFFT_SLAB", c.slab); I("RAFFT_FETCH", c.fetch); I("RAFFT_TAPER", c.taper); I("RAFFT_MAT4", c.mat4);
     I("RAFFT_DEDUPE_PER_CU", c.dedupe_per_cu); I("RAFFT_WIDE_BELOW", c.wide_below); I("RAFFT_MERGE_BELOW", c.merge_below); I("RAFFT_MERGE2_BELOW", c.merge2_below);
     F("RAFFT_RESERVE_FRAC", c.reserve_frac); I("RAFFT_SPLIT", c.split); B("RAFFT_NO_HARVEST", c.no_harvest);
-    I("RAFFT_STEP_AHEAD", c.step_ahead); I("RAFFT_SERIAL", c.serial);
+    I("RAFFT_STEP_AHEAD", c.step_ahead); I("RAFFT_SERIAL", c.serial); I("RAFFT_SEEN_FIXED", c.seen_fixed);
     I("RAFFT_TRACE", c.trace); if (getenv("RAFFT_TRACE") && c.trace < 1) c.trace = 1;      // (set to anything: at least the summaries)
     I("RAFFT_SPANS", c.spans); I("RAFFT_REP", c.rep); I("RAFFT_TWICE", c.twice); I("RAFFT_PROF_SEQ", c.prof_seq);
     I("RAFFT_MAX_WAVES", c.max_waves); L("RAFFT_MERGE_SEQS", c.merge_seqs); I("RAFFT_ADMIT_BELOW", c.admit_below); I("RAFFT_TAIL_SLOT", c.tail_slot);

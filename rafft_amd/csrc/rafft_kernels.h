@@ -51,7 +51,9 @@ struct alignas(16) Cand {
 static_assert(sizeof(Cand) == 32, "Cand must be 32 bytes");
 
 #define NSHARD 64
+#ifndef SEEN0
 #define SEEN0 8192      // initial slots of a sequence's `seen` set (grows x2 by rehash)
+#endif
 #define NCLS 6          // expand size classes: 0-3 the general kernel (NGEN), 4-5 the small-region kernel (teams of 16 / 32 lanes)
 #define NGEN 4
 #define PROF_E 96      // RAFFT_TRACE=3: 64-bit diagnostic slots per expand class (Dev::prof_e)

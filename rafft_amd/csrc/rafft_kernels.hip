@@ -1387,6 +1387,30 @@ __device__ inline void seen_insert(uint64_t *tab, uint32_t cap, uint64_t h1, uin
 }
 
 
+// move every key of a sequence's `seen` set into a bigger, zeroed table.  (round 5: four slots per thread read together and their
+// compare-and-swaps issued together - one slot at a time was a chain of two or three dependent round trips per slot, 32 slots per
+// thread for the first growth: ~60 us of a workgroup's ~250)
+template <int NT>
+__device__ inline void seen_rehash(const uint64_t *stab, uint32_t scap, uint64_t *ntab, uint32_t ncap, int tid)
+{
+    const ulonglong2 *src = (const ulonglong2 *)stab;
+    const uint32_t mask = ncap - 1;
+    for (uint32_t base = 0; base < scap; base += NT * 4) {
+        ulonglong2 e[4];
+        unsigned long long old[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t i = base + (uint32_t)u * NT + (uint32_t)tid; e[u] = i < scap ? src[i] : make_ulonglong2(0ULL, 0ULL); }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { old[u] = 1; if (e[u].x) old[u] = atomicCAS((unsigned long long *)&ntab[2 * (uint64_t)((uint32_t)e[u].x & mask)], 0ULL, (unsigned long long)e[u].x); }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (e[u].x) {
+                if (old[u] == 0) ntab[2 * (uint64_t)((uint32_t)e[u].x & mask) + 1] = e[u].y;
+                else seen_insert(ntab, ncap, e[u].x, e[u].y);        // home slot taken: the probing insert
+            }
+    }
+}
+
 struct ParentInfo {         // filled by the parallel prepass, one entry per beam member
     unsigned long long total, cur;        // product size, cursor
     unsigned long long h1, h2;            // pair-set hash of combo 0 (absolute)
@@ -1628,6 +1652,8 @@ __global__ __launch_bounds__(BS_NT, BS_NT == 256 ? 5 : 1) void beam_step_kernel(
         if ((unsigned long long)(scnt + chunk) * 2 > scap) {   // grow the seen set (rehash into a zeroed region)
             uint32_t ncap = scap;
             while ((unsigned long long)(scnt + BS_NT) * 2 > ncap) ncap <<= 1;
+            STAMP(7);
+            if (prof) atomicAdd(&d.prof[14], 1ULL);
             if (tid == 0) {
                 unsigned long long o = atomicAdd(&d.c->seen_top, (unsigned long long)ncap);
                 if (o + ncap > d.seen_cap_total) { atomicOr(&d.c->overflow, OVF_SEEN); *(unsigned long long *)&sh[8] = ~0ULL; }
@@ -1638,13 +1664,13 @@ __global__ __launch_bounds__(BS_NT, BS_NT == 256 ? 5 : 1) void beam_step_kernel(
             __syncthreads();
             if (o == ~0ULL) { d.done[sq] = 1; return; }
             uint64_t *ntab = d.seen + 2 * o;
-            for (uint32_t i = tid; i < 2 * ncap; i += BS_NT) ntab[i] = 0;   // arena is not pre-zeroed
+            STAMP(11);
+            for (uint32_t i = tid; i < ncap; i += BS_NT) ((ulonglong2 *)ntab)[i] = make_ulonglong2(0ULL, 0ULL);   // arena is not pre-zeroed
             __syncthreads();
-            for (uint32_t i = tid; i < scap; i += BS_NT) {
-                uint64_t k1 = stab[2 * (uint64_t)i];
-                if (k1) seen_insert(ntab, ncap, k1, stab[2 * (uint64_t)i + 1]);
-            }
+            STAMP(12);
+            seen_rehash<BS_NT>(stab, scap, ntab, ncap, tid);
             __syncthreads();
+            STAMP(13);
             stab = ntab; scap = ncap;
             if (tid == 0) { d.seen_off[sq] = o; d.seen_cap[sq] = ncap; }
         }
@@ -1792,12 +1818,9 @@ __global__ __launch_bounds__(BS_NT, BS_NT == 256 ? 5 : 1) void beam_step_kernel(
             __syncthreads();
             if (o == ~0ULL) { d.done[sq] = 1; return; }
             uint64_t *ntab = d.seen + 2 * o;
-            for (uint32_t i = tid; i < 2 * ncap; i += BS_NT) ntab[i] = 0;       // arena is not pre-zeroed
+            for (uint32_t i = tid; i < ncap; i += BS_NT) ((ulonglong2 *)ntab)[i] = make_ulonglong2(0ULL, 0ULL);   // arena is not pre-zeroed
             __syncthreads();
-            for (uint32_t i = tid; i < scap; i += BS_NT) {
-                uint64_t k1 = stab[2 * (uint64_t)i];
-                if (k1) seen_insert(ntab, ncap, k1, stab[2 * (uint64_t)i + 1]);
-            }
+            seen_rehash<BS_NT>(stab, scap, ntab, ncap, tid);
             __syncthreads();
             stab = ntab; scap = ncap;
             if (tid == 0) { d.seen_off[sq] = o; d.seen_cap[sq] = ncap; }
@@ -2551,7 +2574,7 @@ __global__ void init_roots_kernel(Dev d)
         d.nd[sq].ncand = -1; d.nd[sq].cand = 0;
         d.beam[(size_t)sq * d.B] = sq; d.beam_n[sq] = 1; d.nsteps[sq] = 0;
         d.done[sq] = L > 0 ? 0 : 1;
-        d.seen_off[sq] = (uint64_t)sq * SEEN0; d.seen_cap[sq] = SEEN0; d.seen_cnt[sq] = 0;   // zeroed by the host memset
+        d.seen_cnt[sq] = 0;       // (seen_off / seen_cap: uploaded by the host - tables sized from the lengths, zeroed by its memset)
         if (L > 0) {
             int cls = node_class(L, L, 0, 0, d.cls1_P, d.cls1_br);
             unsigned int w = atomicAdd(&d.c->n_work[cls].v, 1u);

@@ -375,3 +375,26 @@ def test_gpu_long_stems_vs_oracle():
     for k, (fin, traj) in enumerate(got):
         assert [[(x.str_struct, x.dcal) for x in st] for st in traj] == want[k], (k, seqs[k])
     assert any(x.str_struct.count("(") >= 60 for fin, _ in got for x in fin)       # the 60-pair stems do form
+
+
+def test_gpu_seen_tables_sized_from_the_length_and_grown(monkeypatch):
+    """round 5: a sequence's `seen` set starts in a table sized from its length (seen_slots0, rafft_api.hip) so that the benchmark set
+    folds without a rehash; a set that outgrows its table is still rehashed into one of twice the size inside beam_step_kernel.  Both
+    sides: random sequences of 60-900 nt with the default tables, with fixed 8192-slot tables (RAFFT_SEEN_FIXED=1: everything beyond
+    ~200 nt grows once or twice) and at max_stack 150 (three times the children per step the sizing was measured at) - same beams, and
+    the oracle's for the shorter ones"""
+    rng = np.random.default_rng(77)
+    seqs = ["".join(rng.choice(list("ACGU"), int(L))) for L in (60, 90, 120, 150, 220, 260, 330, 420, 640, 900)]
+    base = rafft_amd.fold_batch(seqs, 100, 50, 1000)
+    from _oracle_pool import fold_many
+    want = fold_many([(s, 100, 50, 1000, False) for s in seqs[:6]])
+    for k in range(6):
+        assert [(x.str_struct, x.dcal) for x in base[k]] == want[k], k
+    monkeypatch.setenv("RAFFT_SEEN_FIXED", "1")
+    fixed = rafft_amd.fold_batch(seqs, 100, 50, 1000)
+    monkeypatch.delenv("RAFFT_SEEN_FIXED")
+    assert [[(x.str_struct, x.dcal) for x in f] for f in fixed] == [[(x.str_struct, x.dcal) for x in f] for f in base]
+    wide = rafft_amd.fold_batch(seqs[:8], 100, 150, 1000)
+    monkeypatch.setenv("RAFFT_SEEN_FIXED", "1")
+    wide_fixed = rafft_amd.fold_batch(seqs[:8], 100, 150, 1000)
+    assert [[(x.str_struct, x.dcal) for x in f] for f in wide] == [[(x.str_struct, x.dcal) for x in f] for f in wide_fixed]
