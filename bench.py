@@ -661,6 +661,8 @@ def main():
             "weak_value": round(n * world * args.steps / el, 2), "weak_steps": args.steps, "weak_sequences_per_step": n * world,
             "ranks": ranks_info,
             "allocations_in_timed_region": timed_allocs,
+            # waves of the timed region that overflowed an HBM arena and were folded again with larger ones (0 in a healthy run)
+            "regrows_in_timed_region": int(agg.get("n_regrows", 0)),
             "cpu_baseline": cpu,
             "parity_vs_cpu": (dict(parity, guessed_share_of_final_structures=guessed) if parity is not None else
                               ({"guessed_share_of_final_structures": guessed} if guessed is not None else None)),

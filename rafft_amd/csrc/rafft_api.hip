@@ -1681,9 +1681,13 @@ static void scheduler_main()
                 }
                 const bool job_heavy = front.seqs.size() >= 256;
                 if (job_heavy && heavy_running) break;
-                int w = -1;                                       // a free workspace, this lane's parity first
-                for (int k = 0; k < MAX_PIPES && w < 0; k++) if (!slot[k].wave && (k & 1) == ln) w = k;
-                for (int k = 0; k < MAX_PIPES && w < 0; k++) if (!slot[k].wave) w = k;
+                // a free workspace: the biggest one for a bulk wave, the smallest for the others.  (Round 5: by slot parity - "this lane's
+                // first" - a bulk wave now and then landed on the workspace the long-tail waves had used so far and grew all its 43
+                // buffers to bulk size, 23.6 GB of hipMalloc in the middle of a stream of batches - one run in four of the bench, and
+                // one hipMalloc in a few hundred takes half a second.  By size the workspaces settle: three big ones, one small.)
+                int w = -1;
+                for (int k = 0; k < MAX_PIPES; k++)
+                    if (!slot[k].wave && (w < 0 || (job_heavy ? g.ws[k].bytes() > g.ws[w].bytes() : g.ws[k].bytes() < g.ws[w].bytes()))) w = k;
                 if (w < 0) break;
                 // continuous batching: queued jobs with the same parameters join this one (first regrowths stay alone)
                 Job job = std::move(front);
