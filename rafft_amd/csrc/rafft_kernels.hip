@@ -2014,8 +2014,12 @@ __device__ inline MatDesc mat_describe(const Dev &d, int pn, unsigned long long 
     MatDesc m;
     m.pn = pn;
     const Cand cd = d.cand[cidx];
-    m.n = d.nd[pn].n; m.nbr = d.nd[pn].nbr; m.ci = d.nd[pn].ci; m.cj = d.nd[pn].cj;
-    m.srcpos = d.nd[pn].pos; m.srcbr = d.nd[pn].br;
+    // (the header as three 16-byte loads issued together: as single fields the compiler loaded `nbr` where it is first used - after the
+    //  loads of the four stem positions below, whose round trip it then waited for before the arena allocations could be issued)
+    const uint4 *hp = (const uint4 *)&d.nd[pn];
+    const uint4 hq0 = hp[0], hq1 = hp[1], hq2 = hp[2];      // seq pdcal n ci | cj nbr ncand L | pos br
+    m.n = (int)hq0.z; m.ci = (int)hq0.w; m.cj = (int)hq1.x; m.nbr = (int)hq1.y;
+    m.srcpos = (unsigned long long)hq2.x | ((unsigned long long)hq2.y << 32); m.srcbr = (unsigned long long)hq2.z | ((unsigned long long)hq2.w << 32);
     m.cidx = cidx;
     m.mi = cd.mi; m.mj = cd.mj; m.nb = cd.nb;
     const uint16_t *pp = d.pos + m.srcpos;
@@ -2024,12 +2028,85 @@ __device__ inline MatDesc mat_describe(const Dev &d, int pn, unsigned long long 
     m.a0 = pp[m.mi] & pm; m.b0 = pp[m.mj] & pm; m.ao = (int)rao & pm; m.bo = (int)rbo & pm;
     m.newbr = rao | (rbo << 16);          // (with Dev::pos_packed the base codes ride in bits 12-15 and 28-31)
     cd.get_cuts(m.lo0, m.hi0, m.loo, m.hio);      // where the stem cuts the branch list (found by expand_kernel)
-    m.flags = 0; m.win = 0; m.nnod = 0; m.npos_in = m.npos_out = m.nbr_in = m.nbr_out = 0;
-    if (m.mj - m.mi > 1) { m.flags |= 1; m.nnod++; m.npos_in = m.mj - m.mi - 1; m.nbr_in = m.hi0 - m.lo0; }
-    if (m.mi - (m.nb - 1) > 0 || m.mj + m.nb < m.n) {
-        m.flags |= 2; m.nnod++; m.npos_out = (m.mi - m.nb + 1) + (m.n - (m.mj + m.nb)); m.nbr_out = m.loo + 1 + (m.nbr - m.hio);
-    }
+    // (no branches: every header field is used right here, so all of them are loaded together - see above)
+    const bool has_in = m.mj - m.mi > 1, has_out = m.mi - (m.nb - 1) > 0 || m.mj + m.nb < m.n;
+    m.win = 0;
+    m.flags = (has_in ? 1 : 0) | (has_out ? 2 : 0); m.nnod = (has_in ? 1 : 0) + (has_out ? 1 : 0);
+    m.npos_in = has_in ? m.mj - m.mi - 1 : 0; m.nbr_in = has_in ? m.hi0 - m.lo0 : 0;
+    m.npos_out = has_out ? (m.mi - m.nb + 1) + (m.n - (m.mj + m.nb)) : 0; m.nbr_out = has_out ? m.loo + 1 + (m.nbr - m.hio) : 0;
     return m;
+}
+
+// The flat copies of one tile of the materialize kernels: unpaired positions and branch helices of the regions created, pairs of
+// the stems.  (Round 5: U elements per lane are located and LOADED before the first of them is stored - with one element per
+// iteration every load was waited for before its store and the next load issued after it: a dependent HBM round trip per 16 (64)
+// elements, five or six per structure on the benchmark set, a dozen and more on long sequences.)
+// `l`: my lane in the team, STR lanes; descriptor kk of the tile sits at index kb + kk of the k_* arrays.
+template <int STR, int U>
+__device__ __forceinline__ void mat_copy_tile(const Dev &d, int l, int kb, int kt, const int *ps, const int *bs, const int *ns,
+                                              const unsigned long long *k_srcpos, const unsigned long long *k_srcbr, const int *k_mi, const int *k_mj,
+                                              const int *k_nb, const int *k_lo0, const int *k_loo, const int *k_hio, const int *k_newbr,
+                                              int tp, int tbr, int ts, unsigned long long pdst, unsigned long long bdst, unsigned long long sdst, int pmask)
+{
+    for (int f0 = l; f0 < tp; f0 += STR * U) {           // unpaired positions of the regions created here
+        uint32_t v[U];          // (32-bit: two 16-bit values packed into one register are a wait after every load)
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int f = f0 + u * STR;
+            v[u] = 0;
+            if (f < tp) {
+                int lo = 0, hi = 2 * kt - 1;             // last slot starting at or before f (empty slots share starts)
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (ps[mid] <= f) lo = mid; else hi = mid - 1; }
+                const int kk = kb + (lo >> 1), off = f - ps[lo];
+                const uint16_t *pp = d.pos + k_srcpos[kk];
+                int src;
+                if (!(lo & 1)) src = k_mi[kk] + 1 + off;
+                else { const int left = k_mi[kk] - k_nb[kk] + 1; src = off < left ? off : k_mj[kk] + k_nb[kk] + (off - left); }
+                v[u] = pp[src];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int f = f0 + u * STR; if (f < tp) d.pos[pdst + f] = (uint16_t)v[u]; }
+    }
+    for (int f0 = l; f0 < tbr; f0 += STR * U) {          // their branch helices
+        uint32_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int f = f0 + u * STR;
+            v[u] = 0;
+            if (f < tbr) {
+                int lo = 0, hi = 2 * kt - 1;
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (bs[mid] <= f) lo = mid; else hi = mid - 1; }
+                const int kk = kb + (lo >> 1), off = f - bs[lo];
+                const uint32_t *bb = d.br + k_srcbr[kk];
+                if (!(lo & 1)) v[u] = bb[k_lo0[kk] + off];
+                else {
+                    const int loo = k_loo[kk];
+                    v[u] = off < loo ? bb[off] : off == loo ? (uint32_t)k_newbr[kk] : bb[k_hio[kk] + (off - loo - 1)];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int f = f0 + u * STR; if (f < tbr) d.br[bdst + f] = v[u]; }
+    }
+    // the pairs of the stems (rafft/rafft.py:97,127-128 marks them in the parent's dot-bracket row; here the row is implicit)
+    for (int f0 = l; f0 < ts; f0 += STR * U) {
+        uint32_t va[U], vb[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int f = f0 + u * STR;
+            va[u] = 0; vb[u] = 0;
+            if (f < ts) {
+                int lo = 0, hi = kt - 1;
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (ns[mid] <= f) lo = mid; else hi = mid - 1; }
+                const int t = f - ns[lo];
+                const uint16_t *pp = d.pos + k_srcpos[kb + lo];
+                va[u] = pp[k_mi[kb + lo] - t]; vb[u] = pp[k_mj[kb + lo] + t];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int f = f0 + u * STR; if (f < ts) d.sp[sdst + f] = (uint32_t)(va[u] & pmask) | ((uint32_t)(vb[u] & pmask) << 16); }
+    }
 }
 
 #ifndef RAFFT_MAT_WAVES
@@ -2202,39 +2279,8 @@ __global__ __launch_bounds__(MAT_NT, RAFFT_MAT_WAVES) void materialize_kernel(De
         }
         __syncthreads();
         MSTAMP(4);   // pass 2 descriptors + records
-        // unpaired positions of the regions created here
-        for (int f = tid; f < tp; f += MAT_NT) {
-            int lo = 0, hi = 2 * kt - 1;                 // last slot starting at or before f (empty slots share starts)
-            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (ps[mid] <= f) lo = mid; else hi = mid - 1; }
-            const int kk = lo >> 1, off = f - ps[lo];
-            const uint16_t *pp = d.pos + k_srcpos[kk];
-            int src;
-            if (!(lo & 1)) src = k_mi[kk] + 1 + off;
-            else { const int left = k_mi[kk] - k_nb[kk] + 1; src = off < left ? off : k_mj[kk] + k_nb[kk] + (off - left); }
-            d.pos[pbase + run_pos + f] = pp[src];
-        }
-        // their branch helices
-        for (int f = tid; f < tb; f += MAT_NT) {
-            int lo = 0, hi = 2 * kt - 1;
-            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (bs[mid] <= f) lo = mid; else hi = mid - 1; }
-            const int kk = lo >> 1, off = f - bs[lo];
-            const uint32_t *bb = d.br + k_srcbr[kk];
-            uint32_t v;
-            if (!(lo & 1)) v = bb[k_lo0[kk] + off];
-            else {
-                const int loo = k_loo[kk];
-                v = off < loo ? bb[off] : off == loo ? (uint32_t)k_newbr[kk] : bb[k_hio[kk] + (off - loo - 1)];
-            }
-            d.br[bbase + run_br + f] = v;
-        }
-        // the pairs of the stems (rafft/rafft.py:97,127-128 marks them in the parent's dot-bracket row; here the row is implicit)
-        for (int f = tid; f < ts; f += MAT_NT) {
-            int lo = 0, hi = kt - 1;
-            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (ns[mid] <= f) lo = mid; else hi = mid - 1; }
-            const int t = f - ns[lo];
-            const uint16_t *pp = d.pos + k_srcpos[lo];
-            d.sp[sbase + run_sp + f] = (uint32_t)(pp[k_mi[lo] - t] & pmask) | ((uint32_t)(pp[k_mj[lo] + t] & pmask) << 16);
-        }
+        mat_copy_tile<MAT_NT, 4>(d, tid, 0, kt, ps, bs, ns, k_srcpos, k_srcbr, k_mi, k_mj, k_nb, k_lo0, k_loo, k_hio, k_newbr, tp, tb, ts,
+                                 pbase + run_pos, bbase + run_br, sbase + run_sp, pmask);
         run_nodes += tn; run_new += tw; run_pos += tp; run_br += tb; run_sp += ts;
         __syncthreads();
         MSTAMP(5);   // region copies
@@ -2412,37 +2458,9 @@ __global__ __launch_bounds__(64, RAFFT_MAT_WAVES) void materialize_team_kernel(D
             }
         }
         wave_sync();
-        // unpaired positions of the regions created here (descriptor kk of my team sits at lane tb + kk)
-        for (int f = tl; f < tp; f += MAT4_TL) {
-            int lo = 0, hi = 2 * kt - 1;                 // last slot starting at or before f (empty slots share starts)
-            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (ps[mid] <= f) lo = mid; else hi = mid - 1; }
-            const int kk = tb + (lo >> 1), off = f - ps[lo];
-            const uint16_t *pp = d.pos + k_srcpos[kk];
-            int src;
-            if (!(lo & 1)) src = k_mi[kk] + 1 + off;
-            else { const int left = k_mi[kk] - k_nb[kk] + 1; src = off < left ? off : k_mj[kk] + k_nb[kk] + (off - left); }
-            d.pos[pbase + run_pos + f] = pp[src];
-        }
-        for (int f = tl; f < tbr; f += MAT4_TL) {         // their branch helices
-            int lo = 0, hi = 2 * kt - 1;
-            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (bs[mid] <= f) lo = mid; else hi = mid - 1; }
-            const int kk = tb + (lo >> 1), off = f - bs[lo];
-            const uint32_t *bb = d.br + k_srcbr[kk];
-            uint32_t v;
-            if (!(lo & 1)) v = bb[k_lo0[kk] + off];
-            else {
-                const int loo = k_loo[kk];
-                v = off < loo ? bb[off] : off == loo ? (uint32_t)k_newbr[kk] : bb[k_hio[kk] + (off - loo - 1)];
-            }
-            d.br[bbase + run_br + f] = v;
-        }
-        for (int f = tl; f < ts; f += MAT4_TL) {          // the pairs of the stems
-            int lo = 0, hi = kt - 1;
-            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (ns[mid] <= f) lo = mid; else hi = mid - 1; }
-            const int t = f - ns[lo];
-            const uint16_t *pp = d.pos + k_srcpos[tb + lo];
-            d.sp[sbase + run_sp + f] = (uint32_t)(pp[k_mi[tb + lo] - t] & pmask) | ((uint32_t)(pp[k_mj[tb + lo] + t] & pmask) << 16);
-        }
+        // (descriptor kk of my team sits at lane tb + kk)
+        mat_copy_tile<MAT4_TL, 4>(d, tl, tb, kt, ps, bs, ns, k_srcpos, k_srcbr, k_mi, k_mj, k_nb, k_lo0, k_loo, k_hio, k_newbr, tp, tbr, ts,
+                                  pbase + run_pos, bbase + run_br, sbase + run_sp, pmask);
         run_nodes += tn; run_new += tw; run_pos += tp; run_br += tbr; run_sp += ts;
         wave_sync();
     }
