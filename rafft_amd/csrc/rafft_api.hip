@@ -68,6 +68,8 @@ struct Workspace {
         seen_cap, seen_cnt, st, prod, nd, nlist, nd_slot, cslot, pos, br, sp, cand, looptab, trec, tsid,
         work0, work1, work2, work3, work4, work5, mat, counters,
         row_sid, row_off, out_db, out_dcal, row_off2, out_db2, out_dcal2, dbg, big;
+    // every buffer of this workspace at least as big as its counterpart in `o` (defined after ensure())
+    int match(const Workspace &o);
     void release_buffers()
     {
         for (Buf *b : {&codes, &seq_off, &seq_len, &beam, &beam_n, &done, &nsteps, &ch_parent, &ch_combo, &ch_dcal, &ch_h, &seen,
@@ -127,14 +129,14 @@ Ctx &g = *new Ctx();
 // allocations made so far: device buffers (calls, bytes, slowest call in ms) and pinned chunks (calls, bytes) - rafft_alloc_counters()
 std::atomic<unsigned long long> g_dev_allocs{0}, g_dev_bytes{0}, g_dev_worst_us{0}, g_pin_allocs{0}, g_pin_bytes{0};
 
-int ensure(Buf &b, size_t bytes)
+int ensure(Buf &b, size_t bytes, bool exact = false)
 {
     if (bytes <= b.cap) return 0;
     const auto t0_ = std::chrono::steady_clock::now();
     const size_t old_cap = b.cap;
     if (b.p) { std::lock_guard<std::mutex> lk(g.gc_mu); g.garbage.push_back(b.p); b.p = nullptr; b.cap = 0; }
     // a buffer that had to grow once will grow again: leave room (at most 256 MB of it)
-    size_t want = bytes + std::min<size_t>(bytes / (old_cap ? 2 : 8), (size_t)256 << 20) + 256;
+    size_t want = exact ? bytes : bytes + std::min<size_t>(bytes / (old_cap ? 2 : 8), (size_t)256 << 20) + 256;
     want = (want + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);      // whole 2 MiB fragments
     hipError_t e = hipMalloc(&b.p, want);
     if (e != hipSuccess) {
@@ -160,6 +162,19 @@ int ensure(Buf &b, size_t bytes)
         return fail(RAFFT_ERR_HIP, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
     }
     b.cap = want;
+    return 0;
+}
+
+int Workspace::match(const Workspace &o)
+{
+    Buf *mine[] = {&codes, &seq_off, &seq_len, &beam, &beam_n, &done, &nsteps, &ch_parent, &ch_combo, &ch_dcal, &ch_h, &seen,
+                   &seen_off, &seen_cap, &seen_cnt, &st, &prod, &nd, &nlist, &nd_slot, &cslot, &pos, &br, &sp, &cand, &looptab, &trec, &tsid,
+                   &work0, &work1, &work2, &work3, &work4, &work5, &mat, &counters, &row_sid, &row_off, &out_db, &out_dcal, &row_off2, &out_db2, &out_dcal2};
+    const Buf *theirs[] = {&o.codes, &o.seq_off, &o.seq_len, &o.beam, &o.beam_n, &o.done, &o.nsteps, &o.ch_parent, &o.ch_combo, &o.ch_dcal, &o.ch_h, &o.seen,
+                           &o.seen_off, &o.seen_cap, &o.seen_cnt, &o.st, &o.prod, &o.nd, &o.nlist, &o.nd_slot, &o.cslot, &o.pos, &o.br, &o.sp, &o.cand, &o.looptab, &o.trec, &o.tsid,
+                           &o.work0, &o.work1, &o.work2, &o.work3, &o.work4, &o.work5, &o.mat, &o.counters, &o.row_sid, &o.row_off, &o.out_db, &o.out_dcal, &o.row_off2, &o.out_db2, &o.out_dcal2};
+    for (size_t i = 0; i < sizeof(mine) / sizeof(mine[0]); i++)
+        if (int rc = ensure(*mine[i], theirs[i]->cap, true)) return rc;
     return 0;
 }
 
@@ -872,25 +887,43 @@ int Wave::setup()
 
     const double ms_plan = since(tw0);
     hipStream_t st = g.stream;
-    HIPCHK(hipMemcpyAsync(g.codes.p, codes, sumL + 16, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(g.seq_off.p, (char *)stage.p + st_off, S * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(g.seq_len.p, (char *)stage.p + st_len, S * 4, hipMemcpyHostToDevice, st));
+    // (RAFFT_TRACE: a call of this section that keeps the scheduler thread for more than a millisecond is named - every wave in flight waits)
+    double t_mark = ms_plan;
+    auto slow_call = [&](const char *what) {
+        if (!cfg.trace) return;
+        const double now = since(tw0);
+        if (now - t_mark > 1.0) fprintf(stderr, "[rafft] setup of a wave of %zu sequences: %s kept the host for %.3f ms\n", S, what, now - t_mark);
+        t_mark = now;
+    };
     memset(&hc, 0, sizeof hc);
-    {       // the sequences' initial `seen` tables, back to back (seen_slots0)
+    hc.n_struct = S; hc.seen_top = seen0_total;
+    memcpy((char *)stage.p + st_ctr, &hc, sizeof hc);
+    {
+        // the sequences' initial `seen` tables, back to back (seen_slots0)
         uint64_t *so = (uint64_t *)((char *)stage.p + st_soff);
         uint32_t *sc = (uint32_t *)((char *)stage.p + st_scap);
         size_t o = 0;
         for (size_t i = 0; i < S; i++) { so[i] = o; sc[i] = seen_cap0[i]; o += seen_cap0[i]; }
-        HIPCHK(hipMemcpyAsync(g.seen_off.p, so, S * 8, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(g.seen_cap.p, sc, S * 4, hipMemcpyHostToDevice, st));
+        // base codes | offsets | lengths | seen-table offsets | sizes | counters image: one kernel reads them out of the pinned chunk
+        StageIn si;
+        memset(&si, 0, sizeof si);
+        auto seg = [&](size_t off, void *dst, size_t bytes) {
+            si.src[si.n] = (const uint32_t *)((const char *)stage.p + off); si.dst[si.n] = (uint32_t *)dst; si.words[si.n] = (bytes + 3) / 4; si.n++;
+        };
+        seg(st_codes, g.codes.p, sumL + 16); seg(st_off, g.seq_off.p, S * 4); seg(st_len, g.seq_len.p, S * 4);
+        seg(st_soff, g.seen_off.p, S * 8); seg(st_scap, g.seen_cap.p, S * 4); seg(st_ctr, g.counters.p, sizeof hc);
+        const size_t words = (sumL + 16 + 3) / 4;
+        hipLaunchKernelGGL(stage_in_kernel, dim3((unsigned)std::min<size_t>((words + 255) / 256, 1024)), dim3(256), 0, st, si);
+        HIPCHK(hipGetLastError());
     }
-    hc.n_struct = S; hc.seen_top = seen0_total;
-    memcpy((char *)stage.p + st_ctr, &hc, sizeof hc);
-    HIPCHK(hipMemcpyAsync(g.counters.p, (char *)stage.p + st_ctr, sizeof hc, hipMemcpyHostToDevice, st));
+    slow_call("the launch of stage_in_kernel");
     if (d.memo) HIPCHK(hipMemsetAsync(g.looptab.p, 0, c.looptab * 8, st));
+    slow_call("the memset of the loop table");
     HIPCHK(hipMemsetAsync(g.seen.p, 0, seen0_total * 16, st));   // first region of every sequence; later regions are zeroed on allocation
+    slow_call("the memset of the seen tables");
     hipLaunchKernelGGL(init_roots_kernel, dim3((unsigned)S), dim3(64), 0, st, d);
     HIPCHK(hipGetLastError());
+    slow_call("the launch of init_roots_kernel");
     if (seam) HIPCHK(hipStreamSynchronize(st));      // (the seam overwrites the root region with synchronous copies right after)
     // beam_step_kernel LDS: time-shared region 0 (walk scratch 24 B/thread, then sort keys), region list, per-member records
     for (int v = 0; v < 2; v++) {
@@ -1681,13 +1714,15 @@ static void scheduler_main()
                 }
                 const bool job_heavy = front.seqs.size() >= 256;
                 if (job_heavy && heavy_running) break;
-                // a free workspace: the biggest one for a bulk wave, the smallest for the others.  (Round 5: by slot parity - "this lane's
-                // first" - a bulk wave now and then landed on the workspace the long-tail waves had used so far and grew all its 43
-                // buffers to bulk size, 23.6 GB of hipMalloc in the middle of a stream of batches - one run in four of the bench, and
-                // one hipMalloc in a few hundred takes half a second.  By size the workspaces settle: three big ones, one small.)
+                // a free workspace.  The long-tail lane keeps workspace 0 to itself and the bulk lane the others; a lane whose own are all
+                // busy takes any free one - the biggest for a bulk wave, the smallest otherwise.  (Round 5: by slot parity - "this
+                // lane's first" - a bulk wave now and then landed on the workspace the long-tail waves had used so far and grew all
+                // its 43 buffers to bulk size: 23.6 GB of hipMalloc in the middle of a stream of batches, in one bench run out of four,
+                // and one hipMalloc in a few hundred takes SECONDS - measured 3.4 s, a run of 13 k sequences/s instead of 500 k.)
                 int w = -1;
-                for (int k = 0; k < MAX_PIPES; k++)
-                    if (!slot[k].wave && (w < 0 || (job_heavy ? g.ws[k].bytes() > g.ws[w].bytes() : g.ws[k].bytes() < g.ws[w].bytes()))) w = k;
+                auto better = [&](int k) { return w < 0 || (job_heavy ? g.ws[k].bytes() > g.ws[w].bytes() : g.ws[k].bytes() < g.ws[w].bytes()); };
+                for (int k = 0; k < MAX_PIPES; k++) if (!slot[k].wave && (tail_slot ? (k == 0) == (ln == 0) : true) && better(k)) w = k;
+                if (w < 0) for (int k = 0; k < MAX_PIPES; k++) if (!slot[k].wave && better(k)) w = k;
                 if (w < 0) break;
                 // continuous batching: queued jobs with the same parameters join this one (first regrowths stay alone)
                 Job job = std::move(front);
@@ -1748,7 +1783,20 @@ static void scheduler_main()
                     sl.wave.reset(new Wave(g.ws[w], sl.job.members, sl.job.seqs, sl.job.est));
                     sl.wave->depth = sl.job.depth;
                     sl.wave->big_prod = sl.job.big_prod || (big_prod_seen && same_params(big_prod_params, sl.job.members[0]->p));
+                    if (sl.job.members[0]->cfg.trace) fprintf(stderr, "[rafft] wave of %zu sequences (lane %d) takes workspace %d (%.1f GB held)\n", sl.job.seqs.size(), ln, w, (double)g.ws[w].bytes() / 1e9);
                     rc = sl.wave->setup();
+                    // A stream of batches (two or more in flight) will have `max_waves` bulk waves going at once: the bulk lane's other
+                    // workspaces are brought to this one's sizes NOW, while the stream is young, instead of whenever a third wave first
+                    // overlaps two others - 23.6 GB of hipMalloc at an arbitrary moment, and one hipMalloc in a few hundred takes
+                    // seconds (bench.py: a run in six allocated its third workspace inside the timed region, 300 k instead of 500 k).
+                    if (!rc && job_heavy && tail_slot && g.n_inflight >= 2) {
+                        size_t held = 0, add = 0;
+                        for (int k = 0; k < MAX_PIPES; k++) held += g.ws[k].bytes();
+                        for (int k = 1; k <= max_waves && k < MAX_PIPES; k++) if (k != w && !slot[k].wave && g.ws[k].bytes() < g.ws[w].bytes()) add += g.ws[w].bytes() - g.ws[k].bytes();
+                        if (add && held + add <= (size_t)((double)g.hbm_total * 0.5))
+                            for (int k = 1; k <= max_waves && k < MAX_PIPES && !rc; k++)
+                                if (k != w && !slot[k].wave && g.ws[k].bytes() < g.ws[w].bytes()) { rc = init_ws(g.ws[k]); if (!rc) rc = g.ws[k].match(g.ws[w]); }
+                    }
                     if (!rc) rc = sl.wave->issue_step();
                     // step-ahead: the materialize of the first step and the second step are queued at once (counts from the device,
                     // no size class merged away: the first steps are the big ones)

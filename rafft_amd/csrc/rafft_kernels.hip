@@ -1330,6 +1330,14 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
 
 // --------------------------------------------------------- beam step kernel
 
+// "this value is needed HERE": keeps the compiler from sinking a load below a branch that may not need it.  Loads issued back to
+// back are one round trip; a load sunk to its first use, behind an early exit, is a dependent round trip of its own.
+__device__ __forceinline__ void pin(unsigned int &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(int &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(unsigned long long &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(ulonglong2 &x) { asm volatile("" : "+v"(x.x), "+v"(x.y)); }
+__device__ __forceinline__ void pin(uint4 &x) { asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w)); }
+
 // (round 5: four slots per round trip.  A wavefront waits for the longest probe chain among its 64 lanes - at half load that was four or
 //  five dependent trips for a lookup whose expected length is 1.5; the four 16-byte loads are independent and mostly one 64-byte line.
 //  `free_sl`: the empty slot that ended the search - where seen_insert_at starts, every slot before it holds another key for good)
@@ -1340,7 +1348,8 @@ __device__ inline bool seen_lookup(const uint64_t *tab, uint32_t cap, uint64_t h
     const ulonglong2 *t2 = (const ulonglong2 *)tab;
     for (;;) {
         const uint32_t s1 = (sl + 1) & mask, s2 = (sl + 2) & mask, s3 = (sl + 3) & mask;
-        const ulonglong2 e0 = t2[sl], e1 = t2[s1], e2 = t2[s2], e3 = t2[s3];
+        ulonglong2 e0 = t2[sl], e1 = t2[s1], e2 = t2[s2], e3 = t2[s3];
+        pin(e0); pin(e1); pin(e2); pin(e3);           // (all four in flight: without this the compiler loads a slot when the one before did not decide)
         if (e0.x == 0) { free_sl = sl; return false; }
         if (e0.x == h1 && e0.y == h2) return true;
         if (e1.x == 0) { free_sl = s1; return false; }
@@ -1510,7 +1519,18 @@ __global__ __launch_bounds__(BS_NT, BS_NT == 256 ? 5 : 1) void beam_step_kernel(
             int ic = 0;
             if (b < nbeam) {
                 const int sid = oldbeam[b];
-                const StRec r = d.st[sid];                 // the whole row: one round trip
+                // the whole row, one round trip (seven 16-byte loads pinned: as a struct copy the compiler split it into the fields each
+                // branch below uses and loaded them there - two or three dependent trips)
+                StRec r;
+                {
+                    const uint4 *rp = (const uint4 *)&d.st[sid];
+                    uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3], q4 = rp[4], q5 = rp[5], q6 = rp[6];
+                    pin(q0); pin(q1); pin(q2); pin(q3); pin(q4); pin(q5); pin(q6);
+                    auto u64 = [](unsigned int lo, unsigned int hi) { return (unsigned long long)lo | ((unsigned long long)hi << 32); };
+                    r.dcal = (int)q0.y; r.node0 = (int)q0.z; r.nnodes = (int)q0.w; r.nprod = (int)q1.y; r.c0d = (int)q1.z;
+                    r.h1 = u64(q2.x, q2.y); r.h2 = u64(q2.z, q2.w); r.cursor = u64(q3.z, q3.w); r.total = u64(q4.z, q4.w);
+                    r.prod = u64(q5.x, q5.y); r.c0h1 = u64(q5.z, q5.w); r.c0h2 = u64(q6.x, q6.y);
+                }
                 ParentInfo pi;
                 pi.sid = sid; pi.rl0 = 0; pi.nrl = 0; pi.prod = 0; pi.nprod = 0; pi.total = 0; pi.cur = 0; pi.h1 = 0; pi.h2 = 0; pi.dcal0 = 0;
                 if (r.total && r.cursor >= r.total) pi.flag = 1;                       // product exhausted
@@ -1951,31 +1971,34 @@ __global__ __launch_bounds__(BS_NT, BS_NT == 256 ? 5 : 1) void beam_step_kernel(
     __syncthreads();
     if (sbase < 0) { d.done[sq] = 1; return; }
     int run = 0;
+    const int Lsq = d.seq_len[sq];
     for (int base = 0; base < nnew; base += BS_NT) {
         int i = base + tid, f = 0;
         uint32_t ord = 0;
         if (i < nnew) { ord = (uint32_t)skey[i]; f = (ord < (uint32_t)nchild) ? 1 : 0; }
+        // the child's record: five loads issued together, under way while the ranks below are counted (interleaved with the stores they
+        // feed they were three or four dependent round trips)
+        int c_dcal = 0;
+        unsigned int c_par = 0;
+        unsigned long long c_combo = 0;
+        ulonglong2 c_h = make_ulonglong2(0ULL, 0ULL);
+        if (f) {
+            const size_t c = chb + ord;
+            c_dcal = d.ch_dcal[c]; c_par = d.ch_parent[c]; c_combo = d.ch_combo[c]; c_h = *(const ulonglong2 *)&d.ch_h[2 * c];
+        }
         int tot, ex = block_exscan_flag<BS_NT>(f, sh, &tot);
         if (i < nnew) {
             if (f) {
-                int sid = sbase + run + ex;
-                size_t c = chb + ord;
-                d.st[sid].seq = sq;
-                d.st[sid].dcal = d.ch_dcal[c];
-                d.st[sid].h1 = d.ch_h[2 * c];
-                d.st[sid].h2 = d.ch_h[2 * c + 1];
-                d.st[sid].parent = oldbeam[d.ch_parent[c]];
-                d.st[sid].combo = d.ch_combo[c];
-                d.st[sid].cursor = 0;
-                d.st[sid].total = 0;
-                d.st[sid].nnodes = 0;
-                {
-                    const ParentInfo &pp_ = pinfo[d.ch_parent[c]];
-                    MatRec mr;
-                    mr.sid = sid; mr.sq = sq; mr.L = d.seq_len[sq]; mr.dcal = d.ch_dcal[c]; mr.nprod = pp_.nprod; mr.pad = 0;
-                    mr.combo = d.ch_combo[c]; mr.prod = pp_.prod; mr.pad2 = 0;
-                    d.mat[mbase + run + ex] = mr;
-                }
+                pin(c_dcal); pin(c_par); pin(c_combo); pin(c_h);
+                const int sid = sbase + run + ex;
+                const ParentInfo &pp_ = pinfo[c_par];
+                StRec *sr = &d.st[sid];
+                sr->seq = sq; sr->dcal = c_dcal; sr->h1 = c_h.x; sr->h2 = c_h.y; sr->parent = oldbeam[c_par]; sr->combo = c_combo;
+                sr->cursor = 0; sr->total = 0; sr->nnodes = 0;
+                MatRec mr;
+                mr.sid = sid; mr.sq = sq; mr.L = Lsq; mr.dcal = c_dcal; mr.nprod = pp_.nprod; mr.pad = 0;
+                mr.combo = c_combo; mr.prod = pp_.prod; mr.pad2 = 0;
+                d.mat[mbase + run + ex] = mr;
                 beam[i] = sid;
             } else
                 beam[i] = oldbeam[ord - nchild];
@@ -2573,6 +2596,20 @@ __global__ __launch_bounds__(DEDUPE_NT) void dedupe_kernel(Dev d)
 }
 
 // ------------------------------------------------------------- init kernel
+
+// The inputs of a wave, from its pinned staging chunk into the device buffers: up to eight segments copied by one kernel that reads
+// the host memory itself (hipHostMalloc memory is mapped into the device's address space).  Round 5: as hipMemcpyAsync calls the first
+// of these uploads now and then kept the scheduler thread - i.e. every wave in flight - for 12-19 ms (six bench runs in ten on one
+// box, the runtime's copy path waiting for something of its own); a kernel launch never waits.
+struct StageIn { const uint32_t *src[8]; uint32_t *dst[8]; unsigned long long words[8]; int n; };
+__global__ __launch_bounds__(256) void stage_in_kernel(StageIn si)
+{
+    for (int k = 0; k < si.n; k++) {
+        const uint32_t *src = si.src[k];
+        uint32_t *dst = si.dst[k];
+        for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < si.words[k]; i += (unsigned long long)gridDim.x * 256) dst[i] = src[i];
+    }
+}
 
 __global__ void init_roots_kernel(Dev d)
 {
