@@ -1793,7 +1793,10 @@ static void scheduler_main()
                         size_t held = 0, add = 0;
                         for (int k = 0; k < MAX_PIPES; k++) held += g.ws[k].bytes();
                         for (int k = 1; k <= max_waves && k < MAX_PIPES; k++) if (k != w && !slot[k].wave && g.ws[k].bytes() < g.ws[w].bytes()) add += g.ws[w].bytes() - g.ws[k].bytes();
-                        if (add && held + add <= (size_t)((double)g.hbm_total * 0.5))
+                        size_t free_b = 0, total_b = 0;
+                        if (add && hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+                        // (at most half of the card for this process, and at most half of what is free now: other processes share it)
+                        if (add && held + add <= (size_t)((double)g.hbm_total * 0.5) && add <= free_b / 2)
                             for (int k = 1; k <= max_waves && k < MAX_PIPES && !rc; k++)
                                 if (k != w && !slot[k].wave && g.ws[k].bytes() < g.ws[w].bytes()) { rc = init_ws(g.ws[k]); if (!rc) rc = g.ws[k].match(g.ws[w]); }
                     }
