@@ -37,6 +37,14 @@ __device__ __forceinline__ float2 cmulc(float2 a, float2 b) // a * conj(b)
     return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
 }
 
+// "this value is needed HERE": keeps the compiler from sinking a load below a branch that may not need it.  Loads issued back to
+// back are one round trip; a load sunk to its first use, behind an early exit, is a dependent round trip of its own.
+__device__ __forceinline__ void pin(unsigned int &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(int &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(unsigned long long &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(ulonglong2 &x) { asm volatile("" : "+v"(x.x), "+v"(x.y)); }
+__device__ __forceinline__ void pin(uint4 &x) { asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w)); }
+
 // exclusive prefix sum of one int per thread over the workgroup; returns total in *tot.
 // `scratch` needs (NT/64 + 1) ints of LDS.
 template <int NT>
@@ -1329,14 +1337,6 @@ __global__ __launch_bounds__(NT * WPB, (NT == 64 ? (WPB == 16 ? 4 : RAFFT_EXPAND
 #include "rafft_expand_small.hip"
 
 // --------------------------------------------------------- beam step kernel
-
-// "this value is needed HERE": keeps the compiler from sinking a load below a branch that may not need it.  Loads issued back to
-// back are one round trip; a load sunk to its first use, behind an early exit, is a dependent round trip of its own.
-__device__ __forceinline__ void pin(unsigned int &x) { asm volatile("" : "+v"(x)); }
-__device__ __forceinline__ void pin(int &x) { asm volatile("" : "+v"(x)); }
-__device__ __forceinline__ void pin(unsigned long long &x) { asm volatile("" : "+v"(x)); }
-__device__ __forceinline__ void pin(ulonglong2 &x) { asm volatile("" : "+v"(x.x), "+v"(x.y)); }
-__device__ __forceinline__ void pin(uint4 &x) { asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w)); }
 
 // (round 5: four slots per round trip.  A wavefront waits for the longest probe chain among its 64 lanes - at half load that was four or
 //  five dependent trips for a lookup whose expected length is 1.5; the four 16-byte loads are independent and mostly one 64-byte line.
@@ -2658,10 +2658,19 @@ __global__ void output_kernel(Dev d, int nrows, int nrec, const OutRec *recs, ch
         const int L = rc.L;
         for (int x = threadIdx.x; x < L; x += blockDim.x) out_row[x] = '.';
         __syncthreads();
-        for (int s = sid; s >= 0; s = d.st[s].parent) {          // (the unfolded structure has parent -1 and no pairs)
-            const uint32_t *pl = d.sp + d.st[s].sp;
-            const int np = d.st[s].nsp;
+        // the lineage, child to root (the unfolded structure has parent -1 and no pairs).  The next ancestor's row is asked for before
+        // this one's pairs are read: one dependent round trip per generation instead of two (a row of the benchmark set has 5-25)
+        int s = sid, par = -1, np = 0;
+        unsigned long long spo = 0;
+        if (s >= 0) { par = d.st[s].parent; np = d.st[s].nsp; spo = d.st[s].sp; }
+        while (s >= 0) {
+            const int s2 = par;
+            int par2 = -1, np2 = 0;
+            unsigned long long spo2 = 0;
+            if (s2 >= 0) { par2 = d.st[s2].parent; np2 = d.st[s2].nsp; spo2 = d.st[s2].sp; }
+            const uint32_t *pl = d.sp + spo;
             for (int x = threadIdx.x; x < np; x += blockDim.x) { const uint32_t u = pl[x]; out_row[u & 0xFFFFu] = '('; out_row[u >> 16] = ')'; }
+            s = s2; par = par2; np = np2; spo = spo2;
         }
         __syncthreads();
         char *o = out_db + rc.off + (long long)k * (L + 1);
