@@ -1690,7 +1690,7 @@ static void scheduler_main()
         // A caller that streams batches (two or more in flight) queues them microseconds apart: a bulk wave admitted the moment the
         // first one arrives would fold that one alone and the second wave whatever came in the meantime - three waves one after the
         // other (heavy phases do not overlap) where one merged wave would do.  So while submissions keep coming (the last one less
-        // than RAFFT_LINGER_US = 150 us ago) and the queues are below the merge cap, both lanes wait for them.  A lone synchronous
+        // than RAFFT_LINGER_US = 600 us ago) and the queues are below the merge cap, both lanes wait for them.  A lone synchronous
         // call never lingers.
         const long linger_us = scfg.linger_us;
         bool linger = false;

@@ -22,7 +22,7 @@ struct Config {
     double reserve_frac = 0.10;// RAFFT_RESERVE_FRAC  T  workspaces are reserved for the merge cap when that stays below this share of the HBM
     double est = 0.0;          // RAFFT_EST           H  arena estimate (survivors per beam slot); 0: from the lengths
     long merge_seqs = 16384;   // RAFFT_MERGE_SEQS    T  sequences one merged wave may hold
-    long linger_us = 150;      // RAFFT_LINGER_US     T  a stream of submissions is merged while they keep coming this close together
+    long linger_us = 600;      // RAFFT_LINGER_US     T  a stream of submissions is merged while they keep coming this close together (round 5: 150 -> 600 us - a Python caller queues a batch of the benchmark set every 250-300 us, and the first one of a burst was folded alone)
     long spin_us = 200, nap_us = 50; // RAFFT_SCHED_SPIN_US / RAFFT_SCHED_NAP_US  T  the scheduler thread polls this long after progress, then naps in slices
     double big_wave_frac = 0.10; // RAFFT_BIG_WAVE_FRAC T  waves whose arenas pass this share of the HBM run one at a time
     long test_cand_limit = 0;  // RAFFT_TEST_CAND_LIMIT H  lower the 31-bit limit of the candidate table (split path on small jobs)

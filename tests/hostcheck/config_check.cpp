@@ -11,7 +11,7 @@ int main()
     for (const char *v : vars) unsetenv(v);
     const Config d = read_config();
     CHECK(d.trace == 0 && d.spans == -1 && d.prod == 1 && d.small_n4 == 16 && d.small_n5 == 32 && d.merge_seqs == 16384 && d.max_waves == 3);
-    CHECK(d.linger_us == 150 && d.direct_n == 1024 && d.c3_direct == 1 && d.c3_switch == -1 && d.split == -1 && d.step_ahead == 0 && d.mat4 == 1);
+    CHECK(d.linger_us == 600 && d.direct_n == 1024 && d.c3_direct == 1 && d.c3_switch == -1 && d.split == -1 && d.step_ahead == 0 && d.mat4 == 1);
     CHECK(d.test_ovf_at == -1 && d.test_hard_fail == -1 && d.rl_cap == -1 && d.est == 0.0 && d.no_harvest == 0 && d.reserve_frac == 0.10);
     CHECK(same_config(d, read_config()));
     setenv("RAFFT_TRACE", "", 1);                 // set to anything: at least the summaries
