@@ -2494,13 +2494,34 @@ __global__ __launch_bounds__(64, RAFFT_MAT_WAVES) void materialize_team_kernel(D
 
 // ------------------------------------------------------------ dedupe kernel
 
-__device__ inline bool same_loop(const Dev &d, int a, int b)
+// a region header as four 16-byte words, loaded together: seq pdcal n ci | cj nbr ncand L | pos br | cand soff
+struct NodeWords { uint4 q0, q1, q2; };
+__device__ __forceinline__ NodeWords load_node_words(const Dev &d, int nid)
 {
-    if (d.nd[a].seq != d.nd[b].seq || d.nd[a].ci != d.nd[b].ci || d.nd[a].cj != d.nd[b].cj ||
-        d.nd[a].nbr != d.nd[b].nbr || d.nd[a].n != d.nd[b].n) return false;
-    const uint32_t *x = d.br + d.nd[a].br, *y = d.br + d.nd[b].br;
-    for (int i = 0, k = d.nd[a].nbr; i < k; i++)
-        if (x[i] != y[i]) return false;
+    const uint4 *hp = (const uint4 *)&d.nd[nid];
+    NodeWords w;
+    w.q0 = hp[0]; w.q1 = hp[1]; w.q2 = hp[2];
+    pin(w.q0); pin(w.q1); pin(w.q2);
+    return w;
+}
+// (round 5: the other region's header in one round trip and the branch lists four entries at a time - field by field, each
+//  comparison behind the one before, this was seven dependent round trips)
+__device__ inline bool same_loop(const Dev &d, const NodeWords &a, int b)
+{
+    const NodeWords o = load_node_words(d, b);
+    // seq, n, ci | cj, nbr
+    if (a.q0.x != o.q0.x || a.q0.z != o.q0.z || a.q0.w != o.q0.w || a.q1.x != o.q1.x || a.q1.y != o.q1.y) return false;
+    const uint32_t *x = d.br + ((unsigned long long)a.q2.z | ((unsigned long long)a.q2.w << 32));
+    const uint32_t *y = d.br + ((unsigned long long)o.q2.z | ((unsigned long long)o.q2.w << 32));
+    const int k = (int)a.q1.y;
+    for (int i = 0; i < k; i += 4) {
+        unsigned int xa[4], ya[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { xa[u] = i + u < k ? x[i + u] : 0u; ya[u] = i + u < k ? y[i + u] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { pin(xa[u]); pin(ya[u]); }
+        if (xa[0] != ya[0] || xa[1] != ya[1] || xa[2] != ya[2] || xa[3] != ya[3]) return false;
+    }
     return true;
 }
 
@@ -2539,11 +2560,23 @@ __global__ __launch_bounds__(DEDUPE_NT) void dedupe_kernel(Dev d)
             while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (pre[mid] <= f) lo = mid; else hi = mid; }
             nid = (int)(d.nd_base + (unsigned long long)lo * d.nd_shard_cap + prev[lo] + (f - pre[lo]));
             int canon = nid;
+            // the header once, in one round trip (round 5: as single fields it was loaded in three trips here and AGAIN field by field
+            // after the table look-up - the compiler cannot keep a loaded value across the compare-and-swap and the stores between)
+            const NodeWords hw = load_node_words(d, nid);
+            const int h_seq = (int)hw.q0.x, h_n = (int)hw.q0.z, h_ci = (int)hw.q0.w, h_cj = (int)hw.q1.x, h_nbr = (int)hw.q1.y, h_L = (int)hw.q1.w;
             if (d.memo) {
-                const uint32_t *bb = d.br + d.nd[nid].br;
-                const int nbr = d.nd[nid].nbr;
-                uint64_t h = mix64(((uint64_t)(uint32_t)d.nd[nid].seq << 32) ^ ((uint64_t)(uint32_t)(d.nd[nid].ci + 1) << 16) ^ (uint32_t)d.nd[nid].cj);
-                for (int t = 0; t < nbr; t++) h += mix64((uint64_t)bb[t] ^ 0x5bd1e9955bd1e995ULL);
+                const uint32_t *bb = d.br + ((unsigned long long)hw.q2.z | ((unsigned long long)hw.q2.w << 32));
+                const int nbr = h_nbr;
+                uint64_t h = mix64(((uint64_t)(uint32_t)h_seq << 32) ^ ((uint64_t)(uint32_t)(h_ci + 1) << 16) ^ (uint32_t)h_cj);
+                for (int t = 0; t < nbr; t += 4) {           // (four branch helices per round trip)
+                    unsigned int bv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) bv[u] = t + u < nbr ? bb[t + u] : 0u;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) pin(bv[u]);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) if (t + u < nbr) h += mix64((uint64_t)bv[u] ^ 0x5bd1e9955bd1e995ULL);
+                }
                 const unsigned long long tag = (h >> 32) | 0x80000000ULL;
                 const uint64_t mask = d.looptab_cap - 1;
                 uint64_t sl = h & mask;
@@ -2552,7 +2585,7 @@ __global__ __launch_bounds__(DEDUPE_NT) void dedupe_kernel(Dev d)
                     if (old == 0) break;
                     if ((old >> 32) == tag) {
                         int other = (int)(old & 0xffffffffULL) - 1;
-                        if (same_loop(d, nid, other)) { canon = other; break; }
+                        if (same_loop(d, hw, other)) { canon = other; break; }
                     }
                     sl = (sl + 1) & mask;
                     if (probe > d.looptab_cap) { atomicOr(&d.c->overflow, OVF_LOOPTAB); break; }
@@ -2560,12 +2593,12 @@ __global__ __launch_bounds__(DEDUPE_NT) void dedupe_kernel(Dev d)
             }
             if (canon == nid) {
                 // a stem needs two unpaired positions: a lone position (bulge remnant) has no candidates
-                const int n = d.nd[nid].n;
+                const int n = h_n;
                 if (n < 2) d.nd[nid].ncand = 0;
                 else {
                     // (sequences beyond 4096 nt keep out of the one-wavefront class whatever the span: see expand_kernel's Sl)
-                    const int Ls = d.nd[nid].L, span = (d.nd[nid].ci < 0 || Ls > LDS_SEQ) ? Ls : d.nd[nid].cj + 1 - d.nd[nid].ci;
-                    cls = node_class(n, span, d.nd[nid].nbr, d.merge_cls, d.cls1_P, d.cls1_br, d.K, d.sm_n4, d.sm_n5);
+                    const int Ls = h_L, span = (h_ci < 0 || Ls > LDS_SEQ) ? Ls : h_cj + 1 - h_ci;
+                    cls = node_class(n, span, h_nbr, d.merge_cls, d.cls1_P, d.cls1_br, d.K, d.sm_n4, d.sm_n5);
                 }
             }
             else { ((uint32_t *)d.cslot)[d.nd_slot[nid]] = (uint32_t)(canon + 1) | 0x80000000u; aliases++; }      // (the loop is known - reached along another path: the slot points at it)
