@@ -79,7 +79,7 @@ static_assert(sizeof(NodeRec) == 64, "NodeRec must be one cache line");
 
 struct ProdEnt { uint32_t cnt; int32_t node; uint64_t off; };   // one productive region of a structure
 // one new beam member to materialize: everything materialize_kernel needs to start, in one 48-byte read
-struct alignas(16) MatRec { int32_t sid, sq, L, dcal, nprod, pad; uint64_t combo, prod, pad2; };
+struct alignas(16) MatRec { int32_t sid, sq, L, dcal, nprod, pad; uint64_t combo, prod, soff; };     // (soff: the sequence's offset into the base codes - one look-up less in the materialize kernels)
 
 struct Counters {
     // hot part: read back by the host once per folding step.  Every counter that the kernels of a step add to with a RETURNING atomic

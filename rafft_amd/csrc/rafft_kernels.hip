@@ -1972,6 +1972,7 @@ __global__ __launch_bounds__(BS_NT, BS_NT == 256 ? 5 : 1) void beam_step_kernel(
     if (sbase < 0) { d.done[sq] = 1; return; }
     int run = 0;
     const int Lsq = d.seq_len[sq];
+    const unsigned long long soff_sq = (unsigned long long)d.seq_off[sq];
     for (int base = 0; base < nnew; base += BS_NT) {
         int i = base + tid, f = 0;
         uint32_t ord = 0;
@@ -1997,7 +1998,7 @@ __global__ __launch_bounds__(BS_NT, BS_NT == 256 ? 5 : 1) void beam_step_kernel(
                 sr->cursor = 0; sr->total = 0; sr->nnodes = 0;
                 MatRec mr;
                 mr.sid = sid; mr.sq = sq; mr.L = Lsq; mr.dcal = c_dcal; mr.nprod = pp_.nprod; mr.pad = 0;
-                mr.combo = c_combo; mr.prod = pp_.prod; mr.pad2 = 0;
+                mr.combo = c_combo; mr.prod = pp_.prod; mr.soff = soff_sq;
                 d.mat[mbase + run + ex] = mr;
                 beam[i] = sid;
             } else
@@ -2159,7 +2160,7 @@ __global__ __launch_bounds__(MAT_NT, RAFFT_MAT_WAVES) void materialize_kernel(De
 #define MSTAMP(k) do { if (mprof) { const unsigned long long tn_ = clock64(); macc[k] += tn_ - mt; mt = tn_; } } while (0)
     const MatRec rec = d.mat[blockIdx.x];              // written by the beam step: no chain of look-ups to get started
     const int sid = rec.sid, sq = rec.sq, L = rec.L, my_dcal = rec.dcal;
-    const uint64_t soff = (uint64_t)d.seq_off[sq];
+    const uint64_t soff = rec.soff;
     const int pmask = d.pos_packed ? 0x0FFF : 0xFFFF;
     int mprod = rec.nprod;
     if (mprod > d.max_prod) mprod = d.max_prod;
@@ -2348,10 +2349,10 @@ __global__ __launch_bounds__(64, RAFFT_MAT_WAVES) void materialize_team_kernel(D
     const int mat_i = mat_i0 + team;
     const bool live = mat_i < n_mat;
     MatRec rec;
-    rec.sid = 0; rec.sq = 0; rec.L = 0; rec.dcal = 0; rec.nprod = 0; rec.combo = 0; rec.prod = 0; rec.pad2 = 0;
+    rec.sid = 0; rec.sq = 0; rec.L = 0; rec.dcal = 0; rec.nprod = 0; rec.combo = 0; rec.prod = 0; rec.soff = 0;
     if (live) rec = d.mat[mat_i];
     const int sid = rec.sid, sq = rec.sq, L = rec.L, my_dcal = rec.dcal;
-    const uint64_t soff = live ? (uint64_t)d.seq_off[sq] : 0;
+    const uint64_t soff = rec.soff;
     const int pmask = d.pos_packed ? 0x0FFF : 0xFFFF;
     int mprod = rec.nprod;
     if (mprod > MAT4_PROD) mprod = MAT4_PROD;
