@@ -509,8 +509,13 @@ Caps plan_caps(const Config &cfg, size_t S, size_t sumL, const rafft_params &p, 
     // (measured, ms 50, max_branch 1000, regions abandoned by rehashing included: the benchmark set's bulk uses 4.6 x est x
     //  (B + max_branch / 4) slots per sequence, its two 2.9-knt sequences 11.6 x.  A factor of 24 used to reserve 1 MB per
     //  sequence - 12 GB for a merged wave of five batches, and a hipMalloc of that size now and then took seconds.)
-    double per_seq_seen = std::min(std::max(14.0 * est * ((double)B + (double)p.max_branch / 4.0), 16384.0), 16777216.0);
-    c.seen = (size_t)((double)S * seen0_per_seq) + (size_t)((double)S * per_seq_seen);
+    // (round 5: the initial tables are sized from the lengths - seen_slots0 - and a table rarely grows any more: the reserve for growth
+    //  went from 14 x to 5 x est x (B + max_branch / 4), at least as much again as the initial tables.  At 14 x the arena was 10.6 GB of
+    //  a merge-cap plan of 33.7 GB - above the tenth of the HBM up to which a first wave reserves its workspace for the merge cap, so
+    //  every bigger wave of a stream re-allocated two dozen buffers; at 5 x the plan is 28.5 GB and the first wave's workspace holds them all.)
+    double per_seq_seen = std::min(std::max(std::max(5.0 * est * ((double)B + (double)p.max_branch / 4.0), seen0_per_seq), 16384.0), 16777216.0);
+    // (a floor of 4 M slots - 64 MB - whatever the batch: a few long sequences among sixty short ones double their tables twice)
+    c.seen = (size_t)((double)S * seen0_per_seq) + std::max((size_t)((double)S * per_seq_seen), (size_t)4 << 20);
     c.trec = p.traj ? S * (size_t)(est * 3 + 16) : S + 16;
     c.tsid = c.trec * B + 16;
     c.mat = S * B + 16;
@@ -1789,16 +1794,18 @@ static void scheduler_main()
                     // workspaces are brought to this one's sizes NOW, while the stream is young, instead of whenever a third wave first
                     // overlaps two others - 23.6 GB of hipMalloc at an arbitrary moment, and one hipMalloc in a few hundred takes
                     // seconds (bench.py: a run in six allocated its third workspace inside the timed region, 300 k instead of 500 k).
+                    // Only workspaces that are not bulk-sized yet (less than a quarter of this one): one that merely lags behind a
+                    // workspace that grew for some wave is left alone - following it would put 2 x 47 GB of hipMalloc into the stream.
                     if (!rc && job_heavy && tail_slot && g.n_inflight >= 2) {
                         size_t held = 0, add = 0;
                         for (int k = 0; k < MAX_PIPES; k++) held += g.ws[k].bytes();
-                        for (int k = 1; k <= max_waves && k < MAX_PIPES; k++) if (k != w && !slot[k].wave && g.ws[k].bytes() < g.ws[w].bytes()) add += g.ws[w].bytes() - g.ws[k].bytes();
+                        for (int k = 1; k <= max_waves && k < MAX_PIPES; k++) if (k != w && !slot[k].wave && g.ws[k].bytes() < g.ws[w].bytes() / 4) add += g.ws[w].bytes() - g.ws[k].bytes();
                         size_t free_b = 0, total_b = 0;
                         if (add && hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
                         // (at most half of the card for this process, and at most half of what is free now: other processes share it)
                         if (add && held + add <= (size_t)((double)g.hbm_total * 0.5) && add <= free_b / 2)
                             for (int k = 1; k <= max_waves && k < MAX_PIPES && !rc; k++)
-                                if (k != w && !slot[k].wave && g.ws[k].bytes() < g.ws[w].bytes()) { rc = init_ws(g.ws[k]); if (!rc) rc = g.ws[k].match(g.ws[w]); }
+                                if (k != w && !slot[k].wave && g.ws[k].bytes() < g.ws[w].bytes() / 4) { rc = init_ws(g.ws[k]); if (!rc) rc = g.ws[k].match(g.ws[w]); }
                     }
                     if (!rc) rc = sl.wave->issue_step();
                     // step-ahead: the materialize of the first step and the second step are queued at once (counts from the device,
