@@ -1520,7 +1520,7 @@ static void free_garbage()
     for (void *p : junk) { hipError_t e_ = hipFree(p); (void)e_; }
 }
 
-// Nothing in flight: workspaces that grew beyond a quarter of the HBM for some huge batch are given back (other processes
+// Nothing in flight: workspaces that grew beyond two fifths of the HBM for some huge batch are given back (other processes
 // may share the card; the next batch allocates what it needs).
 static void trim_workspaces()
 {
@@ -1528,7 +1528,7 @@ static void trim_workspaces()
     if (!lk.owns_lock()) return;              // a seam call is using workspace 0 right now
     size_t held = 0;
     for (int i = 0; i < MAX_PIPES; i++) held += g.ws[i].bytes();
-    if (held <= g.hbm_total / 4) return;
+    if (held <= g.hbm_total / 5 * 2) return;       // (round 5: 2/5 of the card, a quarter until then - a stream's three bulk workspaces, sized for the merge cap at once, are 96 GB and stay)
     for (int i = 0; i < MAX_PIPES; i++) g.ws[i].release_buffers();
 }
 
