@@ -398,3 +398,23 @@ def test_gpu_seen_tables_sized_from_the_length_and_grown(monkeypatch):
     monkeypatch.setenv("RAFFT_SEEN_FIXED", "1")
     wide_fixed = rafft_amd.fold_batch(seqs[:8], 100, 150, 1000)
     assert [[(x.str_struct, x.dcal) for x in f] for f in wide] == [[(x.str_struct, x.dcal) for x in f] for f in wide_fixed]
+
+
+def test_gpu_beam_wider_than_the_workgroup_vs_oracle(monkeypatch):
+    """round 5: the beam step's flat prepass reads one structure row per thread and numbers the (member, region) items by a prefix sum
+    over the members - a beam wider than the workgroup takes several rounds of both (256-thread kernel forced with RAFFT_WIDE_BELOW=0,
+    max_stack 300 and 700; the 1024-thread kernel at max_stack 1100): final beams equal the oracle's"""
+    rng = np.random.default_rng(4242)
+    seqs = ["".join(rng.choice(list("ACGU"), int(L))) for L in (70, 90, 110, 130, 150, 180)]
+    from _oracle_pool import fold_many
+    for ms, wide_below in ((300, "0"), (700, "0"), (1100, None)):
+        if wide_below is None:
+            monkeypatch.delenv("RAFFT_WIDE_BELOW", raising=False)
+        else:
+            monkeypatch.setenv("RAFFT_WIDE_BELOW", wide_below)
+        sub = seqs if ms == 300 else seqs[:3]
+        want = fold_many([(s, 100, ms, 1000, False) for s in sub])
+        got = rafft_amd.fold_batch(sub, 100, ms, 1000)
+        for k in range(len(sub)):
+            assert [(x.str_struct, x.dcal) for x in got[k]] == want[k], (ms, k)
+        assert max(len(g) for g in got) > 256 or ms == 300
